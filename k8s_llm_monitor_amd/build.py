@@ -1,0 +1,149 @@
+"""In-tree native build for gfx950 (MI355X).
+
+Compiles every HIP/C++ source of the package with explicit ``hipcc`` / ``g++`` command
+lines (no JIT cache, no pip install): the built ``.so`` and executables stay inside the
+package directory so that they travel with a ``gpurun`` snapshot and show up as in-tree
+native code in the loader's ``/proc/self/maps``.
+
+The reference has no build step at all (it is two interpreted files);
+this module exists because the MI355X validation toolkit is native.
+
+Usage::
+
+    python -m k8s_llm_monitor_amd.build            # build what is stale
+    python -m k8s_llm_monitor_amd.build --force    # rebuild everything
+    python -m k8s_llm_monitor_amd.build --list     # show targets
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+PKG = Path(__file__).resolve().parent
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+ARCH = "gfx950"
+BIN_DIR = PKG / "_native" / "bin"
+LIB_DIR = PKG / "_native" / "lib"
+
+
+@dataclass
+class Target:
+    name: str
+    out: Path
+    sources: List[Path]
+    kind: str  # "hip-shared" | "hip-exe" | "cxx-exe"
+    extra: List[str] = field(default_factory=list)
+    deps: List[Path] = field(default_factory=list)  # headers etc. for staleness
+
+    def stale(self) -> bool:
+        if not self.out.exists():
+            return True
+        t = self.out.stat().st_mtime
+        return any(p.exists() and p.stat().st_mtime > t for p in [*self.sources, *self.deps])
+
+
+def hipcc() -> Optional[str]:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), str(ROCM / "bin" / "hipcc")):
+        if c and Path(c).exists():
+            return c
+    return None
+
+
+def targets() -> List[Target]:
+    ops = PKG / "ops" / "csrc"
+    hdr = ops / "klm_ops.h"
+    ops_src = [ops / "gemm_bf16.hip", ops / "gemm_fp8.hip", ops / "hbm.hip"]
+    ops_src = [s for s in ops_src if s.exists()]
+    out: List[Target] = [
+        Target("klm_ops", LIB_DIR / "libklm_ops.so", ops_src, "hip-shared", deps=[hdr]),
+    ]
+    burner = PKG / "loadgen" / "native" / "klm_burner.cpp"
+    if burner.exists():
+        out.append(Target("klm_burner", BIN_DIR / "klm_burner", [burner, *ops_src], "hip-exe",
+                          extra=[f"-I{ops}"], deps=[hdr]))
+    probe = PKG / "parallel" / "csrc" / "rccl_probe.cpp"
+    if probe.exists():
+        out.append(Target("klm_rccl_probe", BIN_DIR / "klm_rccl_probe", [probe], "hip-exe",
+                          extra=[f"-I{ROCM}/include/rccl", f"-L{ROCM}/lib", "-lrccl",
+                                 f"-Wl,-rpath,{ROCM}/lib", "-lpthread"]))
+    smi = PKG / "collectors" / "native" / "amdsmi_sampler.cpp"
+    if smi.exists():
+        out.append(Target("klm_amdsmi_sampler", BIN_DIR / "klm_amdsmi_sampler", [smi], "cxx-exe",
+                          extra=[f"-I{ROCM}/include", f"-L{ROCM}/lib", "-lamd_smi",
+                                 f"-Wl,-rpath,{ROCM}/lib", "-lpthread"]))
+    return out
+
+
+def _cmd(t: Target) -> List[str]:
+    srcs = [str(s) for s in t.sources]
+    if t.kind in ("hip-shared", "hip-exe"):
+        cc = hipcc()
+        if cc is None:
+            raise RuntimeError("hipcc not found (set HIPCC or ROCM_PATH)")
+        base = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function",
+                "-x", "hip"]
+        if t.kind == "hip-shared":
+            base += ["-shared", "-fPIC"]
+        return [*base, *srcs, "-o", str(t.out), *t.extra]
+    if t.kind == "cxx-exe":
+        cxx = shutil.which("g++") or shutil.which("c++") or "g++"
+        return [cxx, "-O2", "-std=c++17", "-Wall", *srcs, "-o", str(t.out), *t.extra]
+    raise ValueError(t.kind)
+
+
+def build_target(t: Target, force: bool = False, verbose: bool = True) -> bool:
+    """Build one target. Returns True when a compile ran."""
+    if not force and not t.stale():
+        return False
+    t.out.parent.mkdir(parents=True, exist_ok=True)
+    cmd = _cmd(t)
+    if verbose:
+        print("[build]", t.name, "->", t.out.relative_to(PKG.parent), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"build of {t.name} failed:\n{' '.join(cmd)}\n{r.stdout}")
+    if verbose and r.stdout.strip():
+        print(r.stdout)
+    return True
+
+
+def build_all(force: bool = False, only: Optional[Sequence[str]] = None, verbose: bool = True) -> List[str]:
+    built = []
+    for t in targets():
+        if only and t.name not in only:
+            continue
+        if build_target(t, force=force, verbose=verbose):
+            built.append(t.name)
+    return built
+
+
+def artifact(name: str) -> Path:
+    for t in targets():
+        if t.name == name:
+            return t.out
+    raise KeyError(name)
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--list", action="store_true")
+    ap.add_argument("targets", nargs="*")
+    a = ap.parse_args(argv)
+    if a.list:
+        for t in targets():
+            print(f"{t.name:22s} {t.kind:10s} {'stale' if t.stale() else 'ok':5s} {t.out}")
+        return 0
+    built = build_all(force=a.force, only=a.targets or None)
+    print("built:", ", ".join(built) if built else "(nothing stale)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,177 @@
+"""Python bindings of the hand-written gfx950 kernels (``libklm_ops.so``, C ABI, ctypes).
+
+The kernels take raw device pointers and a HIP stream, so they run on PyTorch-ROCm
+tensors and on the current torch stream without a torch C++ extension. There is no
+PyTorch fallback: on a machine with a GPU a missing library is an error, never a silent
+eager path (the library can be built in-tree with ``python -m k8s_llm_monitor_amd.build``).
+
+No reference counterpart: the reference has no native code; these are the
+load generators of SURVEY.md 2.4 (N2 GEMM burner, N3 HBM fill, N4 bandwidth burner).
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from pathlib import Path
+from typing import Optional
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "_native" / "lib" / "libklm_ops.so"
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+
+STATUS = {0: "ok", -1: "shape not a multiple of the tile", -2: "pointer not 16-byte aligned",
+          -3: "unknown variant", -4: "HIP launch error", -5: "bad argument"}
+
+
+class KlmOpsError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def available() -> bool:
+    """True when the compiled library exists (it may still need a GPU to run)."""
+    return _LIB_PATH.exists()
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load ``libklm_ops.so``; build it with hipcc when it is missing. Raises if neither works."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not _LIB_PATH.exists() and build_if_missing:
+            from .. import build as _build
+            _build.build_all(only=["klm_ops"], verbose=False)
+        if not _LIB_PATH.exists():
+            raise KlmOpsError(f"{_LIB_PATH} is missing: run `python -m k8s_llm_monitor_amd.build`")
+        lib = ctypes.CDLL(str(_LIB_PATH))
+        vp, i, sz, u32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64
+        lib.klm_gemm_bf16.argtypes = [vp, vp, vp, i, i, i, i, vp]
+        lib.klm_gemm_bf16.restype = i
+        if hasattr(lib, "klm_gemm_fp8"):
+            lib.klm_gemm_fp8.argtypes = [vp, vp, vp, i, i, i, i, vp]
+            lib.klm_gemm_fp8.restype = i
+        lib.klm_hbm_fill.argtypes = [vp, sz, u32, vp]
+        lib.klm_hbm_fill.restype = i
+        lib.klm_hbm_copy.argtypes = [vp, vp, sz, vp]
+        lib.klm_hbm_copy.restype = i
+        lib.klm_hbm_read.argtypes = [vp, sz, vp, vp]
+        lib.klm_hbm_read.restype = i
+        lib.klm_hbm_checksum.argtypes = [vp, sz, vp, vp]
+        lib.klm_hbm_checksum.restype = i
+        lib.klm_spin.argtypes = [u64, i, vp]
+        lib.klm_spin.restype = i
+        lib.klm_version.restype = ctypes.c_char_p
+        _lib = lib
+        return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise KlmOpsError(f"{what}: {STATUS.get(rc, rc)} (status {rc})")
+
+
+def _stream(t) -> int:
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_cuda(*ts) -> None:
+    for t in ts:
+        if not t.is_cuda:
+            raise KlmOpsError("klm ops run on the GPU only (tensor is on %s)" % t.device)
+        if not t.is_contiguous():
+            raise KlmOpsError("klm ops need contiguous tensors")
+
+
+def version() -> str:
+    return load().klm_version().decode()
+
+
+def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
+    """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
+
+    variant None picks the 256x256 ring kernel when the shape allows, else the 128x128 one.
+    """
+    import torch
+    _require_cuda(a, b)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise KlmOpsError("gemm_bf16 needs bfloat16 inputs")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise KlmOpsError(f"gemm_bf16 shapes {tuple(a.shape)} x {tuple(b.shape)}^T do not match")
+    M, K = a.shape
+    N = b.shape[0]
+    if variant is None:
+        variant = 1 if (M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128) else 0
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    else:
+        _require_cuda(out)
+        if out.shape != (M, N) or out.dtype != torch.bfloat16:
+            raise KlmOpsError("gemm_bf16: bad `out`")
+    rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+    _check(rc, f"klm_gemm_bf16(M={M},N={N},K={K},variant={variant})")
+    return out
+
+
+def gemm_fp8(a, b, out=None, variant: int = 0):
+    """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the MX-scaled MFMA."""
+    import torch
+    _require_cuda(a, b)
+    if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
+        raise KlmOpsError("gemm_fp8 needs float8_e4m3fn (OCP) inputs")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise KlmOpsError("gemm_fp8 shapes do not match")
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    lib = load()
+    if not hasattr(lib, "klm_gemm_fp8"):
+        raise KlmOpsError("libklm_ops.so was built without the fp8 kernel")
+    rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+    _check(rc, f"klm_gemm_fp8(M={M},N={N},K={K})")
+    return out
+
+
+def _nbytes(t) -> int:
+    return t.numel() * t.element_size()
+
+
+def hbm_fill(t, pattern: int = 0xA5A5A5A5):
+    """Write `pattern` (32-bit) over the whole tensor with streaming 16-byte stores."""
+    _require_cuda(t)
+    _check(load().klm_hbm_fill(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, _stream(t)), "klm_hbm_fill")
+    return t
+
+
+def hbm_copy(dst, src):
+    _require_cuda(dst, src)
+    if _nbytes(dst) != _nbytes(src):
+        raise KlmOpsError("hbm_copy: size mismatch")
+    _check(load().klm_hbm_copy(dst.data_ptr(), src.data_ptr(), _nbytes(src), _stream(src)), "klm_hbm_copy")
+    return dst
+
+
+def hbm_read(src, sink):
+    _require_cuda(src, sink)
+    _check(load().klm_hbm_read(src.data_ptr(), _nbytes(src), sink.data_ptr(), _stream(src)), "klm_hbm_read")
+
+
+def hbm_checksum(src) -> int:
+    """Sum of the tensor's 32-bit words (mod 2^64); synchronises to return the value."""
+    import torch
+    _require_cuda(src)
+    acc = torch.zeros(1, dtype=torch.int64, device=src.device)
+    _check(load().klm_hbm_checksum(src.data_ptr(), _nbytes(src), acc.data_ptr(), _stream(src)),
+           "klm_hbm_checksum")
+    return int(acc.item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def spin(cycles: int, blocks: int = 256, device=None):
+    import torch
+    s = torch.cuda.current_stream(device).cuda_stream
+    _check(load().klm_spin(int(cycles), int(blocks), s), "klm_spin")

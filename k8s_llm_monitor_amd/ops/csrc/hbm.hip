@@ -1,0 +1,149 @@
+// HBM load kernels for MI355X (gfx950): fill (write-only), copy (read+write), read-only
+// stream, checksum and a traffic-free spin. SURVEY.md 2.4 N3 (HBM fill / exhaustion
+// injector) and N4 (HBM bandwidth burner); no reference counterpart.
+//
+// All of them are grid-stride loops over 16-byte words with the grid capped at
+// 256 CUs x 8 blocks, 256 threads per block (4 waves of 64), 4 independent 16-byte
+// accesses in flight per lane per iteration.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "klm_ops.h"
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+static constexpr int kBlock = 256;
+static constexpr int kMaxGrid = 256 * 8;
+static constexpr int kUnroll = 4;
+
+static inline int grid_for(size_t n16) {
+  size_t per_block = (size_t)kBlock * kUnroll;
+  size_t g = (n16 + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > (size_t)kMaxGrid) g = kMaxGrid;
+  return (int)g;
+}
+
+__global__ __launch_bounds__(kBlock) void hbm_fill_kernel(u32x4* __restrict__ dst, size_t n16,
+                                                          uint32_t pattern) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  const u32x4 v = {pattern, pattern, pattern, pattern};
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + (kUnroll - 1) * stride < n16; i += kUnroll * stride) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) __builtin_nontemporal_store(v, dst + i + u * stride);
+  }
+  for (; i < n16; i += stride) __builtin_nontemporal_store(v, dst + i);
+}
+
+__global__ __launch_bounds__(kBlock) void hbm_copy_kernel(u32x4* __restrict__ dst,
+                                                          const u32x4* __restrict__ src, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + (kUnroll - 1) * stride < n16; i += kUnroll * stride) {
+    u32x4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+// Read-only stream. The XOR of everything read is written once per block only when it
+// equals a value it (practically) never has, which keeps the loads alive without a store
+// stream of its own.
+__global__ __launch_bounds__(kBlock) void hbm_read_kernel(const u32x4* __restrict__ src, size_t n16,
+                                                          uint32_t* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+  for (; i + (kUnroll - 1) * stride < n16; i += kUnroll * stride) {
+    u32x4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) acc ^= v[u];
+  }
+  for (; i < n16; i += stride) acc ^= src[i];
+  const uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+  if (x == 0xA5C3F00Du) sink[0] = x;
+}
+
+__global__ __launch_bounds__(kBlock) void hbm_checksum_kernel(const u32x4* __restrict__ src,
+                                                              size_t n16,
+                                                              unsigned long long* __restrict__ sum) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  unsigned long long s = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) {
+    const u32x4 v = src[i];
+    s += (unsigned long long)v[0] + v[1] + v[2] + v[3];
+  }
+  // wave reduction (64 lanes), then one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(sum, s);
+}
+
+// Busy without memory traffic or matrix work: every wave spins on the shader clock until
+// `cycles` ticks have passed. The exit condition depends only on the wave's own clock
+// reads, so every wave reaches it.
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long cycles) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+
+static inline int check(const void* a, const void* b, size_t bytes) {
+  if (!a) return KLM_ERR_ARG;
+  if (((uintptr_t)a | (uintptr_t)b) & 15) return KLM_ERR_ALIGN;
+  if (bytes == 0 || (bytes & 15)) return KLM_ERR_SHAPE;
+  return KLM_OK;
+}
+
+static inline int done() { return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP; }
+
+extern "C" int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream) {
+  if (int e = check(dst, nullptr, bytes)) return e;
+  const size_t n16 = bytes >> 4;
+  hipLaunchKernelGGL(hbm_fill_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (u32x4*)dst, n16, pattern);
+  return done();
+}
+
+extern "C" int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stream) {
+  if (!src) return KLM_ERR_ARG;
+  if (int e = check(dst, src, bytes)) return e;
+  const size_t n16 = bytes >> 4;
+  hipLaunchKernelGGL(hbm_copy_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (u32x4*)dst, (const u32x4*)src, n16);
+  return done();
+}
+
+extern "C" int klm_hbm_read(const void* src, size_t bytes, void* sink8, void* stream) {
+  if (!sink8) return KLM_ERR_ARG;
+  if (int e = check(src, nullptr, bytes)) return e;
+  const size_t n16 = bytes >> 4;
+  hipLaunchKernelGGL(hbm_read_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const u32x4*)src, n16, (uint32_t*)sink8);
+  return done();
+}
+
+extern "C" int klm_hbm_checksum(const void* src, size_t bytes, void* sum64, void* stream) {
+  if (!sum64 || ((uintptr_t)sum64 & 7)) return KLM_ERR_ARG;
+  if (int e = check(src, nullptr, bytes)) return e;
+  const size_t n16 = bytes >> 4;
+  hipLaunchKernelGGL(hbm_checksum_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+                     (const u32x4*)src, n16, (unsigned long long*)sum64);
+  return done();
+}
+
+extern "C" int klm_spin(uint64_t cycles, int blocks, void* stream) {
+  if (blocks <= 0 || blocks > 65536) return KLM_ERR_ARG;
+  // bound the spin: at most ~2 s at 2.4 GHz (s_memtime ticks are shader cycles)
+  if (cycles > 5000000000ull) return KLM_ERR_ARG;
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
+                     (unsigned long long)cycles);
+  return done();
+}
+
+extern "C" const char* klm_version(void) { return "klm-ops 0.1 gfx950"; }

@@ -1,0 +1,80 @@
+"""GPU check of the klm ops: numerics vs torch fp32 and a quick throughput readout."""
+import json, sys, time
+import torch
+from k8s_llm_monitor_amd import ops
+
+def bench(fn, iters=20, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+def main():
+    dev = torch.device("cuda:0")
+    print(torch.cuda.get_device_name(0), ops.version(), flush=True)
+    res = {}
+    torch.manual_seed(0)
+    for variant, (M, N, K) in [(0, (256, 384, 192)), (1, (512, 768, 320)), (0, (1024, 1024, 1024)), (1, (1024, 1024, 1024))]:
+        a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+        c = ops.gemm_bf16(a, b, variant=variant)
+        ref = a.float() @ b.float().t()
+        err = (c.float() - ref).abs().max().item()
+        rel = err / ref.abs().max().item()
+        print(f"variant {variant} {M}x{N}x{K}: max abs err {err:.4f} rel {rel:.2e}", flush=True)
+        res[f"err_v{variant}_{M}x{N}x{K}"] = rel
+        assert rel < 2e-2, "numerics"
+    # asymmetric integer check (exact)
+    M = N = 256; K = 128
+    a = torch.randint(-3, 4, (M, K), device=dev).to(torch.bfloat16)
+    b = torch.randint(-3, 4, (N, K), device=dev).to(torch.bfloat16)
+    for v in (0, 1):
+        c = ops.gemm_bf16(a, b, variant=v)
+        ref = a.float() @ b.float().t()
+        assert torch.equal(c.float(), ref.to(torch.bfloat16).float()), f"exact int check variant {v}"
+    print("exact integer check ok", flush=True)
+    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192)]:
+        a = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        b = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        fl = 2.0 * M * N * K
+        for v in (0, 1):
+            ms = bench(lambda: ops.gemm_bf16(a, b, out=c, variant=v))
+            print(f"klm v{v} {M}^3: {ms:.3f} ms {fl/ms/1e9:.1f} TF", flush=True)
+            res[f"tf_v{v}_{M}"] = fl / ms / 1e9
+        bt = b.t()
+        ms = bench(lambda: torch.matmul(a, bt, out=c))
+        print(f"torch(hipBLASLt) {M}^3: {ms:.3f} ms {fl/ms/1e9:.1f} TF", flush=True)
+        res[f"tf_torch_{M}"] = fl / ms / 1e9
+    # repeated-run race screen on the ring kernel
+    a = torch.randn(2048, 4096, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(2048, 4096, device=dev, dtype=torch.bfloat16)
+    c0 = ops.gemm_bf16(a, b, variant=1).clone()
+    bad = 0
+    for _ in range(50):
+        if not torch.equal(ops.gemm_bf16(a, b, variant=1), c0): bad += 1
+    print("race screen mismatches:", bad, flush=True)
+    res["race_mismatches"] = bad
+    # HBM
+    n = 4 << 30
+    x = torch.empty(n, dtype=torch.uint8, device=dev); y = torch.empty(n, dtype=torch.uint8, device=dev)
+    sink = torch.zeros(2, dtype=torch.int32, device=dev)
+    ms = bench(lambda: ops.hbm_fill(x, 0x01020304), 10, 2); res["fill_TBps"] = n / ms / 1e9
+    print(f"fill {n/ms/1e9:.2f} TB/s", flush=True)
+    ms = bench(lambda: ops.hbm_copy(y, x), 10, 2); res["copy_TBps"] = 2 * n / ms / 1e9
+    print(f"copy {2*n/ms/1e9:.2f} TB/s (r+w)", flush=True)
+    ms = bench(lambda: ops.hbm_read(x, sink), 10, 2); res["read_TBps"] = n / ms / 1e9
+    print(f"read {n/ms/1e9:.2f} TB/s", flush=True)
+    cs = ops.hbm_checksum(y)
+    exp = (0x01020304 * (n // 4)) & 0xFFFFFFFFFFFFFFFF
+    print("checksum ok" if cs == exp else f"checksum BAD {cs} != {exp}", flush=True)
+    res["checksum_ok"] = cs == exp
+    t0 = time.time(); ops.spin(240_000_000, 256); torch.cuda.synchronize(); res["spin_240Mcyc_s"] = time.time() - t0
+    print("spin 240M cycles took", res["spin_240Mcyc_s"], flush=True)
+    print(json.dumps(res))
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Headline benchmark: the monitored validation load on N MI355X GPUs of one node.
+
+BASELINE.json names no throughput number (the reference publishes none); its metric is
+"telemetry error vs amdsmi/rocprof (%), sampling overhead, alert latency; RCCL busBW
+1-8 GPU" on the configs "single MI355X: amdsmi telemetry + HIP MFMA bf16 GEMM burner"
+and "8xMI355X: RCCL all-reduce probe over xGMI at 1/2/4/8 GPUs". One bench STEP is one
+iteration of exactly that load, on every rank, with the telemetry sampler running:
+
+    1. the hand-written bf16 MFMA GEMM burner (8192^3, C = A @ B^T) on the compute stream;
+    2. for N > 1: an RCCL all-reduce (sum, bf16) of the previous step's 128 MiB output
+       on a communication stream, overlapped with step 1 (double-buffered outputs).
+
+``value`` is the whole-job burner rate in TFLOP/s (sum over ranks, weak scaling); the
+JSON line also carries the all-reduce bus bandwidth and, from short phases outside the
+timed region, the monitor's own figures: sampling overhead (burner rate with the sampler
+on vs off), telemetry error (HBM used vs. the allocator's ground truth, GFX activity vs.
+the known duty cycle) and alert latency (HBM threshold crossing -> alert visible).
+
+Launch: ``python bench.py`` (1 GPU) or
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=8192, help="GEMM M=N=K")
+    ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--no-validation", action="store_true",
+                    help="skip the fidelity / overhead / alert-latency phases")
+    ap.add_argument("--sample-period", type=float, default=0.0,
+                    help="telemetry period in s during the timed region (0 = config default 5 s)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse_args()
+    import torch
+    import torch.distributed as dist
+    from k8s_llm_monitor_amd import ops
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"[bench] note: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from k8s_llm_monitor_amd.validation import benchlib
+    result = benchlib.run(a, rank=rank, world=world, dev=dev, ops=ops)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""The timed loop and the validation phases behind ``bench.py``.
+
+No reference counterpart (the reference has no benchmark); the
+quantities are the self-defined targets of BASELINE.md: telemetry error, sampling
+overhead, alert latency and the RCCL bus bandwidth at N GPUs.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from typing import Any, Dict, Optional
+
+
+def _sync_all(torch, dist, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+class _Load:
+    """One rank's buffers and the step function (GEMM burner + overlapped all-reduce)."""
+
+    def __init__(self, torch, dist, ops, dev, world: int, size: int):
+        self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + (dist.get_rank() if world > 1 else 0))
+        # uniform [-1, 1) operands: zero-filled operands read ~15-20 % high (DVFS)
+        self.a = (torch.rand(size, size, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        self.b = (torch.rand(size, size, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        self.c = [torch.empty(size, size, device=dev, dtype=torch.bfloat16) for _ in range(2)]
+        self.size = size
+        self.flops = 2.0 * size * size * size
+        self.comm = torch.cuda.Stream(device=dev) if world > 1 else None
+        self.ev_gemm = [torch.cuda.Event() for _ in range(2)]
+        self.ev_comm = [torch.cuda.Event() for _ in range(2)]
+        self.i = 0
+        self.allreduce_bytes = size * size * 2 if world > 1 else 0
+
+    def step(self):
+        torch = self.torch
+        k = self.i & 1
+        main = torch.cuda.current_stream()
+        if self.comm is not None:
+            # buffer k was all-reduced two steps ago: the GEMM may only overwrite it after that
+            main.wait_event(self.ev_comm[k])
+        self.ops.gemm_bf16(self.a, self.b, out=self.c[k], variant=1)
+        if self.comm is not None:
+            self.ev_gemm[k].record(main)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.ev_gemm[k])
+                self.dist.all_reduce(self.c[k])
+                self.ev_comm[k].record(self.comm)
+        self.i += 1
+
+    def drain(self):
+        if self.comm is not None:
+            self.torch.cuda.current_stream().wait_stream(self.comm)
+
+
+def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int) -> float:
+    """Seconds for exactly `steps` steps: barrier + synchronize on both sides, MAX over ranks."""
+    for _ in range(warmup):
+        load.step()
+    load.drain()
+    _sync_all(torch, dist, world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        load.step()
+    load.drain()
+    _sync_all(torch, dist, world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=load.a.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def _start_sampler(period: float, device_index: int):
+    """Start the monitor's real sampler on this rank (None when telemetry is unavailable)."""
+    try:
+        from ..collectors.gpu import open_gpu_source
+        from ..server.sampler import BackgroundPoller
+    except Exception:
+        return None
+    try:
+        src = open_gpu_source("auto")
+        if src is None or src.kind == "none":
+            return None
+        p = BackgroundPoller(src, period=period)
+        p.start()
+        return p
+    except Exception:
+        return None
+
+
+def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
+    import torch
+    import torch.distributed as dist
+
+    size = a.size
+    load = _Load(torch, dist, ops, dev, world, size)
+    extras: Dict[str, Any] = {}
+
+    sampler = None
+    period = a.sample_period if a.sample_period > 0 else 5.0
+    if not a.no_sampler:
+        sampler = _start_sampler(period, dev.index or 0)
+    extras["sampler"] = (sampler.describe() if sampler is not None else "off")
+
+    dt = timed_steps(torch, dist, load, world, a.steps, a.warmup)
+    ms = dt / a.steps * 1e3
+    tflops = load.flops * world / (dt / a.steps) / 1e12
+    if world > 1:
+        algbw = load.allreduce_bytes / (dt / a.steps) / 1e9
+        extras["allreduce_bytes_per_step"] = load.allreduce_bytes
+        extras["allreduce_algbw_GBps_overlapped"] = round(algbw, 2)
+        extras["allreduce_busbw_GBps_overlapped"] = round(algbw * 2 * (world - 1) / world, 2)
+
+    if sampler is not None:
+        extras["sampler_stats"] = sampler.stats()
+
+    if not a.no_validation:
+        try:
+            from . import phases
+            extras.update(phases.run_all(torch, dist, ops, dev, rank, world, load, sampler, a))
+        except Exception as e:  # the validation phases never invalidate the timed number
+            extras["validation_error"] = f"{type(e).__name__}: {e}"
+
+    if sampler is not None:
+        sampler.stop()
+
+    return {
+        "metric": "monitored bf16 MFMA burner throughput (validation load under telemetry sampling)",
+        "value": round(tflops, 2),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(ms, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (uniform [-1,1) operands, random init)",
+        "config": {
+            "model": "klm bf16 GEMM burner %d^3 (hand-written gfx950 MFMA kernel) + RCCL all-reduce of its output" % size,
+            "global_batch": world,
+            "seq_len": size,
+            "parallelism": f"dp{world}" if world > 1 else "single",
+        },
+        **extras,
+    }

@@ -1,0 +1,446 @@
+"""GPU telemetry for AMD Instinct MI355X through amdsmi. No NVIDIA path of any kind.
+
+Reference: ``getGpuMetrics`` (monitor_server.js:83-95) shells out to ``nvidia-smi`` and
+returns ``[{name, utilization, memoryUsed, memoryTotal, temperature}]`` with memory in MiB
+and ``[]`` on any failure. This module keeps exactly those five keys with the same units
+(so the reference frontend would still render it) and adds, per GPU: ``index`` (parsed but
+dropped by the reference, :90), HBM bytes and percent, memory-controller activity, power
+and cap, HBM temperature, clocks, ECC counts, throttle residency, and per-link xGMI
+traffic.
+
+Layers:
+  raw reading  - flat dict per GPU straight from amdsmi (``AmdSmiReader``), from the C++
+                 sampler's JSON lines (``NativeSamplerReader``) or from a script
+                 (``fakes.gpu.FakeGpuReader``). Accumulators are still cumulative here.
+  GpuNormalizer - turns raw readings into API samples; owns the delta state.
+  GpuSource     - reader + normalizer, what the sampler loop talks to.
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import threading
+import time
+from typing import Any, Dict, List, Optional, Sequence
+
+from .counters import RateTracker, counter_delta, share
+
+MIB = 1 << 20
+XGMI_LINKS = 8
+
+RESIDENCY_KEYS = ("prochot", "ppt", "socket_thm", "vr_thm", "hbm_thm")
+
+
+def _num(x: Any) -> Optional[float]:
+    """amdsmi's Python layer reports unsupported fields as the string 'N/A'."""
+    if isinstance(x, bool):
+        return float(x)
+    if isinstance(x, (int, float)):
+        return float(x)
+    return None
+
+
+def _int(x: Any) -> Optional[int]:
+    v = _num(x)
+    return None if v is None else int(v)
+
+
+# --------------------------------------------------------------------------------------
+# normaliser
+# --------------------------------------------------------------------------------------
+class GpuNormalizer:
+    """Raw cumulative readings -> API samples. One instance per source (keeps last readings)."""
+
+    def __init__(self):
+        self._rates = RateTracker(bits=64)
+        self._prev: Dict[int, Dict[str, Any]] = {}
+
+    def reset(self) -> None:
+        self.__init__()
+
+    def normalize(self, raw: Dict[str, Any]) -> Dict[str, Any]:
+        idx = int(raw.get("index", 0))
+        t = float(raw.get("t", time.monotonic()))
+        prev = self._prev.get(idx)
+        self._prev[idx] = raw
+
+        total_mib = _int(raw.get("vram_total_mib")) or 0
+        used_mib = _int(raw.get("vram_used_mib")) or 0
+        used_b = _int(raw.get("vram_used_bytes"))
+        total_b = _int(raw.get("vram_total_bytes"))
+        if not used_b:
+            used_b = used_mib * MIB
+        if not total_b or (total_mib and abs(total_b - total_mib * MIB) > total_mib * MIB // 8):
+            # amdsmi's byte-typed total includes carve-outs the MiB-typed one does not; keep
+            # both fields of one API call consistent
+            total_b = total_mib * MIB
+        if not total_mib and total_b:
+            total_mib = total_b // MIB
+        if not used_mib and used_b:
+            used_mib = used_b // MIB
+
+        # activity: accumulator deltas give the exact mean over the sample period; the
+        # instantaneous gauge is a firmware moving average and is kept beside it
+        gfx_inst = _num(raw.get("gfx_activity"))
+        umc_inst = _num(raw.get("umc_activity"))
+        gfx_avg = umc_avg = None
+        residency: Dict[str, Optional[float]] = {}
+        if prev is not None:
+            dacc = counter_delta(_int(prev.get("accumulation_counter")), _int(raw.get("accumulation_counter")))
+            gfx_avg = share(counter_delta(_int(prev.get("gfx_activity_acc")), _int(raw.get("gfx_activity_acc"))), dacc, 1.0)
+            umc_avg = share(counter_delta(_int(prev.get("mem_activity_acc")), _int(raw.get("mem_activity_acc"))), dacc, 1.0)
+            for k in RESIDENCY_KEYS:
+                residency[k] = share(counter_delta(_int(prev.get(f"res_{k}_acc")), _int(raw.get(f"res_{k}_acc"))), dacc, 100.0)
+        if gfx_avg is not None:
+            gfx_avg = min(100.0, max(0.0, gfx_avg))
+        if umc_avg is not None:
+            umc_avg = min(100.0, max(0.0, umc_avg))
+        util = gfx_avg if gfx_avg is not None else gfx_inst
+
+        # power: instantaneous gauge plus the energy-counter mean over the period
+        power_w = _num(raw.get("power_w"))
+        power_avg = None
+        res_uj = _num(raw.get("energy_resolution_uj"))
+        e_rate = self._rates.update(("energy", idx), t, _int(raw.get("energy_acc")))
+        if e_rate is not None and res_uj:
+            power_avg = e_rate * res_uj * 1e-6
+        cap_w = _num(raw.get("power_cap_w"))
+
+        # throttle
+        active = [k for k in RESIDENCY_KEYS if raw.get(f"active_{k}") is True]
+        throttling = [k for k, v in residency.items() if v is not None and v > 0.0]
+
+        # xGMI per-link traffic
+        links = []
+        rd, wr = raw.get("xgmi_read_kib") or [], raw.get("xgmi_write_kib") or []
+        st = raw.get("xgmi_link_status") or []
+        peers = raw.get("xgmi_peers") or []
+        rx_total = tx_total = 0.0
+        any_rate = False
+        for i in range(max(len(rd), len(wr), len(st))):
+            r_kib = _int(rd[i]) if i < len(rd) else None
+            w_kib = _int(wr[i]) if i < len(wr) else None
+            s = st[i] if i < len(st) else None
+            state = {1: "up", 0: "down", "U": "up", "D": "down", "X": "disabled"}.get(s, "n/a")
+            rx = self._rates.update(("xr", idx, i), t, r_kib)
+            tx = self._rates.update(("xw", idx, i), t, w_kib)
+            rx_gbps = None if rx is None else rx * 1024 / 1e9
+            tx_gbps = None if tx is None else tx * 1024 / 1e9
+            if rx_gbps is not None:
+                rx_total += rx_gbps
+                any_rate = True
+            if tx_gbps is not None:
+                tx_total += tx_gbps
+            if state == "n/a" and r_kib in (None, 0) and w_kib in (None, 0):
+                continue  # link slot not populated (the GPU's own position in the hive)
+            links.append({"link": i, "state": state, "peer": peers[i] if i < len(peers) else None,
+                          "rxBytes": None if r_kib is None else r_kib * 1024,
+                          "txBytes": None if w_kib is None else w_kib * 1024,
+                          "rxGBps": rx_gbps, "txGBps": tx_gbps})
+
+        temp = _num(raw.get("temp_hotspot"))
+        out = {
+            # --- the reference's five keys, same meaning and units (monitor_server.js:90)
+            "name": raw.get("name") or "AMD Instinct",
+            "utilization": int(round(util)) if util is not None else 0,
+            "memoryUsed": int(used_mib),
+            "memoryTotal": int(total_mib),
+            "temperature": int(round(temp)) if temp is not None else 0,
+            # --- MI355X extensions
+            "index": idx,
+            "uuid": raw.get("uuid"),
+            "bdf": raw.get("bdf"),
+            "hbmUsedBytes": int(used_b),
+            "hbmTotalBytes": int(total_b),
+            "hbmPercent": (used_b / total_b * 100.0) if total_b else None,
+            "gfxActivity": gfx_inst,
+            "gfxActivityAvg": gfx_avg,
+            "memActivity": umc_inst,
+            "memActivityAvg": umc_avg,
+            "powerW": power_w,
+            "powerAvgW": power_avg,
+            "powerCapW": cap_w,
+            "powerPercent": (power_w / cap_w * 100.0) if (power_w is not None and cap_w) else None,
+            "temperatureHbm": _num(raw.get("temp_mem")),
+            "temperatureEdge": _num(raw.get("temp_edge")),
+            "clockGfxMHz": _num(raw.get("clk_gfx")),
+            "clockMemMHz": _num(raw.get("clk_mem")),
+            "ecc": {"correctable": _int(raw.get("ecc_correctable")),
+                    "uncorrectable": _int(raw.get("ecc_uncorrectable")),
+                    "deferred": _int(raw.get("ecc_deferred"))},
+            "throttle": {"active": bool(active or throttling),
+                         "reasons": sorted(set(active) | set(throttling)),
+                         "residencyPercent": residency},
+            "xgmi": {"links": links,
+                     "rxGBps": rx_total if any_rate else None,
+                     "txGBps": tx_total if any_rate else None,
+                     "linkWidth": _int(raw.get("xgmi_link_width")),
+                     "linkSpeedGbps": _int(raw.get("xgmi_link_speed"))},
+            "pcieGBps": _num(raw.get("pcie_bandwidth_inst")),
+            "processes": raw.get("processes"),
+            "peak": raw.get("peak"),
+            "timestamp": raw.get("wall", time.time()),
+        }
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# readers
+# --------------------------------------------------------------------------------------
+class GpuReader:
+    kind = "none"
+
+    def read(self) -> List[Dict[str, Any]]:
+        return []
+
+    def close(self) -> None:
+        pass
+
+    def describe(self) -> str:
+        return self.kind
+
+
+class AmdSmiReader(GpuReader):
+    """In-process reader on the ``amdsmi`` Python bindings: one ``gpu_metrics`` call, one
+    VRAM call and one ECC call per GPU per sample (about 0.5 ms per GPU on MI355X)."""
+    kind = "amdsmi"
+
+    def __init__(self):
+        import amdsmi  # raises ImportError / OSError when the library is absent
+        self._smi = amdsmi
+        amdsmi.amdsmi_init()
+        self._handles = list(amdsmi.amdsmi_get_processor_handles())
+        if not self._handles:
+            amdsmi.amdsmi_shut_down()
+            raise RuntimeError("amdsmi found no GPU")
+        self._static: List[Dict[str, Any]] = []
+        for h in self._handles:
+            st: Dict[str, Any] = {}
+            for key, fn in (("asic", amdsmi.amdsmi_get_gpu_asic_info),
+                            ("uuid", amdsmi.amdsmi_get_gpu_device_uuid),
+                            ("bdf", amdsmi.amdsmi_get_gpu_device_bdf),
+                            ("cap", amdsmi.amdsmi_get_power_cap_info),
+                            ("energy", amdsmi.amdsmi_get_energy_count)):
+                try:
+                    st[key] = fn(h)
+                except Exception:
+                    st[key] = None
+            self._static.append(st)
+        self._slow_every = 12       # ECC and process list change rarely: read every Nth sample
+        self._n = 0
+        self._slow_cache: Dict[int, Dict[str, Any]] = {}
+        self._lock = threading.Lock()
+
+    def _cap_w(self, st) -> Optional[float]:
+        cap = (st.get("cap") or {}).get("power_cap")
+        v = _num(cap)
+        if not v:
+            return None
+        return v / 1e6 if v > 100000 else v   # reported in microwatts
+
+    def read(self) -> List[Dict[str, Any]]:
+        smi = self._smi
+        out = []
+        with self._lock:
+            slow = (self._n % self._slow_every) == 0
+            self._n += 1
+            for i, h in enumerate(self._handles):
+                st = self._static[i]
+                t = time.monotonic()
+                raw: Dict[str, Any] = {"index": i, "t": t, "wall": time.time(),
+                                       "name": (st.get("asic") or {}).get("market_name"),
+                                       "uuid": st.get("uuid"), "bdf": st.get("bdf"),
+                                       "power_cap_w": self._cap_w(st),
+                                       "energy_resolution_uj": _num((st.get("energy") or {}).get("counter_resolution"))}
+                try:
+                    v = smi.amdsmi_get_gpu_vram_usage(h)
+                    raw["vram_used_mib"], raw["vram_total_mib"] = v.get("vram_used"), v.get("vram_total")
+                except Exception:
+                    pass
+                try:
+                    m = smi.amdsmi_get_gpu_metrics_info(h)
+                except Exception:
+                    m = {}
+                raw.update(metrics_to_raw(m))
+                if slow or i not in self._slow_cache:
+                    sc: Dict[str, Any] = {}
+                    try:
+                        e = smi.amdsmi_get_gpu_total_ecc_count(h)
+                        sc.update(ecc_correctable=e.get("correctable_count"),
+                                  ecc_uncorrectable=e.get("uncorrectable_count"),
+                                  ecc_deferred=e.get("deferred_count"))
+                    except Exception:
+                        pass
+                    try:
+                        sc["processes"] = len(smi.amdsmi_get_gpu_process_list(h))
+                    except Exception:
+                        pass
+                    self._slow_cache[i] = sc
+                raw.update(self._slow_cache[i])
+                out.append(raw)
+        return out
+
+    def close(self) -> None:
+        try:
+            self._smi.amdsmi_shut_down()
+        except Exception:
+            pass
+
+
+def metrics_to_raw(m: Dict[str, Any]) -> Dict[str, Any]:
+    """Map one ``amdsmi_get_gpu_metrics_info`` dict to raw-reading keys."""
+    g = m.get
+    raw = {
+        "gfx_activity": g("average_gfx_activity"),
+        "umc_activity": g("average_umc_activity"),
+        "gfx_activity_acc": g("gfx_activity_acc"),
+        "mem_activity_acc": g("mem_activity_acc"),
+        "accumulation_counter": g("accumulation_counter"),
+        "firmware_timestamp": g("firmware_timestamp"),
+        "power_w": g("current_socket_power") if _num(g("current_socket_power")) is not None else g("average_socket_power"),
+        "energy_acc": g("energy_accumulator"),
+        "temp_hotspot": g("temperature_hotspot"),
+        "temp_mem": g("temperature_mem"),
+        "temp_edge": g("temperature_edge"),
+        "clk_gfx": g("current_gfxclk"),
+        "clk_mem": g("current_uclk"),
+        "res_prochot_acc": g("prochot_residency_acc"),
+        "res_ppt_acc": g("ppt_residency_acc"),
+        "res_socket_thm_acc": g("socket_thm_residency_acc"),
+        "res_vr_thm_acc": g("vr_thm_residency_acc"),
+        "res_hbm_thm_acc": g("hbm_thm_residency_acc"),
+        "xgmi_read_kib": g("xgmi_read_data_acc"),
+        "xgmi_write_kib": g("xgmi_write_data_acc"),
+        "xgmi_link_status": g("xgmi_link_status"),
+        "xgmi_link_width": g("xgmi_link_width"),
+        "xgmi_link_speed": g("xgmi_link_speed"),
+        "pcie_bandwidth_inst": g("pcie_bandwidth_inst"),
+    }
+    return {k: v for k, v in raw.items() if v is not None and v != "N/A"}
+
+
+class NativeSamplerReader(GpuReader):
+    """Reads the JSON lines of the C++ sampler (``klm_amdsmi_sampler``), which polls amdsmi
+    at a high internal rate and emits one aggregated line per period (mean and peak)."""
+    kind = "native"
+
+    def __init__(self, exe: str = "", period: float = 1.0, hz: float = 20.0,
+                 argv: Optional[Sequence[str]] = None):
+        if not exe:
+            from ..build import artifact
+            exe = str(artifact("klm_amdsmi_sampler"))
+        if argv is None and not os.path.exists(exe):
+            raise FileNotFoundError(exe)
+        self.exe = exe
+        cmd = list(argv) if argv is not None else [exe, "--period", str(period), "--hz", str(hz)]
+        self._p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                   text=True, bufsize=1)
+        self._latest: List[Dict[str, Any]] = []
+        self._err: Optional[str] = None
+        self._got = threading.Event()
+        self._th = threading.Thread(target=self._pump, name="klm-native-sampler", daemon=True)
+        self._th.start()
+        # wait for the first line so that a sampler that cannot start is an error now
+        if not self._got.wait(timeout=max(5.0, 3 * period)):
+            self.close()
+            raise RuntimeError(f"{exe} produced no sample")
+        if self._err and not self._latest:
+            self.close()
+            raise RuntimeError(f"{exe}: {self._err}")
+
+    def _pump(self) -> None:
+        assert self._p.stdout is not None
+        for line in self._p.stdout:
+            line = line.strip()
+            if not line:
+                continue
+            try:
+                msg = json.loads(line)
+            except ValueError:
+                continue
+            if "error" in msg:
+                self._err = str(msg["error"])
+                self._got.set()
+                continue
+            gpus = msg.get("gpus")
+            if isinstance(gpus, list):
+                self._latest = gpus
+                self._got.set()
+        self._got.set()
+
+    def read(self) -> List[Dict[str, Any]]:
+        if self._p.poll() is not None and not self._latest:
+            return []
+        return [dict(g) for g in self._latest]
+
+    def close(self) -> None:
+        if self._p.poll() is None:
+            self._p.terminate()
+            try:
+                self._p.wait(timeout=2)
+            except subprocess.TimeoutExpired:
+                self._p.kill()
+
+    def describe(self) -> str:
+        return f"native({os.path.basename(self.exe)})"
+
+
+# --------------------------------------------------------------------------------------
+# source
+# --------------------------------------------------------------------------------------
+class GpuSource:
+    """reader + normaliser. ``sample()`` never raises: a failing reader yields ``[]`` exactly
+    like the reference's catch-all (monitor_server.js:94)."""
+
+    def __init__(self, reader: GpuReader):
+        self.reader = reader
+        self.kind = reader.kind
+        self.norm = GpuNormalizer()
+        self.last_duration_s = 0.0
+        self.last_error: Optional[str] = None
+        self.samples = 0
+
+    def sample(self) -> List[Dict[str, Any]]:
+        t0 = time.perf_counter()
+        try:
+            raws = self.reader.read()
+            out = [self.norm.normalize(r) for r in raws]
+            self.last_error = None
+        except Exception as e:
+            out = []
+            self.last_error = f"{type(e).__name__}: {e}"
+        self.last_duration_s = time.perf_counter() - t0
+        self.samples += 1
+        return out
+
+    def close(self) -> None:
+        self.reader.close()
+
+    def describe(self) -> str:
+        return self.reader.describe()
+
+
+def open_gpu_source(kind: str = "auto", cfg=None) -> GpuSource:
+    """kind: auto | amdsmi | native | fake | none. ``auto`` = amdsmi when it finds a GPU,
+    else none (an empty list, like a host without nvidia-smi in the reference)."""
+    kind = (kind or "auto").lower()
+    if kind == "none":
+        return GpuSource(GpuReader())
+    if kind == "fake":
+        from ..fakes.gpu import FakeGpuReader
+        n = getattr(getattr(cfg, "sources", None), "fake_gpus", 8) if cfg is not None else 8
+        scen = getattr(getattr(cfg, "sources", None), "fake_scenario", "") if cfg is not None else ""
+        return GpuSource(FakeGpuReader(n_gpus=n, scenario=scen))
+    if kind == "native":
+        exe = getattr(getattr(cfg, "sources", None), "native_sampler", "") if cfg is not None else ""
+        period = getattr(getattr(cfg, "periods", None), "realtime", 1.0) if cfg is not None else 1.0
+        return GpuSource(NativeSamplerReader(exe=exe, period=min(period, 1.0)))
+    if kind == "amdsmi":
+        return GpuSource(AmdSmiReader())
+    if kind == "auto":
+        try:
+            return GpuSource(AmdSmiReader())
+        except Exception:
+            return GpuSource(GpuReader())
+    raise ValueError(f"unknown gpu source {kind!r}")

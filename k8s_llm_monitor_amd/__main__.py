@@ -1,0 +1,145 @@
+"""Command line: ``python -m k8s_llm_monitor_amd <command>``.
+
+The reference has one entry point, ``node monitor_server.js`` (README.md:99), with no
+flags. ``serve`` is that entry point; the other commands drive the
+MI355X validation toolkit.
+
+    serve      run the monitor (HTTP API + dashboard + background sampler)
+    demo       the same with every source faked (no GPU, no cluster): BASELINE config 1
+    sample     print one telemetry sample as JSON and exit
+    build      compile the native targets for gfx950
+    burner     run the MFMA GEMM / HBM load generator
+    probe      run the RCCL all-reduce probe and store its curve for the dashboard
+    validate   run the fidelity / overhead / alert-latency phases on this GPU
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import signal
+import sys
+import threading
+import time
+from typing import Optional, Sequence
+
+
+def _cmd_serve(a, demo: bool = False) -> int:
+    from .config import demo_config, load_config
+    from .server.http import MonitorServer
+    from .server.sampler import Monitor
+    over = {}
+    if a.port is not None:
+        over.setdefault("server", {})["port"] = a.port
+    if a.host:
+        over.setdefault("server", {})["host"] = a.host
+    if getattr(a, "scenario", None):
+        over.setdefault("sources", {})["fake_scenario"] = a.scenario
+    if demo:
+        if a.port is None:
+            over.setdefault("server", {})["port"] = 8888
+        cfg = demo_config(**over)
+    else:
+        cfg = load_config(a.config, overrides=over or None)
+    mon = Monitor(cfg).start()
+    srv = MonitorServer(mon, cfg)
+    print(f"🚀 监控面板已启动: {srv.url}  (gpu={mon.gpu.describe()}, kube={mon.kube.describe()}, "
+          f"vllm={mon.vllm.describe()})", flush=True)
+    stop = threading.Event()
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        signal.signal(sig, lambda *_: stop.set())
+    srv.start()
+    try:
+        while not stop.wait(0.5):
+            if a.duration and time.time() - mon.started > a.duration:
+                break
+    finally:
+        srv.stop()
+        mon.stop()
+    return 0
+
+
+def _cmd_sample(a) -> int:
+    from .collectors.gpu import open_gpu_source
+    from .collectors.host import HostCollector
+    src = open_gpu_source(a.source)
+    src.sample()
+    time.sleep(a.interval)
+    out = {"host": HostCollector().collect(), "gpus": src.sample(), "source": src.describe(), "error": src.last_error}
+    src.close()
+    print(json.dumps(out, indent=1, default=str))
+    return 0
+
+
+def _cmd_build(a) -> int:
+    from . import build
+    return build.main((["--force"] if a.force else []) + list(a.targets))
+
+
+def _cmd_burner(a) -> int:
+    from .loadgen import burner
+    return burner.main_from_args(a)
+
+
+def _cmd_probe(a) -> int:
+    from .parallel import probe
+    doc = probe.run_sweep(gpu_counts=[int(x) for x in a.gpus.split(",")], dtypes=a.dtypes.split(","),
+                          path=a.out, max_bytes=a.max_bytes, iters=a.iters, warmup=a.warmup)
+    for s in doc["scaling"]:
+        print(json.dumps(s))
+    print("saved:", a.out or probe.default_results_path())
+    return 0
+
+
+def _cmd_validate(a) -> int:
+    from .validation import phases
+    return phases.main_from_args(a)
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    ap = argparse.ArgumentParser(prog="k8s_llm_monitor_amd", description=__doc__.split("\n")[0])
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    for name in ("serve", "demo"):
+        p = sub.add_parser(name)
+        p.add_argument("--config", default=None, help="JSON/YAML config file (or KLM_CONFIG)")
+        p.add_argument("--port", type=int, default=None)
+        p.add_argument("--host", default="")
+        p.add_argument("--scenario", default="", help="fake scenario name (demo / fake sources)")
+        p.add_argument("--duration", type=float, default=0.0, help="exit after N seconds (0 = run until signalled)")
+    p = sub.add_parser("sample")
+    p.add_argument("--source", default="auto")
+    p.add_argument("--interval", type=float, default=1.0)
+    p = sub.add_parser("build")
+    p.add_argument("--force", action="store_true")
+    p.add_argument("targets", nargs="*")
+    p = sub.add_parser("burner")
+    p.add_argument("--kind", default="gemm_bf16", choices=["gemm_bf16", "gemm_fp8", "hbm_copy", "hbm_read", "hbm_fill", "spin"])
+    p.add_argument("--duty", type=float, default=100.0, help="busy share in percent")
+    p.add_argument("--period-ms", type=float, default=100.0, help="duty-cycle period")
+    p.add_argument("--seconds", type=float, default=10.0)
+    p.add_argument("--size", type=int, default=8192)
+    p.add_argument("--hbm-gib", type=float, default=0.0, help="also hold this much HBM (fill injector)")
+    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--json", action="store_true")
+    p = sub.add_parser("probe")
+    p.add_argument("--gpus", default="1,2,4,8")
+    p.add_argument("--dtypes", default="bf16")
+    p.add_argument("--max-bytes", type=int, default=1 << 30)
+    p.add_argument("--iters", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--out", default="")
+    p = sub.add_parser("validate")
+    p.add_argument("--out", default="")
+    p.add_argument("--quick", action="store_true")
+    p.add_argument("--phases", default="all")
+    p.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.cmd == "serve":
+        return _cmd_serve(a)
+    if a.cmd == "demo":
+        return _cmd_serve(a, demo=True)
+    return {"sample": _cmd_sample, "build": _cmd_build, "burner": _cmd_burner, "probe": _cmd_probe,
+            "validate": _cmd_validate}[a.cmd](a)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,296 @@
+"""The sampling loop: every source is polled on its own period by a background thread, the
+alert engine runs once per tick, HTTP handlers only read snapshots.
+
+Reference behaviour replaced: collectors run synchronously inside each request
+(monitor_server.js:273-288), so every open browser re-runs ``df``, ``nvidia-smi`` and
+``kubectl`` and ``/api/alerts`` mutates ``lastPodStates`` per client (SURVEY.md 2.7 item 2,
+2.8 "blocking collectors" / "duplicate work"). Here cost is independent of viewer count,
+a slow ``kubectl`` cannot stall GPU sampling (one thread per source) and the alert state
+has one owner.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from typing import Any, Callable, Dict, List, Optional
+
+from ..collectors import history as hist
+from ..collectors.gpu import GpuSource, open_gpu_source
+from ..collectors.host import HostCollector
+from ..collectors.kube import KubeSource, open_kube_source
+from ..collectors.prometheus import PrometheusClient
+from ..collectors.vllm import VllmSource, open_vllm_source
+from ..config import Config
+from ..utils.ringbuffer import HistoryStore
+from ..utils.timefmt import parse_duration
+from .alerts import AlertBook, AlertState, check_alerts, empty_alerts
+
+
+class PeriodicTask:
+    """Calls ``fn`` every ``period`` seconds on its own daemon thread, on a fixed time grid
+    (no drift: a slow call skips grid points instead of shifting them). Keeps timing stats
+    of the calls, including the thread's CPU time, which is what "sampling overhead" on the
+    host side means."""
+
+    def __init__(self, name: str, fn: Callable[[], Any], period: float):
+        self.name, self.fn, self.period = name, fn, float(period)
+        self._stop = threading.Event()
+        self._th: Optional[threading.Thread] = None
+        self.calls = 0
+        self.errors = 0
+        self.total_s = 0.0
+        self.max_s = 0.0
+        self.last_s = 0.0
+        self.cpu_s = 0.0
+        self.last_error: Optional[str] = None
+        self.last_run_wall = 0.0
+
+    def run_once(self) -> None:
+        t0, c0 = time.perf_counter(), time.thread_time()
+        try:
+            self.fn()
+        except Exception as e:      # a collector bug must not kill the loop
+            self.errors += 1
+            self.last_error = f"{type(e).__name__}: {e}"
+        dt = time.perf_counter() - t0
+        self.cpu_s += time.thread_time() - c0
+        self.calls += 1
+        self.total_s += dt
+        self.last_s = dt
+        self.max_s = max(self.max_s, dt)
+        self.last_run_wall = time.time()
+
+    def _loop(self) -> None:
+        nxt = time.monotonic()
+        while not self._stop.is_set():
+            self.run_once()
+            nxt += self.period
+            now = time.monotonic()
+            if nxt <= now:                               # overran: realign to the grid
+                nxt = now + self.period - ((now - nxt) % self.period)
+            self._stop.wait(max(0.0, nxt - now))
+
+    def start(self) -> "PeriodicTask":
+        if self._th is None:
+            self._th = threading.Thread(target=self._loop, name=f"klm-{self.name}", daemon=True)
+            self._th.start()
+        return self
+
+    def stop(self, timeout: float = 2.0) -> None:
+        self._stop.set()
+        if self._th is not None:
+            self._th.join(timeout=timeout)
+            self._th = None
+
+    def stats(self) -> Dict[str, Any]:
+        n = max(1, self.calls)
+        return {"period_s": self.period, "calls": self.calls, "errors": self.errors,
+                "mean_ms": round(self.total_s / n * 1e3, 4), "max_ms": round(self.max_s * 1e3, 4),
+                "last_ms": round(self.last_s * 1e3, 4), "cpu_ms_per_call": round(self.cpu_s / n * 1e3, 4),
+                "duty_percent": round(self.total_s / n / self.period * 100.0, 5) if self.period > 0 else None,
+                "last_error": self.last_error}
+
+
+class BackgroundPoller:
+    """One GPU source polled in the background; used by ``bench.py`` to run the monitor's
+    real telemetry path next to the load and by the validation phases to read it."""
+
+    def __init__(self, src: GpuSource, period: float = 5.0):
+        self.src = src
+        self.latest: List[Dict[str, Any]] = []
+        self.series: List[Dict[str, Any]] = []     # (t, per-GPU samples) kept for validation
+        self.keep = 4096
+        self._lock = threading.Lock()
+        self.task = PeriodicTask("gpu-poller", self._tick, period)
+
+    def _tick(self) -> None:
+        s = self.src.sample()
+        with self._lock:
+            self.latest = s
+            self.series.append({"t": time.time(), "gpus": s})
+            if len(self.series) > self.keep:
+                del self.series[: len(self.series) - self.keep]
+
+    def start(self) -> "BackgroundPoller":
+        self.task.start()
+        return self
+
+    def stop(self) -> None:
+        self.task.stop()
+
+    def snapshot(self) -> List[Dict[str, Any]]:
+        with self._lock:
+            return list(self.latest)
+
+    def window(self, since: float) -> List[Dict[str, Any]]:
+        with self._lock:
+            return [s for s in self.series if s["t"] >= since]
+
+    def describe(self) -> str:
+        return f"{self.src.describe()} every {self.task.period:g}s"
+
+    def stats(self) -> Dict[str, Any]:
+        return self.task.stats()
+
+
+class Monitor:
+    """Application state: sources, periodic tasks, latest snapshot, history, alerts."""
+
+    def __init__(self, cfg: Optional[Config] = None, *, host: Optional[HostCollector] = None,
+                 gpu: Optional[GpuSource] = None, kube: Optional[KubeSource] = None,
+                 vllm: Optional[VllmSource] = None, prom: Optional[PrometheusClient] = None,
+                 clock: Callable[[], float] = time.time):
+        self.cfg = cfg or Config()
+        c = self.cfg
+        self.clock = clock
+        self.prom = prom or PrometheusClient(c.prometheus.url, c.prometheus.timeout)
+        self.host = host or HostCollector(cores=c.compat.cpu_cores, cpu_percent=c.compat.cpu_percent)
+        self.gpu = gpu or open_gpu_source(c.sources.gpu, c)
+        self.kube = kube or open_kube_source(c.sources.kube, c)
+        self.vllm = vllm or open_vllm_source(c.sources.vllm, c, self.prom)
+
+        window_s = parse_duration(c.periods.history_window)
+        cap = int(window_s / max(0.05, min(c.periods.realtime, c.periods.history_step))) + 8
+        self.store = HistoryStore(capacity=min(cap, 200000))
+        self.local_history = hist.LocalHistory(self.store, c.periods.history_window, c.periods.history_step, now=clock)
+        self.prom_history = hist.PrometheusHistory(self.prom, hist.prometheus_queries(c), c.periods.history_window,
+                                                   f"{int(c.periods.history_step)}s")
+        self._history_mode = c.sources.history
+        self._prom_ok: Optional[bool] = None
+        self._prom_checked = 0.0
+
+        self._lock = threading.RLock()
+        self._snap: Dict[str, Any] = {"host": {"cpu": {}, "memory": {}, "disk": {}}, "gpus": [], "pods": [],
+                                      "vllm": {"available": False}, "alerts": empty_alerts(),
+                                      "t_host": 0.0, "t_gpu": 0.0, "t_pods": 0.0, "t_vllm": 0.0, "t_alerts": 0.0}
+        self._alert_state = AlertState()
+        self.book = AlertBook(hold_s=c.periods.alert_hold)
+        self.listeners: List[Callable[[str, Any], None]] = []
+        self.started = 0.0
+        self.tasks: Dict[str, PeriodicTask] = {
+            "realtime": PeriodicTask("realtime", self.tick_realtime, c.periods.realtime),
+            "pods": PeriodicTask("pods", self.tick_pods, c.periods.pods),
+            "vllm": PeriodicTask("vllm", self.tick_vllm, c.periods.vllm),
+        }
+
+    # ---- ticks -------------------------------------------------------------------------
+    def tick_realtime(self) -> None:
+        host = self.host.collect()
+        gpus = self.gpu.sample()
+        now = self.clock()
+        with self._lock:
+            self._snap["host"], self._snap["gpus"] = host, gpus
+            self._snap["t_host"] = self._snap["t_gpu"] = now
+            vllm = self._snap["vllm"]
+        self.store.record(now, hist.history_values(host, gpus, vllm if vllm.get("available") else None))
+        self._evaluate(now)
+        self._emit("realtime", {"host": host, "gpus": gpus})
+
+    def tick_pods(self) -> None:
+        pods = self.kube.pods()
+        now = self.clock()
+        with self._lock:
+            self._snap["pods"], self._snap["t_pods"] = pods, now
+        self._evaluate(now)
+        self._emit("pods", pods)
+
+    def tick_vllm(self) -> None:
+        v = self.vllm.sample()
+        now = self.clock()
+        with self._lock:
+            self._snap["vllm"], self._snap["t_vllm"] = v, now
+
+    def tick_all(self) -> None:
+        """One synchronous pass over every source (tests, first paint before the threads run)."""
+        self.tick_vllm()
+        self.tick_pods()
+        self.tick_realtime()
+
+    def _evaluate(self, now: float) -> None:
+        with self._lock:
+            s = self._snap
+            alerts, self._alert_state = check_alerts(s["host"], s["gpus"], s["pods"], self._alert_state, self.cfg,
+                                                     s["vllm"] if s["vllm"].get("available") else None)
+            shown = self.book.update(alerts, now)
+            before = {a.get("key") for t in s["alerts"].values() for a in t}
+            s["alerts"], s["t_alerts"] = shown, now
+            new = [a for t in shown.values() for a in t if a.get("key") not in before]
+        if new:
+            self._emit("alerts", shown)
+
+    def _emit(self, kind: str, payload: Any) -> None:
+        for fn in list(self.listeners):
+            try:
+                fn(kind, payload)
+            except Exception:
+                pass
+
+    # ---- lifecycle ---------------------------------------------------------------------
+    def start(self) -> "Monitor":
+        self.started = self.clock()
+        self.tick_all()
+        for t in self.tasks.values():
+            t.start()
+        return self
+
+    def stop(self) -> None:
+        for t in self.tasks.values():
+            t.stop()
+        for s in (self.gpu, self.kube, self.vllm):
+            try:
+                s.close()
+            except Exception:
+                pass
+
+    # ---- reads (HTTP handlers) -----------------------------------------------------------
+    def get(self, key: str) -> Any:
+        with self._lock:
+            return self._snap[key]
+
+    def snapshot(self) -> Dict[str, Any]:
+        with self._lock:
+            return dict(self._snap)
+
+    def alerts_public(self) -> Dict[str, List[Dict[str, Any]]]:
+        """The reference's shape: three lists of ``{title, desc, fix}`` (+ ``since``, ``key``)."""
+        with self._lock:
+            a = self._snap["alerts"]
+            return {tier: [{k: v for k, v in x.items() if k in ("title", "desc", "fix", "since", "key", "signal")}
+                           for x in a[tier]] for tier in ("minor", "serious", "critical")}
+
+    def prometheus_available(self) -> bool:
+        now = time.monotonic()
+        if self._prom_ok is None or now - self._prom_checked > 60.0:
+            self._prom_ok = self.prom.reachable()
+            self._prom_checked = now
+        return bool(self._prom_ok)
+
+    def history(self) -> Dict[str, Any]:
+        mode = self._history_mode
+        if mode == "auto":
+            mode = "prometheus" if self.prometheus_available() else "local"
+        if mode == "prometheus":
+            out = self.prom_history.payload()
+            # MI355X extras always come from the local ring (no PromQL configured for them)
+            local = self.local_history.payload()
+            for k, v in local.items():
+                out.setdefault(k, v)
+            out["source"] = "prometheus"
+            return out
+        out = self.local_history.payload()
+        out["source"] = "local"
+        return out
+
+    def stats(self) -> Dict[str, Any]:
+        return {"uptime_s": round(self.clock() - self.started, 3) if self.started else 0.0,
+                "sources": {"gpu": self.gpu.describe(), "kube": self.kube.describe(), "vllm": self.vllm.describe(),
+                            "history": self._history_mode, "prometheus": self.prom.url},
+                "tasks": {k: t.stats() for k, t in self.tasks.items()},
+                "collectors": {"host_ms": round(self.host.last_duration_s * 1e3, 4),
+                               "gpu_ms": round(self.gpu.last_duration_s * 1e3, 4),
+                               "kube_ms": round(self.kube.last_duration_s * 1e3, 4),
+                               "vllm_ms": round(self.vllm.last_duration_s * 1e3, 4)},
+                "errors": {"gpu": self.gpu.last_error, "kube": self.kube.last_error, "vllm": self.vllm.last_error,
+                           "prometheus": self.prom.last_error},
+                "history_points": {n: len(self.store.series(n)) for n in self.store.names()[:64]},
+                "alert_evaluations": self._alert_state.evaluations}

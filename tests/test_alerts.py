@@ -1,0 +1,213 @@
+"""Alert engine vs. checkAlerts (monitor_server.js:159-238): every row of SURVEY.md 2.7, the
+boundaries 70 / 85 / 95 with strict '>', NaN input, pod state-change edges, first-sight
+behaviour, the MI355X and vLLM rules, and the AlertBook hold logic."""
+import math
+
+import pytest
+
+from k8s_llm_monitor_amd.config import Config
+from k8s_llm_monitor_amd.server.alerts import AlertBook, AlertState, check_alerts, empty_alerts, tier_of
+
+OK_HOST = {"cpu": {"percent": "5.0"}, "memory": {"percent": "5.0"}, "disk": {"percent": "5.0"}}
+
+
+def host(cpu="5.0", mem="5.0", disk="5.0"):
+    return {"cpu": {"percent": cpu}, "memory": {"percent": mem}, "disk": {"percent": disk}}
+
+
+def gpu(idx=0, used=1000, total=294896, temp=50, **kw):
+    g = {"index": idx, "name": "MI355X", "utilization": 0, "memoryUsed": used, "memoryTotal": total, "temperature": temp}
+    g.update(kw)
+    return g
+
+
+def pod(name="p", ns="default", status="Running", restarts=0, **kw):
+    return dict({"namespace": ns, "name": name, "status": status, "restarts": restarts, "age": "5m"}, **kw)
+
+
+def titles(alerts, tier):
+    return [a["title"] for a in alerts[tier]]
+
+
+def count(alerts):
+    return {t: len(alerts[t]) for t in ("minor", "serious", "critical")}
+
+
+@pytest.mark.parametrize("v,want", [(69.9, None), (70.0, None), (70.1, "minor"), (85.0, "minor"), (85.1, "serious"),
+                                    (95.0, "serious"), (95.1, "critical"), (250.0, "critical"),
+                                    (float("nan"), None), (None, None)])
+def test_tier_boundaries_are_strict(v, want):
+    assert tier_of(v, [70, 85, 95]) == want
+
+
+def test_disabled_tier():
+    assert tier_of(80, [-1, 90, 100]) is None and tier_of(95, [-1, 90, 100]) == "serious"
+
+
+@pytest.mark.parametrize("signal,title_part", [("cpu", "CPU"), ("mem", "内存"), ("disk", "磁盘")])
+@pytest.mark.parametrize("value,tier", [("70.0", None), ("70.1", "minor"), ("85.1", "serious"), ("95.1", "critical")])
+def test_host_signals_one_alert_at_highest_tier(signal, title_part, value, tier):
+    a, _ = check_alerts(host(**{signal: value}), [], [])
+    c = count(a)
+    assert sum(c.values()) == (0 if tier is None else 1)
+    if tier:
+        assert c[tier] == 1 and title_part in a[tier][0]["title"]
+        assert set(("title", "desc", "fix")) <= set(a[tier][0])
+        assert value.rstrip("0").rstrip(".") in a[tier][0]["desc"]
+
+
+def test_failed_host_collector_raises_no_alert():
+    a, _ = check_alerts({"cpu": {}, "memory": {}, "disk": {}}, [], [])        # :80 + :162 NaN
+    assert count(a) == {"minor": 0, "serious": 0, "critical": 0}
+
+
+@pytest.mark.parametrize("frac,tier", [(0.69, None), (0.70, None), (0.71, "minor"), (0.86, "serious"), (0.96, "critical")])
+def test_hbm_tiers_of_288gb(frac, tier):
+    total = 294896
+    a, _ = check_alerts(OK_HOST, [gpu(used=int(total * frac), total=total)], [])
+    assert sum(count(a).values()) == (1 if tier else 0)
+    if tier:
+        al = a[tier][0]
+        assert "HBM" in al["title"] and f"{int(total * frac)}/{total} MB" in al["desc"]
+
+
+def test_screenshot_case_is_serious():
+    # 21174 / 23028 MiB = 91.9 % > 85 %
+    a, _ = check_alerts(OK_HOST, [gpu(used=21174, total=23028)], [])
+    assert count(a) == {"minor": 0, "serious": 1, "critical": 0} and "91.9%" in a["serious"][0]["desc"]
+
+
+def test_every_gpu_is_checked_unless_compat():
+    gpus = [gpu(0), gpu(5, used=290000)]
+    a, _ = check_alerts(OK_HOST, gpus, [])
+    assert count(a)["critical"] == 1 and "GPU 5" in a["critical"][0]["title"]
+    cfg = Config()
+    cfg.compat.gpu0_only_alerts = True                     # monitor_server.js:178
+    a, _ = check_alerts(OK_HOST, gpus, [], cfg=cfg)
+    assert sum(count(a).values()) == 0
+
+
+def test_reference_temperature_thresholds_available_by_config():
+    cfg = Config()
+    cfg.thresholds.gpu_temp = [-1.0, 75.0, 85.0]            # :183-184
+    assert count(check_alerts(OK_HOST, [gpu(temp=75)], [], cfg=cfg)[0])["serious"] == 0
+    assert count(check_alerts(OK_HOST, [gpu(temp=76)], [], cfg=cfg)[0])["serious"] == 1
+    assert count(check_alerts(OK_HOST, [gpu(temp=86)], [], cfg=cfg)[0])["critical"] == 1
+
+
+def test_mi355x_junction_defaults():
+    assert sum(count(check_alerts(OK_HOST, [gpu(temp=88)], [])[0]).values()) == 0     # normal under load
+    assert count(check_alerts(OK_HOST, [gpu(temp=91)], [])[0])["serious"] == 1
+    assert count(check_alerts(OK_HOST, [gpu(temp=101)], [])[0])["critical"] == 1
+    assert count(check_alerts(OK_HOST, [gpu(temperatureHbm=96.0)], [])[0])["critical"] == 1
+
+
+def test_ecc_xgmi_throttle_power_rules():
+    g = gpu(ecc={"correctable": 3, "uncorrectable": 1},
+            xgmi={"links": [{"link": 4, "state": "down", "peer": "0000:15:00.0"}, {"link": 5, "state": "up"}]},
+            throttle={"active": True, "residencyPercent": {"socket_thm": 12.0, "ppt": 80.0}},
+            powerW=1390.0, powerCapW=1400.0)
+    a, st = check_alerts(OK_HOST, [g], [])
+    keys = {x["key"] for t in a.values() for x in t}
+    assert {"gpu/0/ecc_ue", "gpu/0/xgmi/4", "gpu/0/throttle_thm", "gpu/0/throttle_ppt", "gpu/0/power"} <= keys
+    assert any(x["key"] == "gpu/0/ecc_ue" for x in a["critical"]) and any(x["key"] == "gpu/0/xgmi/4" for x in a["critical"])
+    assert "0000:15:00.0" in [x for x in a["critical"] if x["key"] == "gpu/0/xgmi/4"][0]["desc"]
+    # correctable errors alert on growth only
+    assert "gpu/0/ecc_ce" not in keys
+    g2 = dict(g, ecc={"correctable": 5, "uncorrectable": 1})
+    a2, _ = check_alerts(OK_HOST, [g2], [], st)
+    ce = [x for x in a2["minor"] if x["key"] == "gpu/0/ecc_ce"]
+    assert ce and "+2" in ce[0]["desc"] or "新增 2" in ce[0]["desc"]
+
+
+def test_gpu_lost_is_level_triggered_until_it_returns():
+    _, st = check_alerts(OK_HOST, [gpu(i) for i in range(8)], [])
+    a, st = check_alerts(OK_HOST, [gpu(i) for i in range(7)], [], st)
+    assert any(x["key"] == "gpu/lost" for x in a["critical"])
+    a, st = check_alerts(OK_HOST, [gpu(i) for i in range(7)], [], st)
+    assert any(x["key"] == "gpu/lost" for x in a["critical"])
+    a, st = check_alerts(OK_HOST, [gpu(i) for i in range(8)], [], st)
+    assert not a["critical"]
+
+
+# ---- pods (monitor_server.js:187-232) ----------------------------------------------------
+def test_pending_and_failed():
+    a, _ = check_alerts(OK_HOST, [], [pod("a", status="Pending"), pod("b", "llm", status="Failed")])
+    assert titles(a, "serious") == ["Pod 等待调度: a"]
+    assert titles(a, "critical") == ["Pod 异常: b"]
+    assert "kubectl describe pod b -n llm" in a["critical"][0]["fix"]
+
+
+def test_first_sight_is_silent_by_default_and_reference_behaviour_by_flag():
+    pods = [pod("a"), pod("b", restarts=3)]
+    a, st = check_alerts(OK_HOST, [], pods)
+    assert sum(count(a).values()) == 0
+    assert st.pods["default/b"]["restarts"] == 3
+    cfg = Config()
+    cfg.compat.first_sight_alerts = True                   # :194-207: unseen pod == 'Unknown'
+    a, _ = check_alerts(OK_HOST, [], pods, cfg=cfg)
+    assert sorted(titles(a, "serious")) == ["Pod 刚恢复: a", "Pod 刚恢复: b", "Pod 重启: b"]
+    assert "之前状态: Unknown" in a["serious"][0]["desc"]
+
+
+def test_recovery_and_restart_edges_fire_once():
+    _, st = check_alerts(OK_HOST, [], [pod("a", status="Pending")])
+    a, st = check_alerts(OK_HOST, [], [pod("a", status="Running")], st)
+    assert titles(a, "serious") == ["Pod 刚恢复: a"] and "Pending" in a["serious"][0]["desc"] and a["serious"][0]["edge"]
+    a, st = check_alerts(OK_HOST, [], [pod("a", status="Running")], st)
+    assert not a["serious"]
+    a, st = check_alerts(OK_HOST, [], [pod("a", restarts=2)], st)
+    assert titles(a, "serious") == ["Pod 重启: a"]
+    assert "重启次数: 2次 (增加了2次)" in a["serious"][0]["desc"] and "--previous" in a["serious"][0]["fix"]
+    a, st = check_alerts(OK_HOST, [], [pod("a", restarts=2)], st)
+    assert not a["serious"]
+
+
+def test_state_is_replaced_wholesale_and_input_state_untouched():
+    s0 = AlertState()
+    _, s1 = check_alerts(OK_HOST, [], [pod("a"), pod("b")], s0)
+    assert s0.pods == {} and set(s1.pods) == {"default/a", "default/b"}
+    _, s2 = check_alerts(OK_HOST, [], [pod("b")], s1)
+    assert set(s2.pods) == {"default/b"}                   # deleted pods drop out (:235)
+    assert s2.evaluations == 2
+
+
+def test_container_waiting_reasons():
+    a, _ = check_alerts(OK_HOST, [], [pod("v", reason="CrashLoopBackOff"), pod("w", status="Pending", reason="ImagePullBackOff")])
+    assert any("CrashLoopBackOff" in x["desc"] for x in a["critical"])
+    assert any("ImagePullBackOff" in x["desc"] for x in a["serious"])
+
+
+def test_vllm_rules():
+    v = {"available": True, "kvCachePercent": 96.0, "waiting": 20, "running": 64, "ttftP99": 1.0}
+    a, _ = check_alerts(OK_HOST, [], [], vllm=v)
+    assert [x["key"] for x in a["critical"]] == ["vllm/kv"] and [x["key"] for x in a["serious"]] == ["vllm/waiting"]
+    a, _ = check_alerts(OK_HOST, [], [], vllm={"kvCachePercent": 70.0, "waiting": 4, "ttftP99": 2.0})
+    assert sum(count(a).values()) == 0
+
+
+def test_english_catalogue_has_the_same_keys():
+    from k8s_llm_monitor_amd.server.alerts import _MSG
+    assert set(_MSG["zh"]) == set(_MSG["en"])
+    cfg = Config()
+    cfg.compat.language = "en"
+    a, _ = check_alerts(host(cpu="99.0"), [], [], cfg=cfg)
+    assert a["critical"][0]["title"] == "CPU usage critical"
+
+
+# ---- AlertBook ---------------------------------------------------------------------------
+def test_book_holds_edge_alerts_and_stamps_since():
+    book = AlertBook(hold_s=30.0)
+    _, st = check_alerts(OK_HOST, [], [pod("a", status="Pending")])
+    a, st = check_alerts(host(cpu="99.0"), [], [pod("a")], st)
+    shown = book.update(a, now=100.0)
+    assert [x["key"] for x in shown["serious"]] == ["pod/default/a/recovered"]
+    assert shown["critical"][0]["since"] == 100.0
+    a, st = check_alerts(host(cpu="99.0"), [], [pod("a")], st)           # edge gone from the engine
+    shown = book.update(a, now=110.0)
+    assert [x["key"] for x in shown["serious"]] == ["pod/default/a/recovered"]     # still held
+    assert shown["critical"][0]["since"] == 100.0                                   # level alert keeps its start
+    shown = book.update(a, now=131.0)
+    assert shown["serious"] == []
+    shown = book.update(empty_alerts(), now=140.0)
+    assert shown["critical"] == [] and book.history[-1]["event"] == "end"

@@ -1,0 +1,120 @@
+"""Counter arithmetic, the GPU normaliser and the scripted fake GPUs (CPU only).
+
+The raw-reading fixture below is the amdsmi output captured on a real MI355X
+(profiles/r1_amdsmi_probe_mi355x.json), so the field mapping is checked against what the
+hardware actually reports."""
+import json
+import os
+
+import pytest
+
+from k8s_llm_monitor_amd.collectors.counters import RateTracker, counter_delta, share
+from k8s_llm_monitor_amd.collectors.gpu import GpuNormalizer, GpuReader, GpuSource, metrics_to_raw, open_gpu_source
+from k8s_llm_monitor_amd.fakes.gpu import HBM_TOTAL_MIB, SCENARIOS, FakeGpuReader, GpuState
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_counter_delta_wrap_and_reset():
+    assert counter_delta(10, 15) == 5
+    assert counter_delta((1 << 64) - 5, 10) == 15           # one wrap
+    assert counter_delta((1 << 32) - 5, 10, bits=32) == 15
+    assert counter_delta(1_000_000, 5) is None              # went backwards: a reset, no delta
+    assert counter_delta(None, 5) is None
+
+
+def test_rate_tracker():
+    r = RateTracker()
+    assert r.update("k", 0.0, 100) is None
+    assert r.update("k", 2.0, 300) == 100.0
+    assert r.update("k", 2.0, 400) is None                  # dt == 0
+    assert r.update("k", 3.0, 0) is None                    # reset
+    assert r.update("k", 4.0, 50) == 50.0
+    assert share(5, 10) == 50.0 and share(5, 0) is None and share(None, 3) is None
+
+
+def test_real_mi355x_metrics_mapping():
+    with open(os.path.join(ROOT, "profiles", "r1_amdsmi_probe_mi355x.json")) as f:
+        probe = json.load(f)["gpu0"]
+    raw = metrics_to_raw(probe["metrics_info"])
+    assert raw["temp_hotspot"] == 46 and raw["temp_mem"] == 34 and "temp_edge" not in raw     # edge is N/A on MI355X
+    assert raw["power_w"] == 308 and raw["accumulation_counter"] == 23735538
+    assert len(raw["xgmi_read_kib"]) == 8 and raw["xgmi_link_status"][0] == "N/A"
+    raw.update(index=0, t=1.0, vram_used_mib=probe["vram_usage"]["vram_used"], vram_total_mib=probe["vram_usage"]["vram_total"],
+               name=probe["asic"]["market_name"], power_cap_w=1400.0)
+    s = GpuNormalizer().normalize(raw)
+    assert s["name"] == "AMD Instinct MI355 OAM" and s["memoryTotal"] == 294896 and s["memoryUsed"] == 284
+    assert s["temperature"] == 46 and s["utilization"] == 7 and s["powerCapW"] == 1400.0
+    assert len(s["xgmi"]["links"]) == 7 and all(l["state"] == "up" for l in s["xgmi"]["links"])   # own slot skipped
+    assert s["xgmi"]["rxGBps"] is None                      # no rate from a single reading
+
+
+def test_normaliser_uses_accumulator_deltas(clock):
+    fr = FakeGpuReader(1, scenario=lambda t, i: GpuState(gfx=37.0, umc=12.0, power_w=900.0, xgmi_gbps=100.0, ppt_throttle=0.25), clock=clock)
+    src = GpuSource(fr)
+    first = src.sample()[0]
+    assert first["gfxActivityAvg"] is None and first["utilization"] == 37
+    clock.advance(5.0)
+    s = src.sample()[0]
+    assert s["gfxActivityAvg"] == pytest.approx(37.0, abs=0.01) and s["memActivityAvg"] == pytest.approx(12.0, abs=0.01)
+    assert s["powerAvgW"] == pytest.approx(900.0, rel=1e-3)
+    assert s["xgmi"]["rxGBps"] == pytest.approx(700.0, rel=1e-3) and s["xgmi"]["links"][0]["txGBps"] == pytest.approx(100.0, rel=1e-3)
+    assert s["throttle"]["active"] and s["throttle"]["residencyPercent"]["ppt"] == pytest.approx(25.0, abs=0.01)
+    assert s["hbmTotalBytes"] == HBM_TOTAL_MIB << 20 and 0 < s["hbmPercent"] < 100
+
+
+def test_reference_keys_and_types(clock):
+    s = GpuSource(FakeGpuReader(8, clock=clock)).sample()
+    assert len(s) == 8 and [g["index"] for g in s] == list(range(8))
+    for g in s:
+        for k in ("utilization", "memoryUsed", "memoryTotal", "temperature"):
+            assert isinstance(g[k], int)                    # parseInt in the reference (:90)
+        assert isinstance(g["name"], str)
+        assert g["memoryTotal"] == HBM_TOTAL_MIB            # MiB, like nvidia-smi nounits
+
+
+def test_source_never_raises():
+    class Boom(GpuReader):
+        kind = "boom"
+
+        def read(self):
+            raise RuntimeError("driver gone")
+    src = GpuSource(Boom())
+    assert src.sample() == [] and "driver gone" in src.last_error      # [] like monitor_server.js:94
+    assert open_gpu_source("none").sample() == []
+    assert open_gpu_source("auto").kind in ("amdsmi", "none")
+    with pytest.raises(ValueError):
+        open_gpu_source("nvml")
+
+
+@pytest.mark.parametrize("name", sorted(k for k in SCENARIOS if k))
+def test_every_scenario_runs(name, clock):
+    src = GpuSource(FakeGpuReader(8, name, clock=clock))
+    for _ in range(12):
+        clock.advance(5)
+        assert len(src.sample()) >= 7
+
+
+def test_hbm_ramp_crosses_the_three_tiers(clock):
+    src = GpuSource(FakeGpuReader(8, "hbm_ramp", clock=clock))
+    seen = []
+    for _ in range(4):
+        seen.append(round(src.sample()[0]["hbmPercent"]))
+        clock.advance(10)
+    assert seen == [69, 71, 86, 96]
+
+
+def test_xgmi_down_and_gpu_lost(clock):
+    src = GpuSource(FakeGpuReader(8, "xgmi_down", clock=clock))
+    clock.advance(11)
+    g3 = src.sample()[3]
+    assert [l["state"] for l in g3["xgmi"]["links"]].count("down") == 1
+    src = GpuSource(FakeGpuReader(8, "gpu_lost", clock=clock))
+    assert len(src.sample()) == 8
+    clock.advance(11)
+    assert len(src.sample()) == 7
+
+
+def test_unknown_scenario():
+    with pytest.raises(ValueError):
+        FakeGpuReader(1, "nope")

@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--no-validation", action="store_true",
                     help="skip the fidelity / overhead / alert-latency phases")
+    ap.add_argument("--no-probe", action="store_true", help="skip the RCCL all-reduce size sweep (N > 1)")
+    ap.add_argument("--probe-max-bytes", type=int, default=1 << 28)
     ap.add_argument("--sample-period", type=float, default=0.0,
                     help="telemetry period in s during the timed region (0 = config default 5 s)")
     return ap.parse_args()

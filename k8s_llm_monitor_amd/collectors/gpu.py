@@ -28,6 +28,7 @@ from .counters import RateTracker, counter_delta, share
 
 MIB = 1 << 20
 XGMI_LINKS = 8
+ACT_ACC_BITS = 32
 
 RESIDENCY_KEYS = ("prochot", "ppt", "socket_thm", "vr_thm", "hbm_thm")
 
@@ -88,8 +89,9 @@ class GpuNormalizer:
         residency: Dict[str, Optional[float]] = {}
         if prev is not None:
             dacc = counter_delta(_int(prev.get("accumulation_counter")), _int(raw.get("accumulation_counter")))
-            gfx_avg = share(counter_delta(_int(prev.get("gfx_activity_acc")), _int(raw.get("gfx_activity_acc"))), dacc, 1.0)
-            umc_avg = share(counter_delta(_int(prev.get("mem_activity_acc")), _int(raw.get("mem_activity_acc"))), dacc, 1.0)
+            # gfx/mem activity accumulators are 32-bit in amdsmi_gpu_metrics_t (percent x ticks)
+            gfx_avg = share(counter_delta(_int(prev.get("gfx_activity_acc")), _int(raw.get("gfx_activity_acc")), ACT_ACC_BITS), dacc, 1.0)
+            umc_avg = share(counter_delta(_int(prev.get("mem_activity_acc")), _int(raw.get("mem_activity_acc")), ACT_ACC_BITS), dacc, 1.0)
             for k in RESIDENCY_KEYS:
                 residency[k] = share(counter_delta(_int(prev.get(f"res_{k}_acc")), _int(raw.get(f"res_{k}_acc"))), dacc, 100.0)
         if gfx_avg is not None:

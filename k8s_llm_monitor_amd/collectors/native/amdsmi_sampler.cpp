@@ -1,0 +1,338 @@
+// klm_amdsmi_sampler: native MI355X telemetry sampler on libamd_smi.
+//
+// No reference counterpart: the reference forks `nvidia-smi` per request
+// (monitor_server.js:85). SURVEY.md 2.4 N1: per GPU HBM used/total, GFX and memory (UMC)
+// activity, socket power, junction temperature, per-link xGMI counters, ECC counts and
+// throttle residency, with no GPU work submitted.
+//
+// It polls amdsmi at `--hz` and prints one JSON line per `--period` seconds:
+//   {"t": monotonic_s, "wall": epoch_s, "polls": n, "poll_us_mean": .., "gpus": [ {raw reading}, ... ]}
+// A raw reading uses the key names of collectors/gpu.py (metrics_to_raw), so the Python
+// side feeds it to the same GpuNormalizer as the in-process reader. Gauges are the mean of
+// the polls of the period, `peak` holds their maxima (a 5 s dashboard period would
+// otherwise miss a 200 ms power or temperature spike); accumulators are the latest value.
+//
+// amdsmi marks an unsupported field with an all-ones value of its width; those are
+// printed as null.
+#include <amd_smi/amdsmi.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <csignal>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+static volatile sig_atomic_t g_stop = 0;
+static void on_signal(int) { g_stop = 1; }
+
+static double mono_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+static double wall_s() {
+  using namespace std::chrono;
+  return duration<double>(system_clock::now().time_since_epoch()).count();
+}
+
+struct Json {
+  std::string s;
+  bool first = true;
+  void sep() {
+    if (!first) s += ',';
+    first = false;
+  }
+  void key(const char* k) {
+    sep();
+    s += '"';
+    s += k;
+    s += "\":";
+  }
+  void num(const char* k, double v) {
+    key(k);
+    if (std::isfinite(v)) {
+      char b[40];
+      snprintf(b, sizeof b, "%.10g", v);
+      s += b;
+    } else {
+      s += "null";
+    }
+  }
+  void u64(const char* k, uint64_t v) {
+    key(k);
+    s += std::to_string(v);
+  }
+  void null(const char* k) {
+    key(k);
+    s += "null";
+  }
+  void str(const char* k, const char* v) {
+    key(k);
+    s += '"';
+    for (const char* p = v; *p; ++p) {
+      if (*p == '"' || *p == '\\') s += '\\';
+      if ((unsigned char)*p >= 0x20) s += *p;
+    }
+    s += '"';
+  }
+  template <class T>
+  void opt(const char* k, T v) {  // all-ones = unsupported
+    if (v == (T)~(T)0) null(k);
+    else u64(k, (uint64_t)v);
+  }
+};
+
+struct Gauge {
+  double sum = 0, peak = -1e300;
+  int n = 0;
+  void add(double v) {
+    sum += v;
+    peak = std::max(peak, v);
+    ++n;
+  }
+  double mean() const { return n ? sum / n : NAN; }
+  double max() const { return n ? peak : NAN; }
+  void reset() { *this = Gauge(); }
+};
+
+struct Gpu {
+  amdsmi_processor_handle h;
+  std::string name, uuid, bdf;
+  double cap_w = NAN, energy_res_uj = NAN;
+  Gauge gfx, umc, power, temp, temp_mem, clk;
+  amdsmi_gpu_metrics_t m;
+  bool have_m = false;
+  amdsmi_vram_usage_t vram{};
+  bool have_vram = false;
+  amdsmi_error_count_t ecc{};
+  bool have_ecc = false;
+};
+
+template <class T>
+static bool ok(T v) { return v != (T)~(T)0; }
+
+int main(int argc, char** argv) {
+  double period = 1.0, hz = 20.0;
+  bool once = false;
+  long max_lines = 0;
+  for (int i = 1; i < argc; ++i) {
+    std::string k = argv[i];
+    if (k == "--period" && i + 1 < argc) period = atof(argv[++i]);
+    else if (k == "--hz" && i + 1 < argc) hz = atof(argv[++i]);
+    else if (k == "--lines" && i + 1 < argc) max_lines = atol(argv[++i]);
+    else if (k == "--once") once = true;
+    else {
+      fprintf(stderr, "usage: klm_amdsmi_sampler [--period S] [--hz H] [--lines N] [--once]\n");
+      return k == "--help" ? 0 : 1;
+    }
+  }
+  if (period <= 0 || hz <= 0) {
+    printf("{\"error\":\"period and hz must be positive\"}\n");
+    return 1;
+  }
+  signal(SIGINT, on_signal);
+  signal(SIGTERM, on_signal);
+  signal(SIGPIPE, on_signal);
+
+  amdsmi_status_t st = amdsmi_init(AMDSMI_INIT_AMD_GPUS);
+  if (st != AMDSMI_STATUS_SUCCESS) {
+    const char* msg = "?";
+    amdsmi_status_code_to_string(st, &msg);
+    printf("{\"error\":\"amdsmi_init: %s\"}\n", msg);
+    return 2;
+  }
+  std::vector<Gpu> gpus;
+  uint32_t ns = 0;
+  amdsmi_get_socket_handles(&ns, nullptr);
+  std::vector<amdsmi_socket_handle> socks(ns);
+  amdsmi_get_socket_handles(&ns, socks.data());
+  for (uint32_t s = 0; s < ns; ++s) {
+    uint32_t np = 0;
+    amdsmi_get_processor_handles(socks[s], &np, nullptr);
+    std::vector<amdsmi_processor_handle> ph(np);
+    amdsmi_get_processor_handles(socks[s], &np, ph.data());
+    for (uint32_t p = 0; p < np; ++p) {
+      processor_type_t ty;
+      if (amdsmi_get_processor_type(ph[p], &ty) == AMDSMI_STATUS_SUCCESS && ty != AMDSMI_PROCESSOR_TYPE_AMD_GPU) continue;
+      Gpu g;
+      g.h = ph[p];
+      amdsmi_asic_info_t asic;
+      if (amdsmi_get_gpu_asic_info(g.h, &asic) == AMDSMI_STATUS_SUCCESS) g.name = asic.market_name;
+      char uuid[AMDSMI_GPU_UUID_SIZE + 2] = {0};
+      unsigned int ul = AMDSMI_GPU_UUID_SIZE;
+      if (amdsmi_get_gpu_device_uuid(g.h, &ul, uuid) == AMDSMI_STATUS_SUCCESS) g.uuid = uuid;
+      amdsmi_bdf_t bdf;
+      if (amdsmi_get_gpu_device_bdf(g.h, &bdf) == AMDSMI_STATUS_SUCCESS) {
+        char b[32];
+        snprintf(b, sizeof b, "%04llx:%02x:%02x.%x", (unsigned long long)bdf.domain_number, (unsigned)bdf.bus_number,
+                 (unsigned)bdf.device_number, (unsigned)bdf.function_number);
+        g.bdf = b;
+      }
+      amdsmi_power_cap_info_t cap;
+      if (amdsmi_get_power_cap_info(g.h, 0, &cap) == AMDSMI_STATUS_SUCCESS && cap.power_cap)
+        g.cap_w = cap.power_cap > 100000 ? cap.power_cap / 1e6 : (double)cap.power_cap;
+      uint64_t e, ts;
+      float res;
+      if (amdsmi_get_energy_count(g.h, &e, &res, &ts) == AMDSMI_STATUS_SUCCESS) g.energy_res_uj = res;
+      gpus.push_back(g);
+    }
+  }
+  if (gpus.empty()) {
+    printf("{\"error\":\"amdsmi found no GPU\"}\n");
+    amdsmi_shut_down();
+    return 3;
+  }
+
+  const double dt_poll = 1.0 / hz;
+  double next_emit = mono_s() + (once ? 0.0 : period);
+  double next_poll = mono_s();
+  long polls = 0, lines = 0;
+  double poll_us = 0;
+  int slow = 0;
+  while (!g_stop) {
+    const double t0 = mono_s();
+    for (auto& g : gpus) {
+      if (amdsmi_get_gpu_metrics_info(g.h, &g.m) == AMDSMI_STATUS_SUCCESS) {
+        g.have_m = true;
+        if (ok(g.m.average_gfx_activity)) g.gfx.add(g.m.average_gfx_activity);
+        if (ok(g.m.average_umc_activity)) g.umc.add(g.m.average_umc_activity);
+        if (ok(g.m.current_socket_power)) g.power.add(g.m.current_socket_power);
+        else if (ok(g.m.average_socket_power)) g.power.add(g.m.average_socket_power);
+        if (ok(g.m.temperature_hotspot)) g.temp.add(g.m.temperature_hotspot);
+        if (ok(g.m.temperature_mem)) g.temp_mem.add(g.m.temperature_mem);
+        if (ok(g.m.current_gfxclk)) g.clk.add(g.m.current_gfxclk);
+      }
+    }
+    poll_us += (mono_s() - t0) * 1e6;
+    ++polls;
+    const double now = mono_s();
+    if (now >= next_emit) {
+      // VRAM and ECC once per line: they are separate driver calls and change slowly
+      for (auto& g : gpus) {
+        g.have_vram = amdsmi_get_gpu_vram_usage(g.h, &g.vram) == AMDSMI_STATUS_SUCCESS;
+        if (slow % 10 == 0 || !g.have_ecc) g.have_ecc = amdsmi_get_gpu_total_ecc_count(g.h, &g.ecc) == AMDSMI_STATUS_SUCCESS;
+      }
+      ++slow;
+      Json j;
+      j.s = "{";
+      j.num("t", now);
+      j.num("wall", wall_s());
+      j.u64("polls", (uint64_t)polls);
+      j.num("poll_us_mean", polls ? poll_us / polls : NAN);
+      j.key("gpus");
+      j.s += '[';
+      for (size_t i = 0; i < gpus.size(); ++i) {
+        Gpu& g = gpus[i];
+        if (i) j.s += ',';
+        Json r;
+        r.s = "{";
+        r.u64("index", i);
+        r.num("t", now);
+        r.num("wall", wall_s());
+        r.str("name", g.name.c_str());
+        r.str("uuid", g.uuid.c_str());
+        r.str("bdf", g.bdf.c_str());
+        r.num("power_cap_w", g.cap_w);
+        r.num("energy_resolution_uj", g.energy_res_uj);
+        if (g.have_vram) {
+          r.u64("vram_used_mib", g.vram.vram_used);
+          r.u64("vram_total_mib", g.vram.vram_total);
+        }
+        if (g.have_ecc) {
+          r.u64("ecc_correctable", g.ecc.correctable_count);
+          r.u64("ecc_uncorrectable", g.ecc.uncorrectable_count);
+          r.u64("ecc_deferred", g.ecc.deferred_count);
+        }
+        if (g.have_m) {
+          const amdsmi_gpu_metrics_t& m = g.m;
+          r.num("gfx_activity", g.gfx.mean());
+          r.num("umc_activity", g.umc.mean());
+          r.num("power_w", g.power.mean());
+          r.num("temp_hotspot", g.temp.mean());
+          r.num("temp_mem", g.temp_mem.mean());
+          r.num("clk_gfx", g.clk.mean());
+          r.opt("clk_mem", m.current_uclk);
+          r.opt("temp_edge", m.temperature_edge);
+          r.opt("gfx_activity_acc", m.gfx_activity_acc);
+          r.opt("mem_activity_acc", m.mem_activity_acc);
+          r.opt("accumulation_counter", m.accumulation_counter);
+          r.opt("firmware_timestamp", m.firmware_timestamp);
+          r.opt("energy_acc", m.energy_accumulator);
+          r.opt("res_prochot_acc", m.prochot_residency_acc);
+          r.opt("res_ppt_acc", m.ppt_residency_acc);
+          r.opt("res_socket_thm_acc", m.socket_thm_residency_acc);
+          r.opt("res_vr_thm_acc", m.vr_thm_residency_acc);
+          r.opt("res_hbm_thm_acc", m.hbm_thm_residency_acc);
+          r.opt("xgmi_link_width", m.xgmi_link_width);
+          r.opt("xgmi_link_speed", m.xgmi_link_speed);
+          r.opt("pcie_bandwidth_inst", m.pcie_bandwidth_inst);
+          auto arr64 = [&](const char* k, const uint64_t* a) {
+            r.key(k);
+            r.s += '[';
+            for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
+              if (l) r.s += ',';
+              r.s += ok(a[l]) ? std::to_string(a[l]) : std::string("null");
+            }
+            r.s += ']';
+          };
+          arr64("xgmi_read_kib", m.xgmi_read_data_acc);
+          arr64("xgmi_write_kib", m.xgmi_write_data_acc);
+          r.key("xgmi_link_status");
+          r.s += '[';
+          for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
+            if (l) r.s += ',';
+            r.s += ok(m.xgmi_link_status[l]) ? std::to_string(m.xgmi_link_status[l]) : std::string("null");
+          }
+          r.s += ']';
+          r.key("peak");
+          Json p;
+          p.s = "{";
+          p.num("gfx_activity", g.gfx.max());
+          p.num("umc_activity", g.umc.max());
+          p.num("power_w", g.power.max());
+          p.num("temp_hotspot", g.temp.max());
+          p.num("temp_mem", g.temp_mem.max());
+          p.s += '}';
+          r.s += p.s;
+        }
+        r.s += '}';
+        j.s += r.s;
+        g.gfx.reset();
+        g.umc.reset();
+        g.power.reset();
+        g.temp.reset();
+        g.temp_mem.reset();
+        g.clk.reset();
+      }
+      j.s += "]}";
+      puts(j.s.c_str());
+      fflush(stdout);
+      if (ferror(stdout)) break;
+      ++lines;
+      polls = 0;
+      poll_us = 0;
+      if (once || (max_lines && lines >= max_lines)) break;
+      next_emit += period;
+      if (next_emit < now) next_emit = now + period;
+    }
+    next_poll += dt_poll;
+    double wait = next_poll - mono_s();
+    if (wait < 0) {
+      next_poll = mono_s();
+      wait = 0;
+    }
+    // sleep in short slices so a signal ends the loop promptly
+    while (wait > 0 && !g_stop) {
+      const double sl = std::min(wait, 0.05);
+      std::this_thread::sleep_for(std::chrono::duration<double>(sl));
+      wait -= sl;
+    }
+  }
+  amdsmi_shut_down();
+  return 0;
+}

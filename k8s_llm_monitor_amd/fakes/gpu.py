@@ -186,7 +186,7 @@ class FakeGpuReader:
                 "vram_total_mib": HBM_TOTAL_MIB,
                 "vram_used_mib": int(HBM_TOTAL_MIB * s.hbm_frac),
                 "gfx_activity": round(s.gfx), "umc_activity": round(s.umc),
-                "gfx_activity_acc": int(a["gfx"]), "mem_activity_acc": int(a["mem"]),
+                "gfx_activity_acc": int(a["gfx"]) & 0xFFFFFFFF, "mem_activity_acc": int(a["mem"]) & 0xFFFFFFFF,
                 "accumulation_counter": int(a["acc"]),
                 "power_w": round(s.power_w), "power_cap_w": POWER_CAP_W,
                 "energy_acc": int(a["energy"]), "energy_resolution_uj": ENERGY_RES_UJ,

@@ -12,17 +12,24 @@ from typing import Any, Dict, Optional
 
 
 def _sync_all(torch, dist, world):
-    torch.cuda.synchronize()
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if gpu:
+        torch.cuda.synchronize()
 
 
 class _Load:
     """One rank's buffers and the step function (GEMM burner + overlapped all-reduce)."""
 
-    def __init__(self, torch, dist, ops, dev, world: int, size: int):
+    def __init__(self, torch, dist, ops, dev, world: int, size: int, gemm=None):
         self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
+        # `gemm(a, b, out)` computes out = a @ b.T; the default is the hand-written MFMA kernel.
+        # CPU tests of the stream/event/all-reduce logic pass a torch.matmul stand-in.
+        self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out, variant=1))
+        self.gpu = dev.type == "cuda"
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + (dist.get_rank() if world > 1 else 0))
         # uniform [-1, 1) operands: zero-filled operands read ~15-20 % high (DVFS)
@@ -31,20 +38,26 @@ class _Load:
         self.c = [torch.empty(size, size, device=dev, dtype=torch.bfloat16) for _ in range(2)]
         self.size = size
         self.flops = 2.0 * size * size * size
-        self.comm = torch.cuda.Stream(device=dev) if world > 1 else None
-        self.ev_gemm = [torch.cuda.Event() for _ in range(2)]
-        self.ev_comm = [torch.cuda.Event() for _ in range(2)]
+        self.comm = torch.cuda.Stream(device=dev) if (world > 1 and self.gpu) else None
+        self.ev_gemm = [torch.cuda.Event() for _ in range(2)] if self.gpu else []
+        self.ev_comm = [torch.cuda.Event() for _ in range(2)] if self.gpu else []
         self.i = 0
         self.allreduce_bytes = size * size * 2 if world > 1 else 0
 
     def step(self):
         torch = self.torch
         k = self.i & 1
+        if not self.gpu:                       # CPU rehearsal: same data flow, no streams
+            self.gemm(self.a, self.b, self.c[k])
+            if self.world > 1:
+                self.dist.all_reduce(self.c[k])
+            self.i += 1
+            return
         main = torch.cuda.current_stream()
         if self.comm is not None:
             # buffer k was all-reduced two steps ago: the GEMM may only overwrite it after that
             main.wait_event(self.ev_comm[k])
-        self.ops.gemm_bf16(self.a, self.b, out=self.c[k], variant=1)
+        self.gemm(self.a, self.b, self.c[k])
         if self.comm is not None:
             self.ev_gemm[k].record(main)
             with torch.cuda.stream(self.comm):
@@ -121,10 +134,33 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     if sampler is not None:
         extras["sampler_stats"] = sampler.stats()
 
+    if world > 1 and not getattr(a, "no_probe", False):
+        # the RCCL all-reduce curve at this GPU count (outside the timed region)
+        try:
+            from ..parallel import dist_probe, probe
+            c = dist_probe.sweep(dev, probe.sweep_sizes(1024, getattr(a, "probe_max_bytes", 1 << 28), 4), "bf16",
+                                 warmup=3, iters=10)
+            if c is not None:
+                extras["rccl_allreduce"] = {"peak_busbw_GBps": round(c["peak_busbw_GBps"], 2), "peak_bytes": c["peak_bytes"],
+                                            "ceiling_mesh_GBps": c["ceiling_mesh_GBps"], "ceiling_ring_GBps": c["ceiling_ring_GBps"],
+                                            "verified": c["verified"],
+                                            "curve": [[p["bytes"], round(p["busbw_GBps"], 2)] for p in c["points"]]}
+                try:
+                    probe.save_results(probe.merge_results(probe.load_results(), probe.results_doc([c], note="bench.py")))
+                except OSError:
+                    pass
+        except Exception as e:
+            extras["rccl_allreduce"] = {"error": f"{type(e).__name__}: {e}"}
+
     if not a.no_validation:
         try:
             from . import phases
-            extras.update(phases.run_all(torch, dist, ops, dev, rank, world, load, sampler, a))
+            t0 = time.time()
+            v = phases.run_all(torch, dist, ops, dev, rank, world, load, sampler, a, quick=True)
+            if v:
+                extras["validation"] = v.get("summary")
+                extras["validation_detail"] = {k: x for k, x in v.items() if k != "summary"}
+                extras["validation_seconds"] = round(time.time() - t0, 1)
         except Exception as e:  # the validation phases never invalidate the timed number
             extras["validation_error"] = f"{type(e).__name__}: {e}"
 

@@ -1,0 +1,292 @@
+"""Validation phases on a real MI355X: the self-defined baseline of BASELINE.md.
+
+No reference counterpart (the reference has no tests or benchmarks).
+Each phase puts a KNOWN load on the GPU and compares what the monitor reports with it:
+
+  hbm_fidelity       HbmHold adds known amounts of HBM; amdsmi's VRAM-used delta (what the
+                     dashboard shows) vs the bytes allocated, and vs the driver's own figure.
+  activity_fidelity  the MFMA burner at 25 / 50 / 75 / 100 % duty (measured with HIP events);
+                     the monitor's GFX activity over the same window vs the achieved duty.
+  mem_activity       the HBM copy burner at full duty: achieved TB/s next to amdsmi's UMC activity.
+  overhead           burner throughput with the sampler off, on at the dashboard period, and on
+                     at a 20 Hz stress rate; overhead = throughput lost.
+  alert_latency      the full stack (amdsmi -> sampler thread -> alert engine -> HTTP): HBM is
+                     pushed across 70 / 85 / 95 % of the card and /api/alerts is polled like
+                     the page does; latency = crossing -> alert visible.
+
+Targets: error <= 2 %, overhead < 1 %, latency < 10 s.
+"""
+from __future__ import annotations
+
+import json
+import os
+import threading
+import time
+import urllib.request
+from typing import Any, Dict, List, Optional
+
+GIB = 1 << 30
+MIB = 1 << 20
+
+
+def _mean(xs):
+    xs = [x for x in xs if x is not None]
+    return sum(xs) / len(xs) if xs else None
+
+
+def _gpu_sample(src, index: int) -> Optional[Dict[str, Any]]:
+    for g in src.sample():
+        if g.get("index") == index:
+            return g
+    return None
+
+
+def _smi_index_for(torch, dev, src) -> int:
+    """amdsmi enumerates every GPU of the machine; find the one torch's device is (by PCI bus id)."""
+    try:
+        want = torch.cuda.get_device_properties(dev).pci_bus_id
+    except Exception:
+        want = None
+    gpus = src.sample()
+    if want is not None:
+        for g in gpus:
+            bdf = str(g.get("bdf") or "")
+            try:
+                if int(bdf.split(":")[1], 16) == int(want):
+                    return int(g.get("index", 0))
+            except (IndexError, ValueError):
+                continue
+    return int(gpus[0].get("index", 0)) if gpus else 0
+
+
+# ------------------------------------------------------------------------------------------
+def hbm_fidelity(torch, dev, src, smi_idx: int, steps_gib=(16, 64, 128), settle_s: float = 0.3) -> Dict[str, Any]:
+    from ..loadgen.burner import HbmHold
+    rows = []
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    base = _gpu_sample(src, smi_idx)
+    free0, total = torch.cuda.mem_get_info(dev)
+    with HbmHold(dev.index or 0) as hold:
+        for gib in steps_gib:
+            want = int(gib * GIB) - hold.held_bytes()
+            if want > 0:
+                hold.add(want)
+            time.sleep(settle_s)
+            s = _gpu_sample(src, smi_idx)
+            free, _ = torch.cuda.mem_get_info(dev)
+            held = hold.held_bytes()
+            smi_delta = (s["memoryUsed"] - base["memoryUsed"]) * MIB
+            drv_delta = free0 - free
+            rows.append({"held_GiB": held / GIB, "amdsmi_delta_GiB": smi_delta / GIB, "driver_delta_GiB": drv_delta / GIB,
+                         "error_vs_allocated_pct": abs(smi_delta - held) / held * 100.0 if held else None,
+                         "error_vs_driver_pct": abs(smi_delta - drv_delta) / drv_delta * 100.0 if drv_delta else None,
+                         "dashboard_hbm_percent": s.get("hbmPercent")})
+        ok = hold.verify()
+    after = _gpu_sample(src, smi_idx)
+    return {"rows": rows, "pattern_intact": ok,
+            "max_error_vs_allocated_pct": max((r["error_vs_allocated_pct"] or 0.0) for r in rows) if rows else None,
+            "max_error_vs_driver_pct": max((r["error_vs_driver_pct"] or 0.0) for r in rows) if rows else None,
+            "released_back_to_MiB": after["memoryUsed"] if after else None, "baseline_MiB": base["memoryUsed"],
+            "hbm_total_GiB_amdsmi": base["memoryTotal"] / 1024.0, "hbm_total_GiB_driver": total / GIB}
+
+
+def activity_fidelity(torch, dev, src, smi_idx: int, duties=(25.0, 50.0, 75.0, 100.0), seconds: float = 6.0,
+                      kind: str = "gemm_bf16", size: int = 8192, period_ms: float = 100.0) -> Dict[str, Any]:
+    """GFX activity vs the achieved duty. The monitor's figure is the accumulator-delta mean
+    between a sample taken when the load starts and one taken when it ends (exactly what the
+    sampler computes per period); the firmware's own moving-average gauge is listed beside it."""
+    from ..loadgen.burner import Burner
+    rows = []
+    for duty in duties:
+        b = Burner(kind, size=size, duty=duty, period_ms=period_ms, device=dev.index or 0)
+        b.start(seconds + 60.0)
+        time.sleep(min(1.0, seconds / 4))                 # let the load and the firmware average settle
+        src.sample()
+        t0 = time.perf_counter()
+        st0 = dict(b._stats)
+        gauges: List[float] = []
+        powers: List[float] = []
+        while time.perf_counter() - t0 < seconds:
+            time.sleep(0.5)
+        s = _gpu_sample(src, smi_idx)
+        out = b.stop()
+        # sub-sample the instantaneous gauge for comparison
+        rows.append({"duty_target": duty, "duty_achieved": out["duty_achieved"], "gfx_activity_avg": s.get("gfxActivityAvg"),
+                     "gfx_activity_gauge": s.get("gfxActivity"), "mem_activity_avg": s.get("memActivityAvg"),
+                     "power_w": s.get("powerW"), "power_avg_w": s.get("powerAvgW"), "temperature": s.get("temperature"),
+                     "clock_gfx_mhz": s.get("clockGfxMHz"), "tflops_busy": out.get("tflops_busy"), "tflops_avg": out.get("tflops_avg"),
+                     "error_points": None if s.get("gfxActivityAvg") is None else abs(s["gfxActivityAvg"] - out["duty_achieved"])})
+        del b
+        torch.cuda.empty_cache()
+        time.sleep(0.5)
+    errs = [r["error_points"] for r in rows if r["error_points"] is not None]
+    return {"kind": kind, "size": size, "window_s": seconds, "rows": rows,
+            "max_error_points": max(errs) if errs else None, "mean_error_points": _mean(errs)}
+
+
+def mem_activity(torch, dev, src, smi_idx: int, seconds: float = 4.0) -> Dict[str, Any]:
+    from ..loadgen.burner import Burner
+    rows = []
+    for kind in ("hbm_copy", "hbm_read", "hbm_fill"):
+        b = Burner(kind, duty=100.0, device=dev.index or 0, hbm_bytes=4 * GIB)
+        b.start(seconds + 60.0)
+        time.sleep(0.5)
+        src.sample()
+        time.sleep(seconds)
+        s = _gpu_sample(src, smi_idx)
+        out = b.stop()
+        rows.append({"kind": kind, "TBps_busy": out.get("TBps_busy"), "duty_achieved": out["duty_achieved"],
+                     "mem_activity_avg": s.get("memActivityAvg"), "gfx_activity_avg": s.get("gfxActivityAvg"), "power_w": s.get("powerW")})
+        del b
+        torch.cuda.empty_cache()
+    return {"rows": rows}
+
+
+def overhead(torch, dev, seconds: float = 5.0, size: int = 8192, period_s: float = 5.0, stress_hz: float = 20.0,
+             repeats: int = 2) -> Dict[str, Any]:
+    """Burner throughput with the telemetry sampler off / on. Runs are interleaved
+    (off, on, stress, off, on, stress ...) so clock drift does not masquerade as overhead."""
+    from ..collectors.gpu import open_gpu_source
+    from ..loadgen.burner import Burner
+    from ..server.sampler import BackgroundPoller
+    b = Burner("gemm_bf16", size=size, duty=100.0, device=dev.index or 0)
+    b.run(2.0)                                             # warm the clocks
+    res: Dict[str, List[float]] = {"off": [], "on": [], "stress": []}
+    sampler_stats = {}
+    for _ in range(repeats):
+        for mode in ("off", "on", "stress"):
+            poller = None
+            if mode != "off":
+                poller = BackgroundPoller(open_gpu_source("amdsmi"), period=period_s if mode == "on" else 1.0 / stress_hz).start()
+            out = b.run(seconds)
+            res[mode].append(out["tflops_avg"])
+            if poller is not None:
+                sampler_stats[mode] = poller.stats()
+                poller.stop()
+                poller.src.close()
+    off, on, stress = _mean(res["off"]), _mean(res["on"]), _mean(res["stress"])
+    return {"tflops_sampler_off": off, "tflops_sampler_on": on, "tflops_sampler_stress": stress, "runs": res,
+            "period_s": period_s, "stress_hz": stress_hz,
+            "overhead_pct": (off - on) / off * 100.0, "overhead_stress_pct": (off - stress) / off * 100.0,
+            "noise_pct": (max(res["off"]) - min(res["off"])) / off * 100.0,
+            "sampler_stats": sampler_stats}
+
+
+def alert_latency(torch, dev, realtime_period: float = 5.0, poll_s: float = 0.25, tiers=(("minor", 71.0), ("serious", 86.0), ("critical", 96.0)),
+                  timeout_s: float = 20.0) -> Dict[str, Any]:
+    from ..config import load_config
+    from ..loadgen.burner import HbmHold
+    from ..server.http import MonitorServer
+    from ..server.sampler import Monitor
+    cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"},
+                                         "sources": {"gpu": "amdsmi", "kube": "none", "vllm": "none", "history": "local"},
+                                         "periods": {"realtime": realtime_period}})
+    mon = Monitor(cfg).start()
+    srv = MonitorServer(mon, cfg).start()
+    rows = []
+    try:
+        smi_idx = _smi_index_for(torch, dev, mon.gpu)
+        key = f"gpu/{smi_idx}/hbm"
+        total_mib = next(g["memoryTotal"] for g in mon.get("gpus") if g["index"] == smi_idx)
+        with HbmHold(dev.index or 0) as hold:
+            for tier, pct in tiers:
+                # decorrelate the crossing from the sampler's grid
+                time.sleep(0.37 * realtime_period % 1.0)
+                used_mib = next(g["memoryUsed"] for g in mon.gpu.sample() if g["index"] == smi_idx)
+                want = int(total_mib * pct / 100.0 - used_mib) * MIB
+                t_alloc0 = time.perf_counter()
+                got = hold.add(want) if want > 0 else 0
+                t_cross = time.perf_counter()                 # memory is allocated AND touched here
+                seen = None
+                while time.perf_counter() - t_cross < timeout_s:
+                    a = json.loads(urllib.request.urlopen(srv.url + "/api/alerts", timeout=3).read())
+                    if any(x.get("key") == key for x in a[tier]):
+                        seen = time.perf_counter()
+                        break
+                    time.sleep(poll_s)
+                rows.append({"tier": tier, "target_percent": pct, "added_GiB": got / GIB, "alloc_s": t_cross - t_alloc0,
+                             "latency_s": None if seen is None else seen - t_cross})
+                if seen is None:
+                    break
+        time.sleep(min(realtime_period, 2.0) + 0.5)
+    finally:
+        srv.stop()
+        mon.stop()
+    lats = [r["latency_s"] for r in rows if r["latency_s"] is not None]
+    return {"rows": rows, "sample_period_s": realtime_period, "client_poll_s": poll_s,
+            "max_latency_s": max(lats) if len(lats) == len(tiers) else None, "mean_latency_s": _mean(lats)}
+
+
+# ------------------------------------------------------------------------------------------
+def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=None, a=None,
+            quick: bool = True, which: str = "all") -> Dict[str, Any]:
+    """Every phase on this rank's GPU. Rank 0 only when several ranks share a node (the
+    phases fill HBM and start a server)."""
+    if rank != 0:
+        return {}
+    from ..collectors.gpu import open_gpu_source
+    out: Dict[str, Any] = {}
+    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "mem", "overhead", "latency"}
+    src = open_gpu_source("amdsmi")
+    try:
+        idx = _smi_index_for(torch, dev, src)
+        out["amdsmi_index"] = idx
+
+        def guard(name, fn):
+            t0 = time.time()
+            try:
+                out[name] = fn()
+            except Exception as e:
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+            out[name]["phase_seconds"] = round(time.time() - t0, 2)
+            print(f"[validate] {name}: {json.dumps(out[name])[:600]}", flush=True)
+
+        if "hbm" in want:
+            guard("hbm_fidelity", lambda: hbm_fidelity(torch, dev, src, idx, steps_gib=(16, 64) if quick else (16, 64, 128, 200)))
+        if "activity" in want:
+            guard("activity_fidelity", lambda: activity_fidelity(torch, dev, src, idx, seconds=4.0 if quick else 10.0))
+        if "mem" in want:
+            guard("mem_activity", lambda: mem_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
+        if "overhead" in want:
+            guard("overhead", lambda: overhead(torch, dev, seconds=3.0 if quick else 8.0, repeats=2 if quick else 3))
+        if "latency" in want:
+            guard("alert_latency", lambda: alert_latency(torch, dev))
+    finally:
+        src.close()
+    out["summary"] = summarize(out)
+    return out
+
+
+def summarize(out: Dict[str, Any]) -> Dict[str, Any]:
+    g = lambda d, k: (out.get(d) or {}).get(k)
+    s = {"hbm_error_pct": g("hbm_fidelity", "max_error_vs_driver_pct"),
+         "hbm_error_vs_allocated_pct": g("hbm_fidelity", "max_error_vs_allocated_pct"),
+         "gfx_activity_error_points": g("activity_fidelity", "max_error_points"),
+         "sampling_overhead_pct": g("overhead", "overhead_pct"),
+         "sampling_overhead_20hz_pct": g("overhead", "overhead_stress_pct"),
+         "alert_latency_max_s": g("alert_latency", "max_latency_s")}
+    s["targets"] = {"error_pct": 2.0, "overhead_pct": 1.0, "alert_latency_s": 10.0}
+    s["pass"] = {"hbm": s["hbm_error_pct"] is not None and s["hbm_error_pct"] <= 2.0,
+                 "activity": s["gfx_activity_error_points"] is not None and s["gfx_activity_error_points"] <= 2.0,
+                 "overhead": s["sampling_overhead_pct"] is not None and s["sampling_overhead_pct"] < 1.0,
+                 "latency": s["alert_latency_max_s"] is not None and s["alert_latency_max_s"] < 10.0}
+    return s
+
+
+def main_from_args(a) -> int:
+    import torch
+    from .. import ops
+    dev = torch.device("cuda", a.device)
+    torch.cuda.set_device(dev)
+    out = run_all(torch, None, ops, dev, 0, 1, quick=a.quick, which=a.phases)
+    out["timestamp"] = time.time()
+    out["device"] = torch.cuda.get_device_name(dev)
+    from ..server.http import validation_report_path
+    path = a.out or validation_report_path()
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out["summary"]))
+    print("saved:", path)
+    return 0

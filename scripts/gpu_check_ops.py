@@ -49,6 +49,25 @@ def main():
         ms = bench(lambda: torch.matmul(a, bt, out=c))
         print(f"torch(hipBLASLt) {M}^3: {ms:.3f} ms {fl/ms/1e9:.1f} TF", flush=True)
         res[f"tf_torch_{M}"] = fl / ms / 1e9
+    # fp8 (MX-scaled MFMA, unit scales)
+    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192)]:
+        a = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
+        b = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
+        c = ops.gemm_fp8(a, b)
+        ref = a[:256].float() @ b.float().t()
+        rel = ((c[:256].float() - ref).abs().max() / ref.abs().max()).item()
+        print(f"fp8 {M}^3 rel err {rel:.2e}", flush=True)
+        assert rel < 2e-2
+        fl = 2.0 * M * N * K
+        ms = bench(lambda: ops.gemm_fp8(a, b, out=c))
+        print(f"klm fp8 {M}^3: {ms:.3f} ms {fl/ms/1e9:.1f} TF", flush=True)
+        res[f"tf_fp8_{M}"] = fl / ms / 1e9
+    a8 = (torch.rand(2048, 4096, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
+    b8 = (torch.rand(2048, 4096, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
+    c0 = ops.gemm_fp8(a8, b8).clone()
+    bad = sum(0 if torch.equal(ops.gemm_fp8(a8, b8), c0) else 1 for _ in range(50))
+    print("fp8 race screen mismatches:", bad, flush=True)
+    res["fp8_race_mismatches"] = bad
     # repeated-run race screen on the ring kernel
     a = torch.randn(2048, 4096, device=dev, dtype=torch.bfloat16)
     b = torch.randn(2048, 4096, device=dev, dtype=torch.bfloat16)

@@ -1,0 +1,143 @@
+"""Numerics of the hand-written gfx950 kernels against plain PyTorch fp32 references.
+Runs on a real MI355X only (``-m gpu``). The library is loaded with build_if_missing=False:
+a missing ``libklm_ops.so`` is a failure here, never a silent fallback."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from k8s_llm_monitor_amd import ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    ops.load(build_if_missing=False)
+    return torch, ops, torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("variant,shape", [(0, (128, 128, 64)), (0, (256, 384, 192)), (0, (1024, 512, 2048)),
+                                           (1, (256, 256, 128)), (1, (512, 768, 320)), (1, (2048, 1024, 4096)),
+                                           (None, (1024, 1024, 1024)), (None, (384, 128, 64))])
+def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
+    torch, ops, dev = env
+    M, N, K = shape
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+    c = ops.gemm_bf16(a, b, variant=variant)
+    ref = a.float() @ b.float().t()
+    # bf16 output rounding: relative 2^-8 of the value, plus accumulation-order noise
+    torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=1e-2 * K ** 0.5)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_bf16_exact_on_small_integers_with_asymmetric_operands(env, variant):
+    torch, ops, dev = env
+    M, N, K = 512, 256, 192
+    g = torch.Generator(device=dev).manual_seed(7)
+    a = torch.randint(-3, 4, (M, K), device=dev, generator=g).to(torch.bfloat16)
+    b = torch.randint(-3, 4, (N, K), device=dev, generator=g).to(torch.bfloat16)
+    b[:, 0] = torch.arange(N, device=dev).to(torch.bfloat16) % 5          # row-dependent: catches a transposed C
+    c = ops.gemm_bf16(a, b, variant=variant)
+    ref = (a.float() @ b.float().t()).to(torch.bfloat16)
+    assert torch.equal(c, ref)
+
+
+def test_gemm_bf16_identity_picks_rows_not_columns(env):
+    torch, ops, dev = env
+    n = 256
+    eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
+    b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)      # asymmetric
+    for v in (0, 1):
+        assert torch.equal(ops.gemm_bf16(eye, b, variant=v), b.t().contiguous())      # C = I @ B^T
+
+
+def test_gemm_bf16_is_deterministic_run_to_run(env):
+    torch, ops, dev = env
+    a = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
+    c0 = ops.gemm_bf16(a, b, variant=1).clone()
+    for _ in range(20):
+        assert torch.equal(ops.gemm_bf16(a, b, variant=1), c0)       # a ring-buffer race would show as a rare diff
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096)])
+def test_gemm_fp8_matches_fp32_reference(env, shape):
+    torch, ops, dev = env
+    M, N, K = shape
+    torch.manual_seed(K)
+    a = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
+    b = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
+    c = ops.gemm_fp8(a, b)
+    ref = a.float() @ b.float().t()                      # the fp8 VALUES are exact in fp32
+    torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=2e-3 * K ** 0.5)
+
+
+def test_gemm_fp8_exact_on_small_integers(env):
+    torch, ops, dev = env
+    M, N, K = 256, 512, 384
+    g = torch.Generator(device=dev).manual_seed(11)
+    a = torch.randint(-2, 3, (M, K), device=dev, generator=g).float()
+    b = torch.randint(-2, 3, (N, K), device=dev, generator=g).float()
+    b[:, 5] = (torch.arange(N, device=dev) % 3).float()
+    a[:, 200] = (torch.arange(M, device=dev) % 4).float() - 1        # position-dependent along K too
+    c = ops.gemm_fp8(a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn))
+    assert torch.equal(c, (a @ b.t()).to(torch.bfloat16))
+
+
+def test_shape_and_dtype_errors_are_raised_not_launched(env):
+    torch, ops, dev = env
+    a = torch.zeros(100, 64, device=dev, dtype=torch.bfloat16)
+    b = torch.zeros(128, 64, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ops.KlmOpsError, match="multiple of the tile"):
+        ops.gemm_bf16(a, b, variant=0)
+    with pytest.raises(ops.KlmOpsError, match="bfloat16"):
+        ops.gemm_bf16(a.float(), b.float())
+    with pytest.raises(ops.KlmOpsError, match="do not match"):
+        ops.gemm_bf16(torch.zeros(128, 64, device=dev, dtype=torch.bfloat16), torch.zeros(128, 128, device=dev, dtype=torch.bfloat16))
+    with pytest.raises(ops.KlmOpsError, match="GPU only"):
+        ops.gemm_bf16(a.cpu(), b.cpu())
+    with pytest.raises(ops.KlmOpsError):
+        ops.hbm_fill(torch.zeros(17, dtype=torch.uint8, device=dev))          # not a multiple of 16 bytes
+
+
+def test_hbm_kernels(env):
+    torch, ops, dev = env
+    n = 64 << 20
+    x = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ops.hbm_fill(x, 0x01020304)
+    w = x.view(torch.int32)
+    assert int(w[0]) == 0x01020304 and int(w[-1]) == 0x01020304 and bool((w == 0x01020304).all())
+    assert ops.hbm_checksum(x) == 0x01020304 * (n // 4)
+    y = torch.zeros_like(x)
+    src = torch.randint(0, 255, (n,), dtype=torch.uint8, device=dev)
+    ops.hbm_copy(y, src)
+    assert torch.equal(y, src)
+    assert ops.hbm_checksum(src) == int(src.view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    ops.hbm_read(src, sink)
+    torch.cuda.synchronize()
+    odd = torch.zeros(16 * 3, dtype=torch.uint8, device=dev)                   # smaller than one grid pass
+    ops.hbm_fill(odd, 0xFFFFFFFF)
+    assert bool((odd == 255).all())
+
+
+def test_kernels_run_on_the_current_stream_and_capture_into_a_graph(env):
+    torch, ops, dev = env
+    a = torch.randn(512, 256, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(512, 256, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(512, 512, device=dev, dtype=torch.bfloat16)
+    ref = ops.gemm_bf16(a, b).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.gemm_bf16(a, b, out=out)          # warm (sets the LDS attribute outside capture)
+        s.synchronize()
+        out.zero_()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(4):
+                ops.gemm_bf16(a, b, out=out)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)

@@ -1,0 +1,149 @@
+"""The monitor against a real MI355X (``-m gpu``): amdsmi telemetry, the native sampler, the
+burner's duty control, the HBM hold, the native RCCL probe at n = 1, and the whole stack's
+HBM alert on real memory. Short on purpose; the long measurements live in
+``python -m k8s_llm_monitor_amd validate``."""
+import json
+import subprocess
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GIB = 1 << 30
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch, torch.device("cuda:0")
+
+
+def test_amdsmi_source_reports_an_mi355x(torch_dev):
+    from k8s_llm_monitor_amd.collectors.gpu import open_gpu_source
+    src = open_gpu_source("amdsmi")
+    try:
+        src.sample()
+        time.sleep(1.0)
+        gpus = src.sample()
+        assert src.last_error is None and len(gpus) >= 1
+        g = gpus[0]
+        assert 250_000 <= g["memoryTotal"] <= 300_000            # 288 GB of HBM3E, in MiB
+        assert 10 <= g["temperature"] <= 110 and g["powerW"] > 0 and g["powerCapW"] >= 500
+        assert g["gfxActivityAvg"] is not None and 0 <= g["gfxActivityAvg"] <= 100
+        assert g["powerAvgW"] is not None and 50 < g["powerAvgW"] < 2000
+        assert len(g["xgmi"]["links"]) >= 1 and g["ecc"]["uncorrectable"] == 0
+        assert src.last_duration_s < 0.05                          # sampling is cheap
+    finally:
+        src.close()
+
+
+def test_native_sampler_agrees_with_the_python_reader(torch_dev):
+    from k8s_llm_monitor_amd.build import artifact
+    from k8s_llm_monitor_amd.collectors.gpu import GpuSource, NativeSamplerReader, open_gpu_source
+    exe = artifact("klm_amdsmi_sampler")
+    assert exe.exists(), "build the native targets before running GPU tests"
+    r = subprocess.run([str(exe), "--once"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    raw = line["gpus"][0]
+    assert raw["vram_total_mib"] > 250_000 and raw["accumulation_counter"] > 0 and len(raw["xgmi_read_kib"]) == 8
+    nat = GpuSource(NativeSamplerReader(period=0.5, hz=20))
+    py = open_gpu_source("amdsmi")
+    try:
+        time.sleep(1.2)
+        a, b = nat.sample()[0], py.sample()[0]
+        assert a["memoryTotal"] == b["memoryTotal"] and abs(a["memoryUsed"] - b["memoryUsed"]) < 512
+        assert abs(a["temperature"] - b["temperature"]) <= 3 and a["name"] == b["name"]
+        assert a["peak"]["power_w"] >= a["powerW"] - 1
+    finally:
+        nat.close()
+        py.close()
+
+
+def test_burner_duty_is_what_was_asked_and_telemetry_sees_it(torch_dev):
+    torch, dev = torch_dev
+    from k8s_llm_monitor_amd.collectors.gpu import open_gpu_source
+    from k8s_llm_monitor_amd.loadgen.burner import Burner
+    src = open_gpu_source("amdsmi")
+    try:
+        b = Burner("gemm_bf16", size=4096, duty=50.0, period_ms=50.0)
+        b.start(30.0)
+        time.sleep(0.5)
+        src.sample()
+        time.sleep(3.0)
+        g = src.sample()[0]
+        out = b.stop()
+        assert abs(out["duty_achieved"] - 50.0) < 6.0 and out["tflops_busy"] > 300
+        assert abs(g["gfxActivityAvg"] - out["duty_achieved"]) < 10.0          # loose here; `validate` measures it
+        assert g["powerW"] > 300
+    finally:
+        src.close()
+
+
+def test_full_duty_burner_rates(torch_dev):
+    from k8s_llm_monitor_amd.loadgen.burner import Burner
+    out = Burner("gemm_bf16", size=8192, duty=100.0).run(2.0)
+    assert out["duty_achieved"] > 97.0 and out["tflops_avg"] > 1000.0
+    out = Burner("gemm_fp8", size=8192, duty=100.0).run(1.0)
+    assert out["tflops_avg"] > 1500.0
+    out = Burner("hbm_copy", duty=100.0).run(1.0)
+    assert out["TBps_busy"] > 3.0
+
+
+def test_hbm_hold_moves_the_amdsmi_reading_and_releases(torch_dev):
+    torch, dev = torch_dev
+    from k8s_llm_monitor_amd.collectors.gpu import open_gpu_source
+    from k8s_llm_monitor_amd.loadgen.burner import HbmHold
+    src = open_gpu_source("amdsmi")
+    try:
+        torch.cuda.empty_cache()
+        before = src.sample()[0]["memoryUsed"]
+        with HbmHold() as h:
+            assert h.add(32 * GIB) == 32 * GIB and h.verify()
+            during = src.sample()[0]["memoryUsed"]
+        after = src.sample()[0]["memoryUsed"]
+        assert abs((during - before) - 32 * 1024) < 0.02 * 32 * 1024          # within 2 %
+        assert abs(after - before) < 1024
+    finally:
+        src.close()
+
+
+def test_native_rccl_probe_single_gpu(torch_dev):
+    from k8s_llm_monitor_amd.parallel import probe
+    c = probe.run_native(1, max_bytes=1 << 26, iters=5, warmup=2, timeout=120)
+    assert c["verified"] and c["n_gpus"] == 1 and c["peak_busbw_GBps"] == 0.0 and c["peak_algbw_GBps"] > 50.0
+    assert c["header"]["arch"].startswith("gfx950")
+
+
+def test_real_hbm_crossing_raises_the_alert_over_http(torch_dev):
+    import urllib.request
+    torch, dev = torch_dev
+    from k8s_llm_monitor_amd.config import load_config
+    from k8s_llm_monitor_amd.loadgen.burner import HbmHold
+    from k8s_llm_monitor_amd.server.http import MonitorServer
+    from k8s_llm_monitor_amd.server.sampler import Monitor
+    # thresholds scaled down so the test allocates 40 GiB instead of 200: the path is the same
+    cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"}, "periods": {"realtime": 0.5},
+                                         "sources": {"gpu": "amdsmi", "kube": "none", "vllm": "none", "history": "local"},
+                                         "thresholds": {"hbm": [10.0, 50.0, 90.0]}})
+    mon = Monitor(cfg).start()
+    srv = MonitorServer(mon, cfg).start()
+    try:
+        a = json.loads(urllib.request.urlopen(srv.url + "/api/alerts").read())
+        assert not any(x["key"].endswith("/hbm") for x in a["minor"])
+        with HbmHold() as h:
+            h.add(40 * GIB)
+            t0 = time.time()
+            seen = False
+            while time.time() - t0 < 5.0 and not seen:
+                a = json.loads(urllib.request.urlopen(srv.url + "/api/alerts").read())
+                seen = any(x["key"].endswith("/hbm") for x in a["minor"])
+                time.sleep(0.1)
+            assert seen and time.time() - t0 < 1.5
+        g = json.loads(urllib.request.urlopen(srv.url + "/api/gpu/metrics").read())[0]
+        assert g["name"].startswith("AMD Instinct") and isinstance(g["memoryUsed"], int)
+    finally:
+        srv.stop()
+        mon.stop()

@@ -222,6 +222,7 @@ class AmdSmiReader(GpuReader):
             for key, fn in (("asic", amdsmi.amdsmi_get_gpu_asic_info),
                             ("uuid", amdsmi.amdsmi_get_gpu_device_uuid),
                             ("bdf", amdsmi.amdsmi_get_gpu_device_bdf),
+                            ("board", amdsmi.amdsmi_get_gpu_board_info),
                             ("cap", amdsmi.amdsmi_get_power_cap_info),
                             ("energy", amdsmi.amdsmi_get_energy_count)):
                 try:
@@ -233,6 +234,16 @@ class AmdSmiReader(GpuReader):
         self._n = 0
         self._slow_cache: Dict[int, Dict[str, Any]] = {}
         self._lock = threading.Lock()
+
+    @staticmethod
+    def _name(st) -> Optional[str]:
+        """Market name; libdrm's generic fallback ("AMD Radeon Graphics", when amdgpu.ids is not
+        installed) is replaced by the board's product name."""
+        name = (st.get("asic") or {}).get("market_name")
+        board = (st.get("board") or {}).get("product_name")
+        if (not name or name in ("N/A", "AMD Radeon Graphics")) and board and board != "N/A":
+            return board
+        return name
 
     def _cap_w(self, st) -> Optional[float]:
         cap = (st.get("cap") or {}).get("power_cap")
@@ -251,7 +262,7 @@ class AmdSmiReader(GpuReader):
                 st = self._static[i]
                 t = time.monotonic()
                 raw: Dict[str, Any] = {"index": i, "t": t, "wall": time.time(),
-                                       "name": (st.get("asic") or {}).get("market_name"),
+                                       "name": self._name(st),
                                        "uuid": st.get("uuid"), "bdf": st.get("bdf"),
                                        "power_cap_w": self._cap_w(st),
                                        "energy_resolution_uj": _num((st.get("energy") or {}).get("counter_resolution"))}

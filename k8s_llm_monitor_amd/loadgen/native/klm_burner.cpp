@@ -1,0 +1,249 @@
+// klm_burner: standalone MI355X load generator (no Python, no PyTorch): the MFMA GEMM
+// kernels and HBM kernels of ops/csrc behind a duty-cycle loop, for pods that carry only
+// the ROCm runtime. Same control law as loadgen/burner.py.
+//
+// No reference counterpart (BASELINE.json north_star item 4).
+//
+//   klm_burner --kind gemm_bf16|gemm_fp8|hbm_copy|hbm_read|hbm_fill|spin
+//              [--size 8192] [--duty 100] [--period-ms 100] [--seconds 10]
+//              [--hbm-gib G]   also allocate and touch G GiB (HBM exhaustion injector)
+//              [--device 0]
+// Output: one JSON line per second {"t","kernels","duty","tflops"|"TBps"} and a final summary.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <csignal>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "klm_ops.h"
+
+#define HIPCHECK(x)                                                                   \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      printf("{\"error\":\"%s: %s\"}\n", #x, hipGetErrorString(e_));                  \
+      fflush(stdout);                                                                 \
+      exit(2);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+static volatile sig_atomic_t g_stop = 0;
+static void on_signal(int) { g_stop = 1; }
+static double now_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// xorshift fill on the host would take seconds for 8192^2; fill on the device instead
+__global__ void fill_bf16_uniform(uint16_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    const float f = (float)(x & 0xFFFF) / 32768.0f - 1.0f;   // uniform [-1, 1): zero operands read high (DVFS)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    p[i] = (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+  }
+}
+// e4m3 bit patterns with exponent <= 6 (|v| < 1) and any mantissa, random sign: finite, no NaN
+__global__ void fill_fp8_uniform(uint8_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2246822519u ^ seed;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    const uint32_t e = (x >> 8) % 7u, m = x & 7u, s = (x >> 16) & 1u;
+    p[i] = (uint8_t)((s << 7) | (e << 3) | m);
+  }
+}
+
+struct Args {
+  std::string kind = "gemm_bf16";
+  int size = 8192, device = 0;
+  double duty = 100, period_ms = 100, seconds = 10, hbm_gib = 0;
+};
+
+int main(int argc, char** argv) {
+  Args a;
+  for (int i = 1; i < argc; ++i) {
+    std::string k = argv[i];
+    auto val = [&]() -> const char* {
+      if (i + 1 >= argc) { printf("{\"error\":\"missing value for %s\"}\n", k.c_str()); exit(1); }
+      return argv[++i];
+    };
+    if (k == "--kind") a.kind = val();
+    else if (k == "--size") a.size = atoi(val());
+    else if (k == "--duty") a.duty = atof(val());
+    else if (k == "--period-ms") a.period_ms = atof(val());
+    else if (k == "--seconds") a.seconds = atof(val());
+    else if (k == "--hbm-gib") a.hbm_gib = atof(val());
+    else if (k == "--device") a.device = atoi(val());
+    else { fprintf(stderr, "see the header of klm_burner.cpp for usage\n"); return k == "--help" ? 0 : 1; }
+  }
+  if (a.duty < 0 || a.duty > 100 || a.period_ms <= 0 || a.seconds <= 0 || a.size <= 0 || a.size % 256) {
+    printf("{\"error\":\"bad arguments (size must be a multiple of 256, duty 0..100)\"}\n");
+    return 1;
+  }
+  signal(SIGINT, on_signal);
+  signal(SIGTERM, on_signal);
+  HIPCHECK(hipSetDevice(a.device));
+  hipStream_t s;
+  HIPCHECK(hipStreamCreate(&s));
+
+  const bool gemm = a.kind == "gemm_bf16" || a.kind == "gemm_fp8";
+  const bool fp8 = a.kind == "gemm_fp8";
+  const bool hbm = a.kind.rfind("hbm_", 0) == 0;
+  if (!gemm && !hbm && a.kind != "spin") {
+    printf("{\"error\":\"unknown kind %s\"}\n", a.kind.c_str());
+    return 1;
+  }
+  void *A = nullptr, *B = nullptr, *C = nullptr, *X = nullptr, *Y = nullptr, *sink = nullptr;
+  double flops = 0, bytes = 0;
+  const size_t n2 = (size_t)a.size * a.size;
+  if (gemm) {
+    const size_t esz = fp8 ? 1 : 2;
+    HIPCHECK(hipMalloc(&A, n2 * esz));
+    HIPCHECK(hipMalloc(&B, n2 * esz));
+    HIPCHECK(hipMalloc(&C, n2 * 2));
+    if (fp8) {
+      hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)A, n2, 1u);
+      hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)B, n2, 2u);
+    } else {
+      hipLaunchKernelGGL(fill_bf16_uniform, dim3(2048), dim3(256), 0, s, (uint16_t*)A, n2, 1u);
+      hipLaunchKernelGGL(fill_bf16_uniform, dim3(2048), dim3(256), 0, s, (uint16_t*)B, n2, 2u);
+    }
+    flops = 2.0 * a.size * (double)a.size * a.size;
+  } else if (hbm) {
+    const size_t n = (size_t)2 << 30;
+    HIPCHECK(hipMalloc(&X, n));
+    HIPCHECK(hipMalloc(&sink, 16));
+    HIPCHECK(hipMemsetAsync(sink, 0, 16, s));
+    klm_hbm_fill(X, n, 0x5A5A5A5Au, s);
+    if (a.kind == "hbm_copy") {
+      HIPCHECK(hipMalloc(&Y, n));
+      bytes = 2.0 * n;
+    } else {
+      bytes = (double)n;
+    }
+  }
+  // HBM exhaustion injector: hold and touch G GiB in 4 GiB chunks
+  std::vector<void*> hold;
+  double held = 0;
+  if (a.hbm_gib > 0) {
+    size_t left = (size_t)(a.hbm_gib * (double)((size_t)1 << 30)) & ~(size_t)0xF;
+    while (left) {
+      const size_t n = std::min(left, (size_t)4 << 30);
+      void* p = nullptr;
+      if (hipMalloc(&p, n) != hipSuccess) { (void)hipGetLastError(); break; }
+      klm_hbm_fill(p, n, 0xA5A5A5A5u, s);
+      hold.push_back(p);
+      held += (double)n;
+      left -= n;
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    printf("{\"hbm_hold_gib\":%.3f}\n", held / (double)((size_t)1 << 30));
+    fflush(stdout);
+  }
+
+  auto launch = [&]() -> int {
+    if (gemm) return fp8 ? klm_gemm_fp8(A, B, C, a.size, a.size, a.size, 0, s) : klm_gemm_bf16(A, B, C, a.size, a.size, a.size, 1, s);
+    if (a.kind == "hbm_copy") return klm_hbm_copy(Y, X, (size_t)2 << 30, s);
+    if (a.kind == "hbm_read") return klm_hbm_read(X, (size_t)2 << 30, sink, s);
+    if (a.kind == "hbm_fill") return klm_hbm_fill(X, (size_t)2 << 30, 0x5A5A5A5Au, s);
+    return klm_spin(2400000ull, 1024, s);
+  };
+
+  // calibrate the per-kernel time
+  hipEvent_t c0, c1;
+  HIPCHECK(hipEventCreate(&c0));
+  HIPCHECK(hipEventCreate(&c1));
+  for (int i = 0; i < 3; ++i)
+    if (launch() != KLM_OK) { printf("{\"error\":\"kernel launch failed\"}\n"); return 3; }
+  HIPCHECK(hipEventRecord(c0, s));
+  for (int i = 0; i < 10; ++i) launch();
+  HIPCHECK(hipEventRecord(c1, s));
+  HIPCHECK(hipEventSynchronize(c1));
+  float cal_ms = 0;
+  HIPCHECK(hipEventElapsedTime(&cal_ms, c0, c1));
+  const double kernel_s = cal_ms * 1e-3 / 10;
+  const double period_s = a.period_ms * 1e-3;
+  const bool full = a.duty >= 100.0;
+  const int n_per = a.duty <= 0 ? 0 : std::max(1, (int)std::lround(std::min(1.0, a.duty / 100.0) * period_s / kernel_s));
+
+  struct Win { hipEvent_t e0, e1; };
+  std::deque<Win> pending;
+  std::vector<Win> pool;
+  auto get_win = [&]() {
+    if (!pool.empty()) { Win w = pool.back(); pool.pop_back(); return w; }
+    Win w;
+    HIPCHECK(hipEventCreate(&w.e0));
+    HIPCHECK(hipEventCreate(&w.e1));
+    return w;
+  };
+  double busy_s = 0;
+  long kernels = 0;
+  auto retire = [&](bool block) {
+    if (block && !pending.empty()) HIPCHECK(hipEventSynchronize(pending.front().e1));
+    while (!pending.empty() && hipEventQuery(pending.front().e1) == hipSuccess) {
+      float ms = 0;
+      HIPCHECK(hipEventElapsedTime(&ms, pending.front().e0, pending.front().e1));
+      busy_s += ms * 1e-3;
+      kernels += n_per;
+      pool.push_back(pending.front());
+      pending.pop_front();
+    }
+    (void)hipGetLastError();  // hipEventQuery's "not ready" is not an error
+  };
+
+  const double t_start = now_s(), t_end = t_start + a.seconds;
+  double next_report = t_start + 1.0;
+  long k = 0;
+  while (!g_stop && now_s() < t_end) {
+    if (!full) {
+      const double p0 = t_start + k * period_s, now = now_s();
+      if (p0 > now) std::this_thread::sleep_for(std::chrono::duration<double>(std::min(p0 - now, t_end - now)));
+      if (now_s() >= t_end) break;
+    }
+    if (n_per) {
+      Win w = get_win();
+      HIPCHECK(hipEventRecord(w.e0, s));
+      for (int i = 0; i < n_per; ++i) launch();
+      HIPCHECK(hipEventRecord(w.e1, s));
+      pending.push_back(w);
+      if (full) retire(pending.size() >= 4);
+      else { HIPCHECK(hipEventSynchronize(w.e1)); retire(false); }
+    } else {
+      std::this_thread::sleep_for(std::chrono::duration<double>(period_s));
+    }
+    ++k;
+    const double now = now_s();
+    if (now >= next_report) {
+      next_report += 1.0;
+      const double wall = now - t_start;
+      printf("{\"t\":%.3f,\"kernels\":%ld,\"duty\":%.2f", wall, kernels, std::min(100.0, busy_s / wall * 100.0));
+      if (flops) printf(",\"tflops\":%.2f", flops * kernels / std::max(busy_s, 1e-9) / 1e12);
+      if (bytes) printf(",\"TBps\":%.3f", bytes * kernels / std::max(busy_s, 1e-9) / 1e12);
+      printf("}\n");
+      fflush(stdout);
+    }
+  }
+  while (!pending.empty()) retire(true);
+  const double wall = now_s() - t_start;
+  printf("{\"kind\":\"%s\",\"size\":%d,\"duty_target\":%.2f,\"period_ms\":%.2f,\"kernel_ms\":%.4f,\"kernels\":%ld,"
+         "\"wall_s\":%.3f,\"duty_achieved\":%.3f",
+         a.kind.c_str(), a.size, a.duty, a.period_ms, kernel_s * 1e3, kernels, wall, std::min(100.0, busy_s / wall * 100.0));
+  if (flops) printf(",\"tflops_busy\":%.2f,\"tflops_avg\":%.2f", flops * kernels / std::max(busy_s, 1e-9) / 1e12, flops * kernels / wall / 1e12);
+  if (bytes) printf(",\"TBps_busy\":%.3f,\"TBps_avg\":%.3f", bytes * kernels / std::max(busy_s, 1e-9) / 1e12, bytes * kernels / wall / 1e12);
+  printf("}\n");
+  fflush(stdout);
+  for (void* p : hold) (void)hipFree(p);
+  for (void* p : {A, B, C, X, Y, sink}) if (p) (void)hipFree(p);
+  return 0;
+}

@@ -83,8 +83,13 @@ def hbm_fidelity(torch, dev, src, smi_idx: int, steps_gib=(16, 64, 128), settle_
                          "error_vs_driver_pct": abs(smi_delta - drv_delta) / drv_delta * 100.0 if drv_delta else None,
                          "dashboard_hbm_percent": s.get("hbmPercent")})
         ok = hold.verify()
+    # the driver hands freed VRAM back asynchronously: time how long the reading takes to drop
+    t_rel = time.perf_counter()
     after = _gpu_sample(src, smi_idx)
-    return {"rows": rows, "pattern_intact": ok,
+    while after and after["memoryUsed"] - base["memoryUsed"] > 1024 and time.perf_counter() - t_rel < 10.0:
+        time.sleep(0.1)
+        after = _gpu_sample(src, smi_idx)
+    return {"rows": rows, "pattern_intact": ok, "release_visible_after_s": round(time.perf_counter() - t_rel, 3),
             "max_error_vs_allocated_pct": max((r["error_vs_allocated_pct"] or 0.0) for r in rows) if rows else None,
             "max_error_vs_driver_pct": max((r["error_vs_driver_pct"] or 0.0) for r in rows) if rows else None,
             "released_back_to_MiB": after["memoryUsed"] if after else None, "baseline_MiB": base["memoryUsed"],
@@ -104,9 +109,6 @@ def activity_fidelity(torch, dev, src, smi_idx: int, duties=(25.0, 50.0, 75.0, 1
         time.sleep(min(1.0, seconds / 4))                 # let the load and the firmware average settle
         src.sample()
         t0 = time.perf_counter()
-        st0 = dict(b._stats)
-        gauges: List[float] = []
-        powers: List[float] = []
         while time.perf_counter() - t0 < seconds:
             time.sleep(0.5)
         s = _gpu_sample(src, smi_idx)

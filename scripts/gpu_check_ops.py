@@ -1,5 +1,6 @@
 """GPU check of the klm ops: numerics vs torch fp32 and a quick throughput readout."""
-import json, sys, time
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from k8s_llm_monitor_amd import ops
 

@@ -5,9 +5,11 @@ set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 step() { echo "=== $1 ($(date +%T))"; }
+if [ -z "$SKIP_TESTS" ]; then
 step tests && timeout -k 10 420 python -u -m pytest tests -m gpu -x -v --timeout 120 --timeout-method thread > gpurun_out/pytest_gpu.log 2>&1; rc=$?
 tail -40 gpurun_out/pytest_gpu.log
 [ $rc -ne 0 ] && { echo "pytest rc=$rc"; exit $rc; }
+fi
 step check_ops && timeout -k 10 180 python -u scripts/gpu_check_ops.py > gpurun_out/check_ops.log 2>&1; rc=$?
 tail -25 gpurun_out/check_ops.log
 [ $rc -ne 0 ] && { echo "check_ops rc=$rc"; exit $rc; }

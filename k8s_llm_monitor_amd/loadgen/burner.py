@@ -94,7 +94,7 @@ class Burner:
         elif k == "hbm_fill":
             ops.hbm_fill(self.x, 0x5A5A5A5A)
         else:
-            ops.spin(2_000_000, 1024, self.dev)      # ~1 ms of s_memtime ticks at 100 MHz... calibrated anyway
+            ops.spin(2_400_000, 1024, self.dev)      # ~1 ms (s_memtime ticks ~2.4 GHz here); calibrated anyway
 
     def calibrate(self, iters: int = 10) -> float:
         torch = self.torch
@@ -117,20 +117,25 @@ class Burner:
     def run(self, seconds: float, on_period: Optional[Callable[[Dict[str, Any]], None]] = None) -> Dict[str, Any]:
         """Run the duty-cycled load for `seconds` on this thread and return its stats."""
         torch = self.torch
-        n_per = plan_window(self.duty, self.period_s, self.kernel_s)
         full = self.duty >= 100.0
         t_start = time.perf_counter()
         t_end = t_start + seconds
         st = self._zero()
         pending: List[Any] = []
+        # closed loop: the per-kernel time moves with clocks and temperature (a cold calibration
+        # reads ~15 % slow), so every retired window updates the estimate the next window is sized by
+        est = {"k": self.kernel_s}
 
         def retire(block_on_oldest: bool) -> None:
             if block_on_oldest and pending:
                 pending[0][1].synchronize()
             while pending and pending[0][1].query():
-                e0, e1 = pending.pop(0)
-                st["busy_s"] += e0.elapsed_time(e1) / 1e3
-                st["kernels"] += n_per
+                e0, e1, n = pending.pop(0)
+                busy = e0.elapsed_time(e1) / 1e3
+                st["busy_s"] += busy
+                st["kernels"] += n
+                if n:
+                    est["k"] = 0.7 * est["k"] + 0.3 * busy / n
 
         with torch.cuda.stream(self.stream):
             k = 0
@@ -143,13 +148,14 @@ class Burner:
                         time.sleep(min(p0 - now, max(0.0, t_end - now)))
                         if time.perf_counter() >= t_end:
                             break
+                n_per = plan_window(self.duty, self.period_s, est["k"])
                 if n_per:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
                     for _ in range(n_per):
                         self.launch()
                     e1.record(self.stream)
-                    pending.append((e0, e1))
+                    pending.append((e0, e1, n_per))
                     if full:
                         retire(block_on_oldest=len(pending) >= 4)    # keep the queue fed, never drained
                     else:
@@ -163,6 +169,7 @@ class Burner:
                     on_period(st)
             while pending:
                 retire(block_on_oldest=True)
+        self.kernel_s = est["k"]
         st["wall_s"] = time.perf_counter() - t_start
         with self._lock:
             self._stats = st

@@ -175,14 +175,16 @@ int main(int argc, char** argv) {
   const double kernel_s = cal_ms * 1e-3 / 10;
   const double period_s = a.period_ms * 1e-3;
   const bool full = a.duty >= 100.0;
-  const int n_per = a.duty <= 0 ? 0 : std::max(1, (int)std::lround(std::min(1.0, a.duty / 100.0) * period_s / kernel_s));
+  // closed loop: every retired window updates the per-kernel estimate the next one is sized by
+  double k_est = kernel_s;
+  auto plan = [&]() { return a.duty <= 0 ? 0 : std::max(1, (int)std::lround(std::min(1.0, a.duty / 100.0) * period_s / k_est)); };
 
-  struct Win { hipEvent_t e0, e1; };
+  struct Win { hipEvent_t e0, e1; int n; };
   std::deque<Win> pending;
   std::vector<Win> pool;
   auto get_win = [&]() {
     if (!pool.empty()) { Win w = pool.back(); pool.pop_back(); return w; }
-    Win w;
+    Win w{};
     HIPCHECK(hipEventCreate(&w.e0));
     HIPCHECK(hipEventCreate(&w.e1));
     return w;
@@ -195,7 +197,8 @@ int main(int argc, char** argv) {
       float ms = 0;
       HIPCHECK(hipEventElapsedTime(&ms, pending.front().e0, pending.front().e1));
       busy_s += ms * 1e-3;
-      kernels += n_per;
+      kernels += pending.front().n;
+      if (pending.front().n) k_est = 0.7 * k_est + 0.3 * ms * 1e-3 / pending.front().n;
       pool.push_back(pending.front());
       pending.pop_front();
     }
@@ -211,8 +214,10 @@ int main(int argc, char** argv) {
       if (p0 > now) std::this_thread::sleep_for(std::chrono::duration<double>(std::min(p0 - now, t_end - now)));
       if (now_s() >= t_end) break;
     }
+    const int n_per = plan();
     if (n_per) {
       Win w = get_win();
+      w.n = n_per;
       HIPCHECK(hipEventRecord(w.e0, s));
       for (int i = 0; i < n_per; ++i) launch();
       HIPCHECK(hipEventRecord(w.e1, s));

@@ -58,6 +58,11 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         lib.klm_hbm_fill.restype = i
         lib.klm_hbm_copy.argtypes = [vp, vp, sz, vp]
         lib.klm_hbm_copy.restype = i
+        if hasattr(lib, "klm_hbm_copy_ex"):
+            lib.klm_hbm_copy_ex.argtypes = [vp, vp, sz, i, i, vp]
+            lib.klm_hbm_copy_ex.restype = i
+            lib.klm_hbm_fill_ex.argtypes = [vp, sz, u32, i, i, vp]
+            lib.klm_hbm_fill_ex.restype = i
         lib.klm_hbm_read.argtypes = [vp, sz, vp, vp]
         lib.klm_hbm_read.restype = i
         lib.klm_hbm_checksum.argtypes = [vp, sz, vp, vp]
@@ -154,6 +159,21 @@ def hbm_copy(dst, src):
         raise KlmOpsError("hbm_copy: size mismatch")
     _check(load().klm_hbm_copy(dst.data_ptr(), src.data_ptr(), _nbytes(src), _stream(src)), "klm_hbm_copy")
     return dst
+
+
+def hbm_copy_ex(dst, src, flags: int = 3, grid: int = 0):
+    """Tuning variant of hbm_copy (see klm_ops.h)."""
+    _require_cuda(dst, src)
+    if _nbytes(dst) != _nbytes(src):
+        raise KlmOpsError("hbm_copy_ex: size mismatch")
+    _check(load().klm_hbm_copy_ex(dst.data_ptr(), src.data_ptr(), _nbytes(src), flags, grid, _stream(src)), "klm_hbm_copy_ex")
+    return dst
+
+
+def hbm_fill_ex(t, pattern: int = 0xA5A5A5A5, flags: int = 2, grid: int = 0):
+    _require_cuda(t)
+    _check(load().klm_hbm_fill_ex(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, flags, grid, _stream(t)), "klm_hbm_fill_ex")
+    return t
 
 
 def hbm_read(src, sink):

@@ -13,9 +13,13 @@
 // unit scales, 2x the bf16 rate) consumes the whole row per 16x16 tile:
 //   bf16: 16 x mfma_16x16x32 per phase per wave;  fp8: 8 x mfma_scale_16x16x128.
 //
-// Operand k-mapping: lane l supplies 32 consecutive bytes k = 32*(l>>4) .. +31 of row
-// l&15 for A and for B alike. The hardware multiplies A's (lane group, byte j) with B's
-// (lane group, byte j), so the result does not depend on how it orders k inside a lane.
+// Operand k-mapping: lane l (row l&15, lane group g = l>>4) supplies the two 16-byte chunks
+// g and g+4 of the 128-byte row, for A and for B alike. The hardware multiplies A's
+// (lane group, byte j) with B's (lane group, byte j), so any assignment of k to (group, byte)
+// gives the same sum as long as both operands use it. This one makes the LDS read pattern
+// identical to the bf16 kernel's (chunk index = 4*h + g), which rocprofv3 shows free of bank
+// conflicts; "32 consecutive bytes per lane" (chunks 2g, 2g+1) measured 0.64 conflict
+// cycles per active instruction (profiles/r1_prof/pmc_summary.json).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -97,10 +101,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const uint8_t* __restrict__ 
            lw + (stage) * 65536 + ((h) ? KLM_SLOT_B1 : KLM_SLOT_B0) + 1024);                   \
   } while (0)
 
-  // fragment reads: row = base + t*16 + (lane&15); logical 16-byte chunks 2*fq and 2*fq+1
+  // fragment reads: row = base + t*16 + (lane&15); 16-byte chunks fq and fq+4 (swizzled)
   const int fr = lane & 15, fq = lane >> 4;
   const int key = lane & 7;
-  const int c0 = ((2 * fq) ^ key) << 4, c1 = ((2 * fq + 1) ^ key) << 4;
+  const int c0 = (fq ^ key) << 4, c1 = c0 ^ 64;
   const int a_row = (wr * 64 + fr) * 128, b_row = (wc * 32 + fr) * 128;
 
   f32x4 acc[2][2][4][2];

@@ -93,6 +93,96 @@ __global__ __launch_bounds__(64) void spin_kernel(unsigned long long cycles) {
   while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
 }
 
+// Tuning variants of the copy / fill streams (scripts/hbm_sweep.py picks the defaults):
+// flags bit 0: nontemporal loads, bit 1: nontemporal stores, bit 2: each block walks one
+// contiguous chunk instead of the grid-strided interleave. `grid` = blocks (0 = default).
+template <bool NTL, bool NTS, bool CHUNK>
+__global__ __launch_bounds__(kBlock) void hbm_copy_ex_kernel(u32x4* __restrict__ dst,
+                                                             const u32x4* __restrict__ src, size_t n16) {
+  size_t i, end, stride;
+  if (CHUNK) {
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    i = (size_t)blockIdx.x * per + threadIdx.x;
+    end = (size_t)(blockIdx.x + 1) * per < n16 ? (size_t)(blockIdx.x + 1) * per : n16;
+    stride = kBlock;
+  } else {
+    i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    end = n16;
+    stride = (size_t)gridDim.x * kBlock;
+  }
+  for (; i + (kUnroll - 1) * stride < end; i += kUnroll * stride) {
+    u32x4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) v[u] = NTL ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      if (NTS) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+      else dst[i + u * stride] = v[u];
+    }
+  }
+  for (; i < end; i += stride) dst[i] = src[i];
+}
+
+template <bool NTS, bool CHUNK>
+__global__ __launch_bounds__(kBlock) void hbm_fill_ex_kernel(u32x4* __restrict__ dst, size_t n16, uint32_t pattern) {
+  const u32x4 v = {pattern, pattern, pattern, pattern};
+  size_t i, end, stride;
+  if (CHUNK) {
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    i = (size_t)blockIdx.x * per + threadIdx.x;
+    end = (size_t)(blockIdx.x + 1) * per < n16 ? (size_t)(blockIdx.x + 1) * per : n16;
+    stride = kBlock;
+  } else {
+    i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    end = n16;
+    stride = (size_t)gridDim.x * kBlock;
+  }
+  for (; i + (kUnroll - 1) * stride < end; i += kUnroll * stride) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      if (NTS) __builtin_nontemporal_store(v, dst + i + u * stride);
+      else dst[i + u * stride] = v;
+    }
+  }
+  for (; i < end; i += stride) dst[i] = v;
+}
+
+// One-shot form: no loop, one 16 KiB tile (kBlock x kUnroll x 16 B) per block, grid = tiles.
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(kBlock) void hbm_copy_tile_kernel(u32x4* __restrict__ dst,
+                                                               const u32x4* __restrict__ src, size_t n16) {
+  const size_t base = (size_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x;
+  if (base + (kUnroll - 1) * kBlock < n16) {
+    u32x4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) v[u] = NTL ? __builtin_nontemporal_load(src + base + u * kBlock) : src[base + u * kBlock];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      if (NTS) __builtin_nontemporal_store(v[u], dst + base + u * kBlock);
+      else dst[base + u * kBlock] = v[u];
+    }
+  } else {
+    for (size_t i = base; i < n16; i += kBlock) dst[i] = src[i];
+  }
+}
+
+template <bool NTS>
+__global__ __launch_bounds__(kBlock) void hbm_fill_tile_kernel(u32x4* __restrict__ dst, size_t n16, uint32_t pattern) {
+  const u32x4 v = {pattern, pattern, pattern, pattern};
+  const size_t base = (size_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x;
+  if (base + (kUnroll - 1) * kBlock < n16) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      if (NTS) __builtin_nontemporal_store(v, dst + base + u * kBlock);
+      else dst[base + u * kBlock] = v;
+    }
+  } else {
+    for (size_t i = base; i < n16; i += kBlock) dst[i] = v;
+  }
+}
+
+static inline size_t tiles_for(size_t n16) { return (n16 + kBlock * kUnroll - 1) / (kBlock * kUnroll); }
+
 static inline int check(const void* a, const void* b, size_t bytes) {
   if (!a) return KLM_ERR_ARG;
   if (((uintptr_t)a | (uintptr_t)b) & 15) return KLM_ERR_ALIGN;
@@ -116,6 +206,62 @@ extern "C" int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stre
   const size_t n16 = bytes >> 4;
   hipLaunchKernelGGL(hbm_copy_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
                      (u32x4*)dst, (const u32x4*)src, n16);
+  return done();
+}
+
+extern "C" int klm_hbm_copy_ex(void* dst, const void* src, size_t bytes, int flags, int grid, void* stream) {
+  if (!src) return KLM_ERR_ARG;
+  if (int e = check(dst, src, bytes)) return e;
+  if (grid < 0 || grid > 1 << 20 || flags < 0 || flags > 15) return KLM_ERR_ARG;
+  const size_t n16 = bytes >> 4;
+  const dim3 g(grid ? grid : grid_for(n16)), b(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  u32x4* d = (u32x4*)dst;
+  const u32x4* r = (const u32x4*)src;
+  if (flags & 8) {
+    const size_t tiles = tiles_for(n16);
+    if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+    const dim3 gt((unsigned)tiles);
+    switch (flags & 3) {
+      case 0: hipLaunchKernelGGL((hbm_copy_tile_kernel<false, false>), gt, b, 0, s, d, r, n16); break;
+      case 1: hipLaunchKernelGGL((hbm_copy_tile_kernel<true, false>), gt, b, 0, s, d, r, n16); break;
+      case 2: hipLaunchKernelGGL((hbm_copy_tile_kernel<false, true>), gt, b, 0, s, d, r, n16); break;
+      default: hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true>), gt, b, 0, s, d, r, n16); break;
+    }
+    return done();
+  }
+  switch (flags) {
+    case 0: hipLaunchKernelGGL((hbm_copy_ex_kernel<false, false, false>), g, b, 0, s, d, r, n16); break;
+    case 1: hipLaunchKernelGGL((hbm_copy_ex_kernel<true, false, false>), g, b, 0, s, d, r, n16); break;
+    case 2: hipLaunchKernelGGL((hbm_copy_ex_kernel<false, true, false>), g, b, 0, s, d, r, n16); break;
+    case 3: hipLaunchKernelGGL((hbm_copy_ex_kernel<true, true, false>), g, b, 0, s, d, r, n16); break;
+    case 4: hipLaunchKernelGGL((hbm_copy_ex_kernel<false, false, true>), g, b, 0, s, d, r, n16); break;
+    case 5: hipLaunchKernelGGL((hbm_copy_ex_kernel<true, false, true>), g, b, 0, s, d, r, n16); break;
+    case 6: hipLaunchKernelGGL((hbm_copy_ex_kernel<false, true, true>), g, b, 0, s, d, r, n16); break;
+    default: hipLaunchKernelGGL((hbm_copy_ex_kernel<true, true, true>), g, b, 0, s, d, r, n16); break;
+  }
+  return done();
+}
+
+extern "C" int klm_hbm_fill_ex(void* dst, size_t bytes, uint32_t pattern, int flags, int grid, void* stream) {
+  if (int e = check(dst, nullptr, bytes)) return e;
+  if (grid < 0 || grid > 1 << 20 || flags < 0 || flags > 15) return KLM_ERR_ARG;
+  const size_t n16 = bytes >> 4;
+  const dim3 g(grid ? grid : grid_for(n16)), b(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  u32x4* d = (u32x4*)dst;
+  if (flags & 8) {
+    const size_t tiles = tiles_for(n16);
+    if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+    if (flags & 2) hipLaunchKernelGGL((hbm_fill_tile_kernel<true>), dim3((unsigned)tiles), b, 0, s, d, n16, pattern);
+    else hipLaunchKernelGGL((hbm_fill_tile_kernel<false>), dim3((unsigned)tiles), b, 0, s, d, n16, pattern);
+    return done();
+  }
+  const bool nts = flags & 2, chunk = flags & 4;
+  if (!nts && !chunk) hipLaunchKernelGGL((hbm_fill_ex_kernel<false, false>), g, b, 0, s, d, n16, pattern);
+  else if (nts && !chunk) hipLaunchKernelGGL((hbm_fill_ex_kernel<true, false>), g, b, 0, s, d, n16, pattern);
+  else if (!nts && chunk) hipLaunchKernelGGL((hbm_fill_ex_kernel<false, true>), g, b, 0, s, d, n16, pattern);
+  else hipLaunchKernelGGL((hbm_fill_ex_kernel<true, true>), g, b, 0, s, d, n16, pattern);
   return done();
 }
 

@@ -43,6 +43,10 @@ int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int
 int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream);   // write-only
 int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stream);    // read+write
 int klm_hbm_read(const void* src, size_t bytes, void* sink8, void* stream);  // read-only
+// Tuning variants. flags: bit 0 nontemporal loads, bit 1 nontemporal stores, bit 2 one
+// contiguous chunk per block; grid = number of 256-thread blocks (0 = the default cap).
+int klm_hbm_copy_ex(void* dst, const void* src, size_t bytes, int flags, int grid, void* stream);
+int klm_hbm_fill_ex(void* dst, size_t bytes, uint32_t pattern, int flags, int grid, void* stream);
 // Sums 32-bit words of [src, src+bytes) into *sum64 (device memory, must be zeroed by the
 // caller on the same stream). Used to check that a filled region holds its pattern.
 int klm_hbm_checksum(const void* src, size_t bytes, void* sum64, void* stream);

@@ -152,19 +152,32 @@ def read_counters(path: str) -> Dict[str, Dict[str, float]]:
     return out
 
 
-def derive(c: Dict[str, float], n_cu: int = 256, simd_per_cu: int = 4) -> Dict[str, Optional[float]]:
-    """MfmaUtil-style figures from raw counters of one kernel."""
+def derive(c: Dict[str, float], n_cu: int = 256, simd_per_cu: int = 4, n_xcd: int = 8,
+           read_req_bytes: float = 128.0) -> Dict[str, Optional[float]]:
+    """MfmaUtil-style figures from the raw counters of one kernel (sums over its dispatches;
+    byte and FLOP totals are returned per dispatch).
+
+    Calibrated on MI355X against known work (profiles/r1_prof/pmc_summary.json):
+      * SQ_INSTS_VALU_MFMA_MOPS_* x 512 is exactly 2*M*N*K for both the bf16 and the MX-fp8 kernel;
+      * GRBM_GUI_ACTIVE / GRBM_COUNT are summed over the 8 XCDs (8 x clock x time), while
+        SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, so the MFMA-busy share of SIMD
+        time is busy / (gui / n_xcd * n_cu * simd_per_cu);
+      * a wide (16 B per lane) streaming read shows one TCC_EA0_RDREQ per 128 bytes; writes show
+        one 64-byte WRREQ per 64 bytes (a 2 GiB copy reads 16.78 M and writes 33.56 M requests).
+    """
     g = c.get
+    n = g("dispatches") or 1.0
     out: Dict[str, Optional[float]] = {}
     gui = g("GRBM_GUI_ACTIVE")
     if g("GRBM_COUNT"):
         out["gpu_busy_share"] = gui / g("GRBM_COUNT") if gui is not None else None
+    if gui:
+        out["gfx_cycles_per_dispatch"] = gui / n_xcd / n
     if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None and gui:
-        # busy cycles are summed over SIMDs (and reported per 4 cycles on gfx9): share of all SIMD time
-        out["mfma_busy_share"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (gui * n_cu * simd_per_cu)
+        out["mfma_busy_share"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (gui / n_xcd * n_cu * simd_per_cu)
     mops = (g("SQ_INSTS_VALU_MFMA_MOPS_BF16") or 0.0) + (g("SQ_INSTS_VALU_MFMA_MOPS_F8") or 0.0)
     if mops:
-        out["mfma_flop"] = mops * MOPS_FLOP
+        out["mfma_flop"] = mops * MOPS_FLOP / n
     if g("SQ_WAVE_CYCLES"):
         for k, name in (("SQ_WAIT_ANY", "wait_share"), ("SQ_WAIT_INST_ANY", "issue_stall_share"), ("SQ_ACTIVE_INST_ANY", "active_share")):
             if g(k) is not None:
@@ -174,9 +187,9 @@ def derive(c: Dict[str, float], n_cu: int = 256, simd_per_cu: int = 4) -> Dict[s
     rd, rd32 = g("TCC_EA0_RDREQ_sum"), g("TCC_EA0_RDREQ_32B_sum")
     wr, wr64 = g("TCC_EA0_WRREQ_sum"), g("TCC_EA0_WRREQ_64B_sum")
     if rd is not None:
-        out["hbm_read_bytes"] = (rd - (rd32 or 0.0)) * 64.0 + (rd32 or 0.0) * 32.0
+        out["hbm_read_bytes"] = ((rd - (rd32 or 0.0)) * read_req_bytes + (rd32 or 0.0) * 32.0) / n
     if wr is not None:
-        out["hbm_write_bytes"] = (wr64 or 0.0) * 64.0 + (wr - (wr64 or 0.0)) * 32.0
+        out["hbm_write_bytes"] = ((wr64 or 0.0) * 64.0 + (wr - (wr64 or 0.0)) * 32.0) / n
     return out
 
 

@@ -2,9 +2,13 @@
 // stream, checksum and a traffic-free spin. SURVEY.md 2.4 N3 (HBM fill / exhaustion
 // injector) and N4 (HBM bandwidth burner); no reference counterpart.
 //
-// All of them are grid-stride loops over 16-byte words with the grid capped at
-// 256 CUs x 8 blocks, 256 threads per block (4 waves of 64), 4 independent 16-byte
-// accesses in flight per lane per iteration.
+// 256 threads per block (4 waves of 64), 4 independent 16-byte accesses in flight per lane.
+// Block -> data mapping and cache hints were picked by a sweep on MI355X
+// (scripts/hbm_sweep.py, profiles/r1_prof/hbm_sweep_*.log):
+//   fill  plain stores, one contiguous chunk per block, 16384 blocks     6.1 TB/s
+//   copy  one 16 KiB tile per block, nontemporal loads and stores        5.7 TB/s (read+write)
+//   read  grid-stride, nontemporal loads, 2048 blocks                    6.1 TB/s
+// (the first version, a 2048-block grid-stride loop with nontemporal stores, wrote 4.6-4.7).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,32 +26,6 @@ static inline int grid_for(size_t n16) {
   if (g < 1) g = 1;
   if (g > (size_t)kMaxGrid) g = kMaxGrid;
   return (int)g;
-}
-
-__global__ __launch_bounds__(kBlock) void hbm_fill_kernel(u32x4* __restrict__ dst, size_t n16,
-                                                          uint32_t pattern) {
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  const u32x4 v = {pattern, pattern, pattern, pattern};
-  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  for (; i + (kUnroll - 1) * stride < n16; i += kUnroll * stride) {
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) __builtin_nontemporal_store(v, dst + i + u * stride);
-  }
-  for (; i < n16; i += stride) __builtin_nontemporal_store(v, dst + i);
-}
-
-__global__ __launch_bounds__(kBlock) void hbm_copy_kernel(u32x4* __restrict__ dst,
-                                                          const u32x4* __restrict__ src, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  for (; i + (kUnroll - 1) * stride < n16; i += kUnroll * stride) {
-    u32x4 v[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
-  }
-  for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 // Read-only stream. The XOR of everything read is written once per block only when it
@@ -192,10 +170,19 @@ static inline int check(const void* a, const void* b, size_t bytes) {
 
 static inline int done() { return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP; }
 
+static inline int chunk_grid(size_t n16) {
+  // one contiguous chunk per block; 16384 blocks measured best (profiles/r1_prof/hbm_sweep_2.log)
+  const size_t per_block = (size_t)kBlock * kUnroll;
+  size_t g = (n16 + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > 16384) g = 16384;
+  return (int)g;
+}
+
 extern "C" int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream) {
   if (int e = check(dst, nullptr, bytes)) return e;
   const size_t n16 = bytes >> 4;
-  hipLaunchKernelGGL(hbm_fill_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((hbm_fill_ex_kernel<false, true>), dim3(chunk_grid(n16)), dim3(kBlock), 0, (hipStream_t)stream,
                      (u32x4*)dst, n16, pattern);
   return done();
 }
@@ -204,7 +191,10 @@ extern "C" int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stre
   if (!src) return KLM_ERR_ARG;
   if (int e = check(dst, src, bytes)) return e;
   const size_t n16 = bytes >> 4;
-  hipLaunchKernelGGL(hbm_copy_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+  const size_t tiles = tiles_for(n16);
+  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+  // one-shot 16 KiB tiles, nontemporal loads and stores: 5.66 TB/s vs 4.74 for the strided loop
+  hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
                      (u32x4*)dst, (const u32x4*)src, n16);
   return done();
 }

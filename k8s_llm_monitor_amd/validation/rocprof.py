@@ -52,9 +52,12 @@ def check_pass(counters: Sequence[str]) -> None:
         if base in seen:
             continue
         seen.add(base)
+        if base in TCC_COST:                      # derived counters that live in the TCC block
+            used["TCC_"] = used.get("TCC_", 0) + TCC_COST[base]
+            continue
         for pre in SLOTS:
             if base.startswith(pre):
-                used[pre] = used.get(pre, 0) + (TCC_COST.get(base, 1) if pre == "TCC_" else 1)
+                used[pre] = used.get(pre, 0) + 1
     for pre, n in used.items():
         if n > SLOTS[pre]:
             raise ValueError(f"{n} {pre}* counters in one pass; the hardware holds {SLOTS[pre]}")

@@ -63,6 +63,14 @@ def main():
         ms = bench(lambda: ops.gemm_fp8(a, b, out=c))
         print(f"klm fp8 {M}^3: {ms:.3f} ms {fl/ms/1e9:.1f} TF", flush=True)
         res[f"tf_fp8_{M}"] = fl / ms / 1e9
+        try:
+            one = torch.ones((), device=dev)
+            bt8 = b.t()
+            ms = bench(lambda: torch._scaled_mm(a, bt8, scale_a=one, scale_b=one, out_dtype=torch.bfloat16))
+            print(f"torch._scaled_mm fp8 {M}^3: {ms:.3f} ms {fl/ms/1e9:.1f} TF", flush=True)
+            res[f"tf_torch_fp8_{M}"] = fl / ms / 1e9
+        except Exception as e:
+            print("torch._scaled_mm unavailable:", type(e).__name__, str(e)[:120], flush=True)
     a8 = (torch.rand(2048, 4096, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
     b8 = (torch.rand(2048, 4096, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
     c0 = ops.gemm_fp8(a8, b8).clone()

@@ -10,7 +10,7 @@ def test_pass_slot_limits():
     with pytest.raises(ValueError, match="SQ_"):
         rocprof.check_pass([f"SQ_X{i}" for i in range(9)])
     with pytest.raises(ValueError, match="TCC_"):
-        rocprof.check_pass(["TCC_FETCH_SIZE", "TCC_WRITE_SIZE"])      # 3 + 2 > 4 slots
+        rocprof.check_pass(["FETCH_SIZE", "WRITE_SIZE"])      # 3 + 2 > 4 slots
     with pytest.raises(ValueError, match="GRBM_"):
         rocprof.check_pass(["GRBM_A", "GRBM_B", "GRBM_C"])
     rocprof.check_pass(["TCC_HIT_sum", "TCC_HIT_avr", "TCC_MISS_sum"])    # _sum/_avr of one counter count once

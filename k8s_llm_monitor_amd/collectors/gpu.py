@@ -435,7 +435,7 @@ class GpuSource:
 
 
 def open_gpu_source(kind: str = "auto", cfg=None) -> GpuSource:
-    """kind: auto | amdsmi | native | fake | none. ``auto`` = amdsmi when it finds a GPU,
+    """kind: auto | amdsmi | native | exporter | fake | none. ``auto`` = amdsmi when it finds a GPU,
     else none (an empty list, like a host without nvidia-smi in the reference)."""
     kind = (kind or "auto").lower()
     if kind == "none":
@@ -449,6 +449,12 @@ def open_gpu_source(kind: str = "auto", cfg=None) -> GpuSource:
         exe = getattr(getattr(cfg, "sources", None), "native_sampler", "") if cfg is not None else ""
         period = getattr(getattr(cfg, "periods", None), "realtime", 1.0) if cfg is not None else 1.0
         return GpuSource(NativeSamplerReader(exe=exe, period=min(period, 1.0)))
+    if kind == "exporter":
+        from .exporter import ExporterGpuReader
+        ex = getattr(cfg, "exporter", None)
+        if ex is None:
+            raise ValueError("gpu source 'exporter' needs a config (exporter.url)")
+        return GpuSource(ExporterGpuReader(ex.url, ex.names(), ex.timeout))
     if kind == "amdsmi":
         return GpuSource(AmdSmiReader())
     if kind == "auto":

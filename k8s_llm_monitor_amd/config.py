@@ -25,6 +25,8 @@ class ServerConfig:
     cors_origin: str = "*"           # monitor_server.js:244
     access_log: bool = False
     static_dir: str = ""             # "" = the package's web/ directory
+    state_dir: str = ""              # checkpoint/resume of history + alert state; "" = keep nothing on disk
+    persist_period: float = 60.0     # seconds between checkpoints
 
 
 @dataclass
@@ -37,12 +39,13 @@ class PeriodsConfig:
     history_window: str = "30m"      # monitor_server.js:119 ('30m')
     alert_hold: float = 30.0         # how long an edge-triggered pod alert stays visible
     probe: float = 0.0               # RCCL probe re-run period, 0 = only on demand
+    peers: float = 5.0               # cluster view: peer poll period
 
 
 @dataclass
 class SourcesConfig:
     """Which backend feeds each collector. ``auto`` picks the real one when it works."""
-    gpu: str = "auto"                # auto | amdsmi | native | fake | none
+    gpu: str = "auto"                # auto | amdsmi | native | exporter | fake | none
     kube: str = "auto"               # auto | kubectl | api | fake | none
     history: str = "auto"            # auto | local | prometheus
     vllm: str = "auto"               # auto | prometheus | direct | fake | none
@@ -53,6 +56,7 @@ class SourcesConfig:
     kube_token_file: str = "/var/run/secrets/kubernetes.io/serviceaccount/token"
     kube_ca_file: str = "/var/run/secrets/kubernetes.io/serviceaccount/ca.crt"
     vllm_endpoints: List[str] = field(default_factory=list)   # direct /metrics URLs
+    peers: List[str] = field(default_factory=list)            # other monitors to aggregate (cluster view)
     native_sampler: str = ""         # path of klm_amdsmi_sampler, "" = in-tree build
     probe_results: str = ""          # JSON file the RCCL probe writes, "" = in-tree default
 
@@ -78,6 +82,32 @@ class PrometheusConfig:
     q_vllm_kv_cache: str = "max(vllm:gpu_cache_usage_perc) * 100"
     q_vllm_running: str = "sum(vllm:num_requests_running)"
     q_vllm_waiting: str = "sum(vllm:num_requests_waiting)"
+
+
+@dataclass
+class ExporterConfig:
+    """AMD device-metrics-exporter scraped directly (``sources.gpu = exporter``). Metric names
+    are deployment-specific configuration; "" keeps the built-in default of that field
+    (collectors/exporter.py DEFAULT_NAMES, unverified against a live exporter)."""
+    url: str = "http://localhost:5000/metrics"
+    timeout: float = 3.0
+    m_gfx_activity: str = ""
+    m_umc_activity: str = ""
+    m_vram_used_mib: str = ""
+    m_vram_total_mib: str = ""
+    m_temp_hotspot: str = ""
+    m_temp_mem: str = ""
+    m_power_w: str = ""
+    m_power_cap_w: str = ""
+    m_clk_gfx: str = ""
+    m_energy_uj: str = ""
+    m_ecc_correctable: str = ""
+    m_ecc_uncorrectable: str = ""
+    m_xgmi_rx_bytes: str = ""
+    m_xgmi_tx_bytes: str = ""
+
+    def names(self) -> Dict[str, str]:
+        return {f.name[2:]: getattr(self, f.name) for f in fields(self) if f.name.startswith("m_") and getattr(self, f.name)}
 
 
 Tiers = Tuple[float, float, float]   # minor, serious, critical; a tier < 0 is disabled
@@ -119,6 +149,7 @@ class Config:
     periods: PeriodsConfig = field(default_factory=PeriodsConfig)
     sources: SourcesConfig = field(default_factory=SourcesConfig)
     prometheus: PrometheusConfig = field(default_factory=PrometheusConfig)
+    exporter: ExporterConfig = field(default_factory=ExporterConfig)
     thresholds: ThresholdsConfig = field(default_factory=ThresholdsConfig)
     compat: CompatConfig = field(default_factory=CompatConfig)
 
@@ -201,7 +232,7 @@ def validate(cfg: Config) -> None:
             raise ConfigError(f"periods.{name} must be > 0")
     if cfg.compat.cpu_percent not in ("load", "util"):
         raise ConfigError("compat.cpu_percent must be 'load' or 'util'")
-    allowed = {"gpu": {"auto", "amdsmi", "native", "fake", "none"},
+    allowed = {"gpu": {"auto", "amdsmi", "native", "exporter", "fake", "none"},
                "kube": {"auto", "kubectl", "api", "fake", "none"},
                "history": {"auto", "local", "prometheus"},
                "vllm": {"auto", "prometheus", "direct", "fake", "none"}}

@@ -15,7 +15,7 @@ Dropped: the ``/danyichun*`` route, which joins the raw URL onto the directory o
 ``try`` block (path traversal plus a crash on a missing file, :266-270).
 
 Added (additive only): ``/api/vllm/metrics``, ``/api/xgmi``, ``/api/rccl/probe``,
-``/api/alerts/history``, ``/api/summary`` (everything the page needs in one request),
+``/api/alerts/history``, ``/api/cluster`` (this node plus its configured peers), ``/api/summary`` (everything the page needs in one request),
 ``/api/events`` (server-sent events, so an alert reaches an open page without waiting for
 its next poll), ``/api/monitor/stats``, ``/api/validation``, ``/metrics`` (Prometheus text),
 ``/healthz``. Handlers read the sampler's snapshot and never run a collector.
@@ -123,6 +123,8 @@ class MonitorServer:
         if path == "/api/rccl/probe":
             doc = rccl_probe.load_results(self.cfg.sources.probe_results)
             return 200, JSON_CT, _dumps(doc or {"curves": [], "scaling": [], "note": "no probe result yet"})
+        if path == "/api/cluster":
+            return 200, JSON_CT, _dumps(m.cluster())
         if path == "/api/validation":
             return 200, JSON_CT, _dumps(load_validation_report())
         if path == "/api/summary":

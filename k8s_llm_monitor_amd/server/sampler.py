@@ -172,6 +172,53 @@ class Monitor:
             "pods": PeriodicTask("pods", self.tick_pods, c.periods.pods),
             "vllm": PeriodicTask("vllm", self.tick_vllm, c.periods.vllm),
         }
+        from ..collectors.peers import PeerPoller
+        self.peers = PeerPoller(c.sources.peers, timeout=min(2.0, c.periods.peers))
+        if self.peers.peers:
+            self.tasks["peers"] = PeriodicTask("peers", self.peers.poll, c.periods.peers)
+        if c.periods.probe > 0:
+            self.tasks["probe"] = PeriodicTask("probe", self.run_probe, c.periods.probe)
+        self.state_dir = c.server.state_dir
+        self.restored: Dict[str, Any] = {"history": False, "alert_state": False}
+        if self.state_dir:
+            self.tasks["persist"] = PeriodicTask("persist", self.checkpoint, max(1.0, c.server.persist_period))
+            self.restore()
+
+    # ---- checkpoint / resume (the reference keeps nothing: a restart clears lastPodStates and
+    # re-fires its first-sight alerts, and history lives only in Prometheus)
+    def _state_path(self, name: str) -> str:
+        import os
+        return os.path.join(self.state_dir, name)
+
+    def checkpoint(self) -> None:
+        import json
+        import os
+        if not self.state_dir:
+            return
+        os.makedirs(self.state_dir, exist_ok=True)
+        self.store.save(self._state_path("history.json"))
+        with self._lock:
+            st = self._alert_state
+            doc = {"saved": self.clock(), "pods": st.pods, "gpu_count": st.gpu_count,
+                   "ecc_correctable": {str(k): v for k, v in st.ecc_correctable.items()}, "evaluations": st.evaluations}
+        tmp = self._state_path(f"alert_state.json.tmp.{os.getpid()}")
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump(doc, f)
+        os.replace(tmp, self._state_path("alert_state.json"))
+
+    def restore(self, max_age_s: float = 3600.0) -> None:
+        import json
+        self.restored["history"] = self.store.load(self._state_path("history.json"))
+        try:
+            with open(self._state_path("alert_state.json"), "r", encoding="utf-8") as f:
+                d = json.load(f)
+            if self.clock() - float(d.get("saved", 0.0)) <= max_age_s:       # a stale pod table would raise false edges
+                self._alert_state = AlertState(pods={str(k): dict(v) for k, v in d["pods"].items()}, gpu_count=d.get("gpu_count"),
+                                               ecc_correctable={int(k): int(v) for k, v in (d.get("ecc_correctable") or {}).items()},
+                                               evaluations=int(d.get("evaluations", 0)))
+                self.restored["alert_state"] = True
+        except (OSError, ValueError, KeyError, TypeError, AttributeError):
+            pass
 
     # ---- ticks -------------------------------------------------------------------------
     def tick_realtime(self) -> None:
@@ -225,6 +272,16 @@ class Monitor:
             except Exception:
                 pass
 
+    def run_probe(self) -> None:
+        """Re-run the native RCCL probe (``periods.probe`` > 0) so the dashboard's curve stays fresh."""
+        from ..parallel import probe
+        probe.run_sweep(path=self.cfg.sources.probe_results, max_bytes=1 << 28, iters=10, warmup=3)
+
+    def cluster(self) -> Dict[str, Any]:
+        s = self.snapshot()
+        local = {"host": s["host"], "gpus": s["gpus"], "pods": s["pods"], "vllm": s["vllm"], "alerts": self.alerts_public()}
+        return self.peers.cluster(local)
+
     # ---- lifecycle ---------------------------------------------------------------------
     def start(self) -> "Monitor":
         self.started = self.clock()
@@ -236,6 +293,11 @@ class Monitor:
     def stop(self) -> None:
         for t in self.tasks.values():
             t.stop()
+        if self.state_dir:
+            try:
+                self.checkpoint()
+            except OSError:
+                pass
         for s in (self.gpu, self.kube, self.vllm):
             try:
                 s.close()
@@ -293,4 +355,5 @@ class Monitor:
                 "errors": {"gpu": self.gpu.last_error, "kube": self.kube.last_error, "vllm": self.vllm.last_error,
                            "prometheus": self.prom.last_error},
                 "history_points": {n: len(self.store.series(n)) for n in self.store.names()[:64]},
-                "alert_evaluations": self._alert_state.evaluations}
+                "alert_evaluations": self._alert_state.evaluations,
+                "state_dir": self.state_dir or None, "restored": self.restored}

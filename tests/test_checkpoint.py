@@ -1,0 +1,78 @@
+"""Checkpoint / resume of history and alert state (the reference keeps
+nothing on disk, so a restart empties the charts' local source and re-fires first-sight alerts)."""
+import json
+import os
+
+from k8s_llm_monitor_amd.collectors.gpu import GpuSource
+from k8s_llm_monitor_amd.config import demo_config
+from k8s_llm_monitor_amd.fakes.gpu import FakeGpuReader
+from k8s_llm_monitor_amd.fakes.kube import FakeKube
+from k8s_llm_monitor_amd.server.sampler import Monitor
+
+
+def make(clock, state_dir, kube="steady"):
+    cfg = demo_config(server={"state_dir": str(state_dir)}, periods={"history_step": 5.0})
+    return Monitor(cfg, gpu=GpuSource(FakeGpuReader(2, clock=clock)), kube=FakeKube(kube, clock=clock), clock=clock)
+
+
+def test_history_and_alert_state_survive_a_restart(tmp_path, clock):
+    m1 = make(clock, tmp_path, kube="pending")
+    for _ in range(4):
+        m1.tick_all()
+        clock.advance(5)
+    assert len(m1.history()["cpu"]["data"]) == 4
+    assert [a["key"] for a in m1.alerts_public()["serious"]] == ["pod/llm/vllm-llama3-405b-tp8-0/pending"]
+    m1.stop()                                                     # writes the checkpoint
+    assert os.path.exists(tmp_path / "history.json") and os.path.exists(tmp_path / "alert_state.json")
+
+    m2 = make(clock, tmp_path, kube="steady")                     # the pending pod is now gone, the others still run
+    assert m2.restored == {"history": True, "alert_state": True}
+    assert len(m2.history()["cpu"]["data"]) == 4                  # charts keep their window
+    assert "llm/vllm-llama3-8b-7f9c6d5b8-2xkzv" in m2._alert_state.pods
+    m2.tick_all()
+    assert m2.alerts_public()["serious"] == []                    # known pods: no first-sight noise, no stale alert
+    assert m2.stats()["restored"]["history"] is True
+    m2.stop()
+
+
+def test_restored_pod_table_detects_a_restart_that_happened_while_down(tmp_path, clock):
+    m1 = make(clock, tmp_path)
+    m1.tick_all()
+    m1.stop()
+    from k8s_llm_monitor_amd.fakes.kube import base_pods
+
+    def bumped(t):
+        pods = base_pods()
+        pods[0].restarts += 2
+        return pods
+
+    m2 = make(clock, tmp_path, kube=bumped)
+    m2.tick_all()
+    assert [a["key"] for a in m2.alerts_public()["serious"]] == ["pod/kube-system/coredns-6799fbcd5-x7k2p/restart"]
+    m2.stop()
+
+
+def test_stale_or_corrupt_state_is_ignored(tmp_path, clock):
+    m1 = make(clock, tmp_path)
+    m1.tick_all()
+    m1.stop()
+    clock.advance(7200)                                            # older than an hour: pod table not trusted
+    m2 = make(clock, tmp_path)
+    assert m2.restored["alert_state"] is False and m2._alert_state.pods == {}
+    m2.stop()
+    (tmp_path / "alert_state.json").write_text("{broken")
+    (tmp_path / "history.json").write_text("[]")
+    m3 = make(clock, tmp_path)
+    assert m3.restored == {"history": False, "alert_state": False}
+    m3.tick_all()
+    m3.stop()
+    json.loads((tmp_path / "alert_state.json").read_text())       # rewritten cleanly
+
+
+def test_no_state_dir_writes_nothing(tmp_path, clock, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    cfg = demo_config()
+    m = Monitor(cfg, gpu=GpuSource(FakeGpuReader(1, clock=clock)), kube=FakeKube(clock=clock), clock=clock)
+    m.tick_all()
+    m.stop()
+    assert "persist" not in m.tasks and os.listdir(tmp_path) == []

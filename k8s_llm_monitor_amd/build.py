@@ -97,6 +97,24 @@ def _cmd(t: Target) -> List[str]:
     raise ValueError(t.kind)
 
 
+SANITIZE_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+
+
+def sanitized(t: Target, out_dir: Optional[Path] = None) -> Target:
+    """The debug preset of SURVEY.md section 5 ("build native code with -fsanitize=address,
+    undefined"): host code only. GPU sanitizers are not available on the MI355X pool, so HIP
+    targets get the flags on the host side alone (``-Xarch_host``)."""
+    d = out_dir or (PKG / "_native" / "bin-asan")
+    extra = list(t.extra)
+    if t.kind == "cxx-exe":
+        extra = SANITIZE_FLAGS + extra
+    else:
+        for f in SANITIZE_FLAGS[3:]:
+            extra = ["-Xarch_host", f] + extra
+        extra = ["-g"] + extra
+    return Target(t.name + "-asan", d / t.out.name, t.sources, t.kind, extra=extra, deps=t.deps)
+
+
 def build_target(t: Target, force: bool = False, verbose: bool = True) -> bool:
     """Build one target. Returns True when a compile ran."""
     if not force and not t.stale():
@@ -134,6 +152,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--list", action="store_true")
+    ap.add_argument("--sanitize", action="store_true", help="also build the host-sanitizer preset (bin-asan/) of the C++ executables")
     ap.add_argument("targets", nargs="*")
     a = ap.parse_args(argv)
     if a.list:
@@ -141,6 +160,11 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             print(f"{t.name:22s} {t.kind:10s} {'stale' if t.stale() else 'ok':5s} {t.out}")
         return 0
     built = build_all(force=a.force, only=a.targets or None)
+    if a.sanitize:
+        for t in targets():
+            if t.kind == "cxx-exe" and (not a.targets or t.name in a.targets):
+                if build_target(sanitized(t), force=a.force):
+                    built.append(t.name + "-asan")
     print("built:", ", ".join(built) if built else "(nothing stale)")
     return 0
 

@@ -116,6 +116,156 @@ struct Gpu {
 template <class T>
 static bool ok(T v) { return v != (T)~(T)0; }
 
+// One output line from the current per-GPU state; resets the period's gauges.
+static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, double poll_us) {
+  Json j;
+  j.s = "{";
+  j.num("t", now);
+  j.num("wall", wall_s());
+  j.u64("polls", (uint64_t)polls);
+  j.num("poll_us_mean", polls ? poll_us / polls : NAN);
+  j.key("gpus");
+  j.s += '[';
+  for (size_t i = 0; i < gpus.size(); ++i) {
+    Gpu& g = gpus[i];
+    if (i) j.s += ',';
+    Json r;
+    r.s = "{";
+    r.u64("index", i);
+    r.num("t", now);
+    r.num("wall", wall_s());
+    r.str("name", g.name.c_str());
+    r.str("uuid", g.uuid.c_str());
+    r.str("bdf", g.bdf.c_str());
+    r.num("power_cap_w", g.cap_w);
+    r.num("energy_resolution_uj", g.energy_res_uj);
+    if (g.have_vram) {
+      r.u64("vram_used_mib", g.vram.vram_used);
+      r.u64("vram_total_mib", g.vram.vram_total);
+    }
+    if (g.have_ecc) {
+      r.u64("ecc_correctable", g.ecc.correctable_count);
+      r.u64("ecc_uncorrectable", g.ecc.uncorrectable_count);
+      r.u64("ecc_deferred", g.ecc.deferred_count);
+    }
+    if (g.have_m) {
+      const amdsmi_gpu_metrics_t& m = g.m;
+      r.num("gfx_activity", g.gfx.mean());
+      r.num("umc_activity", g.umc.mean());
+      r.num("power_w", g.power.mean());
+      r.num("temp_hotspot", g.temp.mean());
+      r.num("temp_mem", g.temp_mem.mean());
+      r.num("clk_gfx", g.clk.mean());
+      r.opt("clk_mem", m.current_uclk);
+      r.opt("temp_edge", m.temperature_edge);
+      r.opt("gfx_activity_acc", m.gfx_activity_acc);
+      r.opt("mem_activity_acc", m.mem_activity_acc);
+      r.opt("accumulation_counter", m.accumulation_counter);
+      r.opt("firmware_timestamp", m.firmware_timestamp);
+      r.opt("energy_acc", m.energy_accumulator);
+      r.opt("res_prochot_acc", m.prochot_residency_acc);
+      r.opt("res_ppt_acc", m.ppt_residency_acc);
+      r.opt("res_socket_thm_acc", m.socket_thm_residency_acc);
+      r.opt("res_vr_thm_acc", m.vr_thm_residency_acc);
+      r.opt("res_hbm_thm_acc", m.hbm_thm_residency_acc);
+      r.opt("xgmi_link_width", m.xgmi_link_width);
+      r.opt("xgmi_link_speed", m.xgmi_link_speed);
+      r.opt("pcie_bandwidth_inst", m.pcie_bandwidth_inst);
+      auto arr64 = [&](const char* k, const uint64_t* a) {
+        r.key(k);
+        r.s += '[';
+        for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
+          if (l) r.s += ',';
+          r.s += ok(a[l]) ? std::to_string(a[l]) : std::string("null");
+        }
+        r.s += ']';
+      };
+      arr64("xgmi_read_kib", m.xgmi_read_data_acc);
+      arr64("xgmi_write_kib", m.xgmi_write_data_acc);
+      r.key("xgmi_link_status");
+      r.s += '[';
+      for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
+        if (l) r.s += ',';
+        r.s += ok(m.xgmi_link_status[l]) ? std::to_string(m.xgmi_link_status[l]) : std::string("null");
+      }
+      r.s += ']';
+      r.key("peak");
+      Json p;
+      p.s = "{";
+      p.num("gfx_activity", g.gfx.max());
+      p.num("umc_activity", g.umc.max());
+      p.num("power_w", g.power.max());
+      p.num("temp_hotspot", g.temp.max());
+      p.num("temp_mem", g.temp_mem.max());
+      p.s += '}';
+      r.s += p.s;
+    }
+    r.s += '}';
+    j.s += r.s;
+    g.gfx.reset();
+    g.umc.reset();
+    g.power.reset();
+    g.temp.reset();
+    g.temp_mem.reset();
+    g.clk.reset();
+  }
+  j.s += "]}";
+  return j.s;
+}
+
+// --selftest: render one line from synthetic metrics (no driver needed), including
+// unsupported-field sentinels and a 32-bit activity accumulator near its wrap. Lets the JSON
+// writer run under host sanitizers and feeds the Python reader in CPU tests.
+static int selftest() {
+  std::vector<Gpu> gpus(2);
+  for (size_t i = 0; i < gpus.size(); ++i) {
+    Gpu& g = gpus[i];
+    g.h = nullptr;
+    g.name = i ? "AMD Instinct \"MI355X\"" : "AMD Instinct MI355X";
+    g.uuid = "selftest-" + std::to_string(i);
+    g.bdf = i ? "0000:75:00.0" : "0000:72:00.0";
+    g.cap_w = 1400.0;
+    g.energy_res_uj = 15.3;
+    memset(&g.m, 0xFF, sizeof g.m);                 // every field "unsupported" ...
+    g.have_m = true;
+    g.m.gfx_activity_acc = 0xFFFFFFF0u + (uint32_t)i;   // ... then the ones MI355X reports
+    g.m.mem_activity_acc = 1000;
+    g.m.accumulation_counter = 23735538 + i;
+    g.m.firmware_timestamp = 2399753411260ull;
+    g.m.energy_accumulator = 456357518510ull;
+    g.m.current_uclk = 2000;
+    g.m.prochot_residency_acc = 0;
+    g.m.ppt_residency_acc = 36266;
+    g.m.socket_thm_residency_acc = 0;
+    g.m.vr_thm_residency_acc = 0;
+    g.m.hbm_thm_residency_acc = 0;
+    g.m.xgmi_link_width = 16;
+    g.m.xgmi_link_speed = 38;
+    g.m.pcie_bandwidth_inst = 18;
+    for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
+      const bool self = (size_t)l == i;
+      g.m.xgmi_read_data_acc[l] = self ? 0 : 43353304ull + l;
+      g.m.xgmi_write_data_acc[l] = self ? 0 : 43520298ull + l;
+      g.m.xgmi_link_status[l] = self ? 0xFFFF : 1;
+    }
+    for (double v : {10.0, 30.0}) g.gfx.add(v);
+    g.umc.add(5);
+    for (double v : {300.0, 900.0}) g.power.add(v);
+    g.temp.add(46);
+    g.temp_mem.add(34);
+    g.clk.add(2100);
+    g.vram.vram_total = 294896;
+    g.vram.vram_used = 284 + 1000 * (uint32_t)i;
+    g.have_vram = true;
+    g.ecc.correctable_count = i;
+    g.ecc.uncorrectable_count = 0;
+    g.ecc.deferred_count = 0;
+    g.have_ecc = true;
+  }
+  puts(render_line(gpus, 1234.5, 20, 6000.0).c_str());
+  return 0;
+}
+
 int main(int argc, char** argv) {
   double period = 1.0, hz = 20.0;
   bool once = false;
@@ -126,8 +276,9 @@ int main(int argc, char** argv) {
     else if (k == "--hz" && i + 1 < argc) hz = atof(argv[++i]);
     else if (k == "--lines" && i + 1 < argc) max_lines = atol(argv[++i]);
     else if (k == "--once") once = true;
+    else if (k == "--selftest") return selftest();
     else {
-      fprintf(stderr, "usage: klm_amdsmi_sampler [--period S] [--hz H] [--lines N] [--once]\n");
+      fprintf(stderr, "usage: klm_amdsmi_sampler [--period S] [--hz H] [--lines N] [--once] [--selftest]\n");
       return k == "--help" ? 0 : 1;
     }
   }
@@ -218,99 +369,8 @@ int main(int argc, char** argv) {
         if (slow % 10 == 0 || !g.have_ecc) g.have_ecc = amdsmi_get_gpu_total_ecc_count(g.h, &g.ecc) == AMDSMI_STATUS_SUCCESS;
       }
       ++slow;
-      Json j;
-      j.s = "{";
-      j.num("t", now);
-      j.num("wall", wall_s());
-      j.u64("polls", (uint64_t)polls);
-      j.num("poll_us_mean", polls ? poll_us / polls : NAN);
-      j.key("gpus");
-      j.s += '[';
-      for (size_t i = 0; i < gpus.size(); ++i) {
-        Gpu& g = gpus[i];
-        if (i) j.s += ',';
-        Json r;
-        r.s = "{";
-        r.u64("index", i);
-        r.num("t", now);
-        r.num("wall", wall_s());
-        r.str("name", g.name.c_str());
-        r.str("uuid", g.uuid.c_str());
-        r.str("bdf", g.bdf.c_str());
-        r.num("power_cap_w", g.cap_w);
-        r.num("energy_resolution_uj", g.energy_res_uj);
-        if (g.have_vram) {
-          r.u64("vram_used_mib", g.vram.vram_used);
-          r.u64("vram_total_mib", g.vram.vram_total);
-        }
-        if (g.have_ecc) {
-          r.u64("ecc_correctable", g.ecc.correctable_count);
-          r.u64("ecc_uncorrectable", g.ecc.uncorrectable_count);
-          r.u64("ecc_deferred", g.ecc.deferred_count);
-        }
-        if (g.have_m) {
-          const amdsmi_gpu_metrics_t& m = g.m;
-          r.num("gfx_activity", g.gfx.mean());
-          r.num("umc_activity", g.umc.mean());
-          r.num("power_w", g.power.mean());
-          r.num("temp_hotspot", g.temp.mean());
-          r.num("temp_mem", g.temp_mem.mean());
-          r.num("clk_gfx", g.clk.mean());
-          r.opt("clk_mem", m.current_uclk);
-          r.opt("temp_edge", m.temperature_edge);
-          r.opt("gfx_activity_acc", m.gfx_activity_acc);
-          r.opt("mem_activity_acc", m.mem_activity_acc);
-          r.opt("accumulation_counter", m.accumulation_counter);
-          r.opt("firmware_timestamp", m.firmware_timestamp);
-          r.opt("energy_acc", m.energy_accumulator);
-          r.opt("res_prochot_acc", m.prochot_residency_acc);
-          r.opt("res_ppt_acc", m.ppt_residency_acc);
-          r.opt("res_socket_thm_acc", m.socket_thm_residency_acc);
-          r.opt("res_vr_thm_acc", m.vr_thm_residency_acc);
-          r.opt("res_hbm_thm_acc", m.hbm_thm_residency_acc);
-          r.opt("xgmi_link_width", m.xgmi_link_width);
-          r.opt("xgmi_link_speed", m.xgmi_link_speed);
-          r.opt("pcie_bandwidth_inst", m.pcie_bandwidth_inst);
-          auto arr64 = [&](const char* k, const uint64_t* a) {
-            r.key(k);
-            r.s += '[';
-            for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
-              if (l) r.s += ',';
-              r.s += ok(a[l]) ? std::to_string(a[l]) : std::string("null");
-            }
-            r.s += ']';
-          };
-          arr64("xgmi_read_kib", m.xgmi_read_data_acc);
-          arr64("xgmi_write_kib", m.xgmi_write_data_acc);
-          r.key("xgmi_link_status");
-          r.s += '[';
-          for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
-            if (l) r.s += ',';
-            r.s += ok(m.xgmi_link_status[l]) ? std::to_string(m.xgmi_link_status[l]) : std::string("null");
-          }
-          r.s += ']';
-          r.key("peak");
-          Json p;
-          p.s = "{";
-          p.num("gfx_activity", g.gfx.max());
-          p.num("umc_activity", g.umc.max());
-          p.num("power_w", g.power.max());
-          p.num("temp_hotspot", g.temp.max());
-          p.num("temp_mem", g.temp_mem.max());
-          p.s += '}';
-          r.s += p.s;
-        }
-        r.s += '}';
-        j.s += r.s;
-        g.gfx.reset();
-        g.umc.reset();
-        g.power.reset();
-        g.temp.reset();
-        g.temp_mem.reset();
-        g.clk.reset();
-      }
-      j.s += "]}";
-      puts(j.s.c_str());
+      const std::string line = render_line(gpus, now, polls, poll_us);
+      puts(line.c_str());
       fflush(stdout);
       if (ferror(stdout)) break;
       ++lines;

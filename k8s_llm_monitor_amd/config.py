@@ -134,6 +134,16 @@ class ThresholdsConfig:
 
 
 @dataclass
+class NotifyConfig:
+    """Alert delivery beyond the poll response. The reference has no notification channel,
+    no debouncing and no alert history."""
+    webhook_url: str = ""            # POST a JSON document on every alert begin / end ("" = off)
+    webhook_timeout: float = 3.0
+    min_tier: str = "minor"          # lowest tier that is sent: minor | serious | critical
+    debounce_s: float = 0.0          # a level alert must persist this long before it is shown / sent
+
+
+@dataclass
 class CompatConfig:
     """Switches between the reference's behaviour and the fixed one."""
     cpu_percent: str = "load"        # "load": load_1min/cores*100 (:76) | "util": /proc/stat
@@ -151,6 +161,7 @@ class Config:
     prometheus: PrometheusConfig = field(default_factory=PrometheusConfig)
     exporter: ExporterConfig = field(default_factory=ExporterConfig)
     thresholds: ThresholdsConfig = field(default_factory=ThresholdsConfig)
+    notify: NotifyConfig = field(default_factory=NotifyConfig)
     compat: CompatConfig = field(default_factory=CompatConfig)
 
     def to_dict(self) -> Dict[str, Any]:
@@ -230,6 +241,10 @@ def validate(cfg: Config) -> None:
     for name in ("realtime", "pods", "vllm", "history_step"):
         if getattr(cfg.periods, name) <= 0:
             raise ConfigError(f"periods.{name} must be > 0")
+    if cfg.notify.min_tier not in ("minor", "serious", "critical"):
+        raise ConfigError("notify.min_tier must be minor, serious or critical")
+    if cfg.notify.debounce_s < 0:
+        raise ConfigError("notify.debounce_s must be >= 0")
     if cfg.compat.cpu_percent not in ("load", "util"):
         raise ConfigError("compat.cpu_percent must be 'load' or 'util'")
     allowed = {"gpu": {"auto", "amdsmi", "native", "exporter", "fake", "none"},

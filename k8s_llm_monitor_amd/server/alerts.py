@@ -354,8 +354,11 @@ class AlertBook:
     alerts for ``hold_s`` seconds; every alert gets ``since`` (epoch seconds of first sight).
     """
 
-    def __init__(self, hold_s: float = 30.0):
+    def __init__(self, hold_s: float = 30.0, debounce_s: float = 0.0):
         self.hold_s = hold_s
+        self.debounce_s = debounce_s     # level alerts younger than this are not shown yet
+        self.on_event = None             # callable(event: dict) for begin / end (notifier hook)
+        self._announced: Dict[str, str] = {}      # key -> tier it was last announced at
         self._since: Dict[str, float] = {}
         self._held: Dict[str, Tuple[float, Alert]] = {}
         self.history: List[Dict[str, Any]] = []     # bounded log of alert begin/end events
@@ -370,25 +373,43 @@ class AlertBook:
                 live.add(key)
                 if key not in self._since:
                     self._since[key] = now
-                    self._log("begin", a, now)
                 a = dict(a, since=self._since[key])
                 if a.get("edge"):
+                    if key not in self._announced:
+                        self._announced[key] = tier
+                        self._log("begin", a, now)
                     self._held[key] = (now + self.hold_s, a)
-                else:
+                elif now - self._since[key] >= self.debounce_s:
+                    if key not in self._announced:
+                        self._log("begin", a, now)
+                    elif self._announced[key] != tier:          # e.g. HBM minor -> critical
+                        self._log("change", dict(a, previous_tier=self._announced[key]), now)
+                    self._announced[key] = tier
                     out[tier].append(a)
         for key in [k for k in self._since if k not in live and k not in self._held]:
-            self._log("end", {"key": key}, now)
+            if key in self._announced:
+                self._log("end", {"key": key, "tier": self._announced.pop(key)}, now)
             del self._since[key]
         for key, (until, a) in list(self._held.items()):
             if now >= until:
                 del self._held[key]
                 if key not in live:
                     self._since.pop(key, None)
+                    self._announced.pop(key, None)
                 continue
             out[a["tier"]].append(a)
         return out
 
     def _log(self, what: str, a: Mapping[str, Any], now: float) -> None:
-        self.history.append({"t": now, "event": what, "key": a.get("key"), "tier": a.get("tier"), "title": a.get("title")})
+        ev = {"t": now, "event": what, "key": a.get("key"), "tier": a.get("tier"), "title": a.get("title"),
+              "desc": a.get("desc"), "fix": a.get("fix")}
+        if a.get("previous_tier"):
+            ev["previous_tier"] = a["previous_tier"]
+        self.history.append(ev)
+        if self.on_event is not None:
+            try:
+                self.on_event(ev)
+            except Exception:
+                pass
         if len(self.history) > self.max_history:
             del self.history[: len(self.history) - self.max_history]

@@ -164,7 +164,12 @@ class Monitor:
                                       "vllm": {"available": False}, "alerts": empty_alerts(),
                                       "t_host": 0.0, "t_gpu": 0.0, "t_pods": 0.0, "t_vllm": 0.0, "t_alerts": 0.0}
         self._alert_state = AlertState()
-        self.book = AlertBook(hold_s=c.periods.alert_hold)
+        self.book = AlertBook(hold_s=c.periods.alert_hold, debounce_s=c.notify.debounce_s)
+        self.notifier = None
+        if c.notify.webhook_url:
+            from .notify import WebhookNotifier
+            self.notifier = WebhookNotifier(c.notify.webhook_url, c.notify.webhook_timeout, c.notify.min_tier)
+            self.book.on_event = self.notifier
         self.listeners: List[Callable[[str, Any], None]] = []
         self.started = 0.0
         self.tasks: Dict[str, PeriodicTask] = {
@@ -298,6 +303,9 @@ class Monitor:
                 self.checkpoint()
             except OSError:
                 pass
+        if self.notifier is not None:
+            self.notifier.flush(1.0)
+            self.notifier.close()
         for s in (self.gpu, self.kube, self.vllm):
             try:
                 s.close()
@@ -356,4 +364,5 @@ class Monitor:
                            "prometheus": self.prom.last_error},
                 "history_points": {n: len(self.store.series(n)) for n in self.store.names()[:64]},
                 "alert_evaluations": self._alert_state.evaluations,
-                "state_dir": self.state_dir or None, "restored": self.restored}
+                "state_dir": self.state_dir or None, "restored": self.restored,
+                "webhook": self.notifier.stats() if self.notifier is not None else None}

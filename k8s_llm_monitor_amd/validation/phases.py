@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 import threading
 import time
 import urllib.request
@@ -242,7 +243,8 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
             except Exception as e:
                 out[name] = {"error": f"{type(e).__name__}: {e}"}
             out[name]["phase_seconds"] = round(time.time() - t0, 2)
-            print(f"[validate] {name}: {json.dumps(out[name])[:600]}", flush=True)
+            # progress goes to stderr: bench.py's stdout carries exactly one JSON line
+            print(f"[validate] {name}: {json.dumps(out[name])[:600]}", file=sys.stderr, flush=True)
 
         if "hbm" in want:
             guard("hbm_fidelity", lambda: hbm_fidelity(torch, dev, src, idx, steps_gib=(16, 64) if quick else (16, 64, 128, 200)))

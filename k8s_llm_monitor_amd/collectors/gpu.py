@@ -181,6 +181,7 @@ class GpuNormalizer:
                      "linkSpeedGbps": _int(raw.get("xgmi_link_speed"))},
             "pcieGBps": _num(raw.get("pcie_bandwidth_inst")),
             "processes": raw.get("processes"),
+            "processList": raw.get("process_list"),
             "peak": raw.get("peak"),
             "timestamp": raw.get("wall", time.time()),
         }
@@ -208,8 +209,9 @@ class AmdSmiReader(GpuReader):
     VRAM call and one ECC call per GPU per sample (about 0.5 ms per GPU on MI355X)."""
     kind = "amdsmi"
 
-    def __init__(self):
+    def __init__(self, processes: bool = False):
         import amdsmi  # raises ImportError / OSError when the library is absent
+        self.processes = processes
         self._smi = amdsmi
         amdsmi.amdsmi_init()
         self._handles = list(amdsmi.amdsmi_get_processor_handles())
@@ -285,10 +287,15 @@ class AmdSmiReader(GpuReader):
                                   ecc_deferred=e.get("deferred_count"))
                     except Exception:
                         pass
-                    try:
-                        sc["processes"] = len(smi.amdsmi_get_gpu_process_list(h))
-                    except Exception:
-                        pass
+                    if self.processes:       # off by default: the call is slow and noisy on stderr without /proc access
+                        try:
+                            pl = smi.amdsmi_get_gpu_process_list(h)
+                            sc["processes"] = len(pl)
+                            sc["process_list"] = [{"pid": int(p.get("pid")), "name": p.get("name"),
+                                                   "vramBytes": int((p.get("memory_usage") or {}).get("vram_mem") or p.get("mem") or 0)}
+                                                  for p in pl]
+                        except Exception:
+                            pass
                     self._slow_cache[i] = sc
                 raw.update(self._slow_cache[i])
                 out.append(raw)
@@ -455,11 +462,12 @@ def open_gpu_source(kind: str = "auto", cfg=None) -> GpuSource:
         if ex is None:
             raise ValueError("gpu source 'exporter' needs a config (exporter.url)")
         return GpuSource(ExporterGpuReader(ex.url, ex.names(), ex.timeout))
+    procs = bool(getattr(getattr(cfg, "sources", None), "gpu_processes", False)) if cfg is not None else False
     if kind == "amdsmi":
-        return GpuSource(AmdSmiReader())
+        return GpuSource(AmdSmiReader(processes=procs))
     if kind == "auto":
         try:
-            return GpuSource(AmdSmiReader())
+            return GpuSource(AmdSmiReader(processes=procs))
         except Exception:
             return GpuSource(GpuReader())
     raise ValueError(f"unknown gpu source {kind!r}")

@@ -99,6 +99,7 @@ def pod_from_item(item: Mapping[str, Any], now: Optional[float] = None) -> Dict[
         "node": spec.get("nodeName"),
         "gpus": _gpu_request(spec),
         "vllm": _looks_like_vllm(item),
+        "uid": meta.get("uid"),
     }
 
 

@@ -56,6 +56,7 @@ class SourcesConfig:
     kube_token_file: str = "/var/run/secrets/kubernetes.io/serviceaccount/token"
     kube_ca_file: str = "/var/run/secrets/kubernetes.io/serviceaccount/ca.crt"
     vllm_endpoints: List[str] = field(default_factory=list)   # direct /metrics URLs
+    gpu_processes: bool = False      # per-process VRAM and pod attribution (needs hostPID in a pod)
     peers: List[str] = field(default_factory=list)            # other monitors to aggregate (cluster view)
     native_sampler: str = ""         # path of klm_amdsmi_sampler, "" = in-tree build
     probe_results: str = ""          # JSON file the RCCL probe writes, "" = in-tree default

@@ -199,5 +199,6 @@ class FakeGpuReader:
                 "xgmi_link_status": status, "xgmi_link_width": 16, "xgmi_link_speed": 38,
                 "xgmi_peers": [None if l == i % 8 else f"0000:{0x10 + l:02x}:00.0" for l in range(8)],
                 "processes": 1,
+                "process_list": [{"pid": 40000 + i, "name": "python3 (vllm worker)", "vramBytes": int(HBM_TOTAL_MIB * s.hbm_frac) << 20}],
             })
         return out

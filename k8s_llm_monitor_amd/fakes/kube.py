@@ -34,6 +34,13 @@ def _iso(epoch: float) -> str:
     return datetime.fromtimestamp(epoch, tz=timezone.utc).strftime("%Y-%m-%dT%H:%M:%SZ")
 
 
+def fake_uid(namespace: str, name: str) -> str:
+    """A stable UUID-shaped uid per pod name."""
+    import hashlib
+    h = hashlib.md5(f"{namespace}/{name}".encode()).hexdigest()
+    return f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:32]}"
+
+
 def pod_item(p: PodSpec, now: float) -> Dict[str, Any]:
     state: Dict[str, Any]
     if p.waiting_reason:
@@ -51,7 +58,8 @@ def pod_item(p: PodSpec, now: float) -> Dict[str, Any]:
         container["resources"] = {"limits": {"amd.com/gpu": str(p.gpus)}, "requests": {"amd.com/gpu": str(p.gpus)}}
     item: Dict[str, Any] = {
         "apiVersion": "v1", "kind": "Pod",
-        "metadata": {"namespace": p.namespace, "name": p.name, "labels": {"app": p.name.rsplit("-", 2)[0]}},
+        "metadata": {"namespace": p.namespace, "name": p.name, "uid": fake_uid(p.namespace, p.name),
+                     "labels": {"app": p.name.rsplit("-", 2)[0]}},
         "spec": {"nodeName": p.node, "containers": [container]},
         "status": {"phase": p.phase},
     }

@@ -15,6 +15,7 @@ import time
 from typing import Any, Callable, Dict, List, Optional
 
 from ..collectors import history as hist
+from ..collectors import procmap
 from ..collectors.gpu import GpuSource, open_gpu_source
 from ..collectors.host import HostCollector
 from ..collectors.kube import KubeSource, open_kube_source
@@ -148,6 +149,7 @@ class Monitor:
         self.gpu = gpu or open_gpu_source(c.sources.gpu, c)
         self.kube = kube or open_kube_source(c.sources.kube, c)
         self.vllm = vllm or open_vllm_source(c.sources.vllm, c, self.prom)
+        self.pod_resolver = procmap.PodResolver()
 
         window_s = parse_duration(c.periods.history_window)
         cap = int(window_s / max(0.05, min(c.periods.realtime, c.periods.history_step))) + 8
@@ -229,6 +231,10 @@ class Monitor:
     def tick_realtime(self) -> None:
         host = self.host.collect()
         gpus = self.gpu.sample()
+        if self.cfg.sources.gpu_processes and gpus:
+            with self._lock:
+                pods = self._snap["pods"]
+            procmap.attribute(gpus, pods, self.pod_resolver)
         now = self.clock()
         with self._lock:
             self._snap["host"], self._snap["gpus"] = host, gpus

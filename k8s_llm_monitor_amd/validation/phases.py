@@ -64,9 +64,21 @@ def _smi_index_for(torch, dev, src) -> int:
 def hbm_fidelity(torch, dev, src, smi_idx: int, steps_gib=(16, 64, 128), settle_s: float = 0.3) -> Dict[str, Any]:
     from ..loadgen.burner import HbmHold
     rows = []
+    import gc
+    gc.collect()
     torch.cuda.synchronize(dev)
     torch.cuda.empty_cache()
+    # amdsmi's VRAM figure follows a free with a lag of ~2 s (the driver releases asynchronously):
+    # take the baseline only once two readings 0.5 s apart agree
     base = _gpu_sample(src, smi_idx)
+    t_wait = time.perf_counter()
+    while time.perf_counter() - t_wait < 8.0:
+        time.sleep(0.5)
+        again = _gpu_sample(src, smi_idx)
+        settled = abs(again["memoryUsed"] - base["memoryUsed"]) <= 2
+        base = again
+        if settled:
+            break
     free0, total = torch.cuda.mem_get_info(dev)
     with HbmHold(dev.index or 0) as hold:
         for gib in steps_gib:

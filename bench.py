@@ -7,9 +7,10 @@ BASELINE.json names no throughput number (the reference publishes none); its met
 and "8xMI355X: RCCL all-reduce probe over xGMI at 1/2/4/8 GPUs". One bench STEP is one
 iteration of exactly that load, on every rank, with the telemetry sampler running:
 
-    1. the hand-written bf16 MFMA GEMM burner (8192^3, C = A @ B^T) on the compute stream;
-    2. for N > 1: an RCCL all-reduce (sum, bf16) of the previous step's 128 MiB output
-       on a communication stream, overlapped with step 1 (double-buffered outputs).
+    1. the three GEMMs of one 8192x8192 linear layer's training step (fwd, dgrad, wgrad;
+       6 * 8192^3 FLOP) on the hand-written bf16 MFMA burner kernel, on the compute stream;
+    2. for N > 1: the data-parallel gradient all-reduce (RCCL, sum, bf16, 128 MiB of dW) on a
+       communication stream, overlapped with the next step's fwd and dgrad (dW double-buffered).
 
 ``value`` is the whole-job burner rate in TFLOP/s (sum over ranks, weak scaling); the
 JSON line also carries the all-reduce bus bandwidth and, from short phases outside the
@@ -34,8 +35,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=8192, help="GEMM M=N=K")
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--no-validation", action="store_true",

@@ -228,6 +228,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const uint16_t* __restrict_
   } while (0)
 #define KLM_BAR() __builtin_amdgcn_s_barrier()
 
+#ifdef KLM_EXP_NO_GLOBAL   // timing-only: the loop issues no global->LDS traffic (outputs are wrong)
+#undef KLM_ISSUE_A
+#undef KLM_ISSUE_B
+#define KLM_ISSUE_A(h, stage, k0) do { } while (0)
+#define KLM_ISSUE_B(h, stage, k0) do { } while (0)
+#endif
   const int nt = K >> 6;
 
   // ---- prologue: stage K tile 0 into stage 0 in need order A0,B0 | B1 | A1
@@ -253,14 +259,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const uint16_t* __restrict_
     KLM_MFMA16(0, 0, b0);
     KLM_BAR();
     // phase 1
+#ifndef KLM_EXP_SKIP_B1
     KLM_READ_B(b1, sb + KLM_SLOT_B1);
+#endif
     KLM_ISSUE_B(1, nxt, k1);
     KLM_VMCNT(6);
     KLM_BAR();
     KLM_MFMA16(0, 1, b1);
     KLM_BAR();
     // phase 2
+#ifndef KLM_EXP_SKIP_A1
     KLM_READ_A(sb + KLM_SLOT_A1);
+#endif
     KLM_ISSUE_A(1, nxt, k1);
     KLM_BAR();
     KLM_MFMA16(1, 1, b1);

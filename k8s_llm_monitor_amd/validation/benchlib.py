@@ -22,7 +22,21 @@ def _sync_all(torch, dist, world):
 
 
 class _Load:
-    """One rank's buffers and the step function (GEMM burner + overlapped all-reduce)."""
+    """One rank's buffers and the step function.
+
+    A step is the GEMM work of one linear layer's training step on the burner kernel, with
+    the data-parallel gradient all-reduce overlapped the way DP training overlaps it:
+
+        fwd    Y  = X  @ W^T          (compute stream)
+        dgrad  dX = dY @ (W^T)^T      (compute stream)
+        wgrad  dW = dY^T @ (X^T)^T    (compute stream)  -> all-reduce(dW) over RCCL on the
+                                                           communication stream, overlapping
+                                                           the NEXT step's fwd and dgrad
+    All operands are square `size` x `size` bf16, stored K-major as the kernel wants them
+    (the transposed copies are made once, outside the timed region). dW is double-buffered:
+    the wgrad of step i+2 waits for the all-reduce of step i. 6*size^3 FLOP and one
+    2*size^2-byte all-reduce per step.
+    """
 
     def __init__(self, torch, dist, ops, dev, world: int, size: int, gemm=None):
         self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
@@ -32,12 +46,19 @@ class _Load:
         self.gpu = dev.type == "cuda"
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + (dist.get_rank() if world > 1 else 0))
-        # uniform [-1, 1) operands: zero-filled operands read ~15-20 % high (DVFS)
-        self.a = (torch.rand(size, size, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
-        self.b = (torch.rand(size, size, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
-        self.c = [torch.empty(size, size, device=dev, dtype=torch.bfloat16) for _ in range(2)]
+
+        def rnd():
+            # uniform [-1, 1) operands: zero-filled operands read ~15-20 % high (DVFS)
+            return (torch.rand(size, size, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+
+        self.x, self.w, self.dy = rnd(), rnd(), rnd()
+        self.wt, self.dyt, self.xt = self.w.t().contiguous(), self.dy.t().contiguous(), self.x.t().contiguous()
+        self.a, self.b = self.dyt, self.xt                     # the operands of the all-reduced GEMM (tests)
+        self.y = torch.empty(size, size, device=dev, dtype=torch.bfloat16)
+        self.dx = torch.empty(size, size, device=dev, dtype=torch.bfloat16)
+        self.c = [torch.empty(size, size, device=dev, dtype=torch.bfloat16) for _ in range(2)]    # dW, double-buffered
         self.size = size
-        self.flops = 2.0 * size * size * size
+        self.flops = 3 * 2.0 * size * size * size
         self.comm = torch.cuda.Stream(device=dev) if (world > 1 and self.gpu) else None
         self.ev_gemm = [torch.cuda.Event() for _ in range(2)] if self.gpu else []
         self.ev_comm = [torch.cuda.Event() for _ in range(2)] if self.gpu else []
@@ -48,16 +69,20 @@ class _Load:
         torch = self.torch
         k = self.i & 1
         if not self.gpu:                       # CPU rehearsal: same data flow, no streams
-            self.gemm(self.a, self.b, self.c[k])
+            self.gemm(self.x, self.w, self.y)
+            self.gemm(self.dy, self.wt, self.dx)
+            self.gemm(self.dyt, self.xt, self.c[k])
             if self.world > 1:
                 self.dist.all_reduce(self.c[k])
             self.i += 1
             return
         main = torch.cuda.current_stream()
+        self.gemm(self.x, self.w, self.y)
+        self.gemm(self.dy, self.wt, self.dx)
         if self.comm is not None:
-            # buffer k was all-reduced two steps ago: the GEMM may only overwrite it after that
+            # dW buffer k was all-reduced two steps ago: wgrad may only overwrite it after that
             main.wait_event(self.ev_comm[k])
-        self.gemm(self.a, self.b, self.c[k])
+        self.gemm(self.dyt, self.xt, self.c[k])
         if self.comm is not None:
             self.ev_gemm[k].record(main)
             with torch.cuda.stream(self.comm):
@@ -122,6 +147,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         sampler = _start_sampler(period, dev.index or 0)
     extras["sampler"] = (sampler.describe() if sampler is not None else "off")
 
+    extras["flop_per_step"] = load.flops
     dt = timed_steps(torch, dist, load, world, a.steps, a.warmup)
     ms = dt / a.steps * 1e3
     tflops = load.flops * world / (dt / a.steps) / 1e12
@@ -183,7 +209,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         sampler.stop()
 
     return {
-        "metric": "monitored bf16 MFMA burner throughput (validation load under telemetry sampling)",
+        "metric": "monitored validation-load throughput: bf16 MFMA burner training step (fwd+dgrad+wgrad GEMMs, DP all-reduce over RCCL) under telemetry sampling",
         "value": round(tflops, 2),
         "unit": "TFLOP/s",
         "n_gpus": world,
@@ -196,7 +222,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         "dtype": "bf16",
         "data": "synthetic (uniform [-1,1) operands, random init)",
         "config": {
-            "model": "klm bf16 GEMM burner %d^3 (hand-written gfx950 MFMA kernel) + RCCL all-reduce of its output" % size,
+            "model": "klm bf16 GEMM burner, one %dx%d linear layer: fwd+dgrad+wgrad (hand-written gfx950 MFMA kernel) + RCCL all-reduce of dW" % (size, size),
             "global_batch": world,
             "seq_len": size,
             "parallelism": f"dp{world}" if world > 1 else "single",

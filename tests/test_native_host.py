@@ -33,7 +33,9 @@ def test_all_targets_exist_and_carry_gfx950_code(built):
         assert path.exists(), name
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if os.path.exists(objdump):
-        r = subprocess.run([objdump, "--offloading", str(built["klm_ops"])], capture_output=True, text=True)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:      # --offloading extracts the code objects into the cwd
+            r = subprocess.run([objdump, "--offloading", str(built["klm_ops"])], capture_output=True, text=True, cwd=td)
         assert "gfx950" in r.stdout + r.stderr
 
 

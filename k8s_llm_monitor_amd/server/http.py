@@ -24,10 +24,8 @@ from __future__ import annotations
 
 import json
 import os
-import queue
 import threading
 import time
-from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
 from pathlib import Path
 from typing import Any, Callable, Dict, Optional, Tuple
 
@@ -67,38 +65,85 @@ def xgmi_matrix(gpus) -> Dict[str, Any]:
     return {"gpus": rows, "totalGBps": total, "linkPeakGBps": rccl_probe.XGMI_LINK_GBPS}
 
 
+# Paths whose body depends only on the sampler's snapshot: serialised once per snapshot
+# version, then served as cached bytes (the reference re-runs its collectors per request).
+_SNAPSHOT_PATHS = {"/api/host/metrics", "/api/gpu/metrics", "/api/k8s/pods", "/api/alerts", "/api/vllm/metrics",
+                   "/api/xgmi", "/api/alerts/history", "/metrics"}
+_REASONS = {200: b"OK", 404: b"Not Found", 405: b"Method Not Allowed", 400: b"Bad Request", 500: b"Internal Server Error",
+            503: b"Service Unavailable", 431: b"Request Header Fields Too Large"}
+_BLOCKING_PATHS = {"/api/history", "/api/cluster", "/api/rccl/probe", "/api/validation"}     # may do I/O: run off the loop
+
+
 class MonitorServer:
+    """asyncio HTTP/1.1 server (keep-alive, GET / HEAD / OPTIONS) on its own thread.
+
+    One event loop serves every connection; handlers only copy cached bytes, so a request
+    costs microseconds and a slow client cannot hold a thread. The few routes that may touch
+    the network or the disk (history through Prometheus, the cluster view, result files) run in
+    the loop's executor. ``/api/events`` is a server-sent-events stream fed from the sampler."""
+
+    MAX_HEADER = 16384
+
     def __init__(self, monitor: Monitor, cfg: Optional[Config] = None):
+        import asyncio
+        import socket
         self.monitor = monitor
         self.cfg = cfg or monitor.cfg
         static = Path(self.cfg.server.static_dir) if self.cfg.server.static_dir else WEB_DIR
         self.static_dir = static
         # like the reference, the page is read once at start-up and a missing file is fatal (:241)
         self.html = (static / "monitor.html").read_bytes()
-        self._sse: "set[queue.Queue]" = set()
-        self._sse_lock = threading.Lock()
-        monitor.listeners.append(self._on_event)
-        self.httpd = ThreadingHTTPServer((self.cfg.server.host, self.cfg.server.port), self._handler_class())
-        self.httpd.daemon_threads = True
-        self.port = self.httpd.server_address[1]
-        self._th: Optional[threading.Thread] = None
+        self._cache: Dict[str, Tuple[int, Tuple[int, str, bytes]]] = {}
+        self._head_cors = ("Access-Control-Allow-Origin: %s\r\nAccess-Control-Allow-Methods: GET, OPTIONS\r\n"
+                           % self.cfg.server.cors_origin).encode("latin-1")
+        self._sse: "set" = set()
+        self._closing = False
         self.requests = 0
+        self._loop = asyncio.new_event_loop()
+        self._sock = socket.socket(socket.AF_INET6 if ":" in self.cfg.server.host else socket.AF_INET, socket.SOCK_STREAM)
+        self._sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        self._sock.bind((self.cfg.server.host, self.cfg.server.port))
+        self._sock.listen(512)
+        self._sock.setblocking(False)
+        self.port = self._sock.getsockname()[1]
+        self._server = None
+        self._th: Optional[threading.Thread] = None
+        self._ready = threading.Event()
+        monitor.listeners.append(self._on_event)
 
     # ---- server-sent events ------------------------------------------------------------
     def _on_event(self, kind: str, payload: Any) -> None:
-        if kind != "alerts":
+        if kind != "alerts" or not self._sse or self._closing:
             return
         msg = b"event: alerts\ndata: " + _dumps(self.monitor.alerts_public()) + b"\n\n"
-        with self._sse_lock:
-            for q in list(self._sse):
-                try:
-                    q.put_nowait(msg)
-                except queue.Full:
-                    pass
+        try:
+            self._loop.call_soon_threadsafe(self._broadcast, msg)
+        except RuntimeError:
+            pass
+
+    def _broadcast(self, msg: bytes) -> None:
+        for w in list(self._sse):
+            try:
+                if w.transport.get_write_buffer_size() < 1 << 20:     # a stalled client is skipped, not buffered
+                    w.write(msg)
+            except Exception:
+                self._sse.discard(w)
 
     # ---- routing -------------------------------------------------------------------------
     def route(self, path: str) -> Optional[Tuple[int, str, bytes]]:
         """(status, content type, body) for a GET, None for an unknown path."""
+        if path in _SNAPSHOT_PATHS:
+            ver = self.monitor.version
+            hit = self._cache.get(path)
+            if hit is not None and hit[0] == ver:
+                return hit[1]
+            r = self._route(path)
+            if r is not None:
+                self._cache[path] = (ver, r)
+            return r
+        return self._route(path)
+
+    def _route(self, path: str) -> Optional[Tuple[int, str, bytes]]:
         m = self.monitor
         if path in ("/", "/monitor.html"):
             return 200, "text/html; charset=utf-8", self.html
@@ -137,7 +182,7 @@ class MonitorServer:
             st["http_requests"] = self.requests
             return 200, JSON_CT, _dumps(st)
         if path == "/api/config":
-            return 200, JSON_CT, _dumps(self.cfg.to_dict())
+            return 200, JSON_CT, _dumps(redacted_config(self.cfg))
         if path == "/metrics":
             return 200, "text/plain; version=0.0.4; charset=utf-8", exporter.render(m.snapshot(), m.stats()).encode("utf-8")
         if path == "/healthz":
@@ -146,104 +191,158 @@ class MonitorServer:
             return (200 if ok else 503), JSON_CT, _dumps({"ok": ok, "last_sample_age_s": round(age, 3)})
         return None
 
-    def _handler_class(self):
-        outer = self
-        cfg = self.cfg
+    # ---- wire ----------------------------------------------------------------------------
+    def _response(self, status: int, ctype: str, body: bytes, head_only: bool, keep: bool) -> bytes:
+        h = (b"HTTP/1.1 %d %s\r\n" % (status, _REASONS.get(status, b"OK")) + self._head_cors +
+             b"Content-Type: " + ctype.encode("latin-1") + b"\r\nContent-Length: %d\r\nCache-Control: no-store\r\n" % len(body) +
+             (b"Connection: keep-alive\r\n\r\n" if keep else b"Connection: close\r\n\r\n"))
+        return h if head_only else h + body
 
-        class Handler(BaseHTTPRequestHandler):
-            protocol_version = "HTTP/1.1"
-            server_version = "klm-monitor"
-
-            def log_message(self, fmt, *args):
-                if cfg.server.access_log:
-                    BaseHTTPRequestHandler.log_message(self, fmt, *args)
-
-            def _send(self, status: int, ctype: str, body: bytes) -> None:
-                self.send_response(status)
-                self.send_header("Access-Control-Allow-Origin", cfg.server.cors_origin)
-                self.send_header("Access-Control-Allow-Methods", "GET, OPTIONS")
-                self.send_header("Content-Type", ctype)
-                self.send_header("Content-Length", str(len(body)))
-                self.send_header("Cache-Control", "no-store")
-                self.end_headers()
-                if self.command != "HEAD":
-                    self.wfile.write(body)
-
-            def do_OPTIONS(self):
-                outer.requests += 1
-                self._send(200, JSON_CT, b"")
-
-            def do_HEAD(self):
-                self.do_GET()
-
-            def do_GET(self):
-                outer.requests += 1
-                path = self.path.split("?", 1)[0]
-                if path == "/api/events":
-                    return self._events()
+    async def _handle(self, reader, writer) -> None:
+        import asyncio
+        loop = self._loop
+        try:
+            while not self._closing:
                 try:
-                    r = outer.route(path)
-                    if r is None:
-                        # the reference keeps the JSON content type on its plain-text 404 (:290)
-                        return self._send(404, JSON_CT, b"Not Found")
-                    self._send(*r)
-                except (BrokenPipeError, ConnectionResetError):
-                    pass
-                except Exception as e:
-                    self._send(500, JSON_CT, _dumps({"error": str(e)}))
+                    head = await asyncio.wait_for(reader.readuntil(b"\r\n\r\n"), timeout=30.0)
+                except asyncio.LimitOverrunError:
+                    writer.write(self._response(431, JSON_CT, b"", False, False))
+                    break
+                except (asyncio.IncompleteReadError, asyncio.TimeoutError, ConnectionError):
+                    break
+                self.requests += 1
+                line, _, rest = head.partition(b"\r\n")
+                parts = line.split()
+                if len(parts) < 2:
+                    writer.write(self._response(400, JSON_CT, _dumps({"error": "bad request line"}), False, False))
+                    break
+                method, target = parts[0].upper(), parts[1].decode("latin-1")
+                low = rest.lower()
+                keep = (len(parts) > 2 and parts[2] == b"HTTP/1.1" and b"connection: close" not in low) or b"connection: keep-alive" in low
+                clen = 0
+                i = low.find(b"content-length:")
+                if i >= 0:
+                    try:
+                        clen = int(low[i + 15: low.find(b"\r\n", i)].strip() or 0)
+                    except ValueError:
+                        clen = 0
+                if clen:                                   # a body we never use: drain it so keep-alive stays in sync
+                    if clen > 1 << 20:
+                        keep = False
+                    else:
+                        await reader.readexactly(clen)
+                path = target.split("?", 1)[0]             # the query string is ignored (monitor_server.js:250)
+                if self.cfg.server.access_log:
+                    print("[http] %s %s" % (method.decode("latin-1"), target), flush=True)
+                if method == b"OPTIONS":
+                    writer.write(self._response(200, JSON_CT, b"", False, keep))
+                elif method not in (b"GET", b"HEAD"):
+                    writer.write(self._response(405, JSON_CT, _dumps({"error": "GET and OPTIONS only"}), False, keep))
+                elif path == "/api/events" and method == b"GET":
+                    await self._events(writer)
+                    return
+                else:
+                    try:
+                        if path in _BLOCKING_PATHS:
+                            r = await loop.run_in_executor(None, self.route, path)
+                        else:
+                            r = self.route(path)
+                        if r is None:
+                            # the reference keeps the JSON content type on its plain-text 404 (:290)
+                            r = (404, JSON_CT, b"Not Found")
+                    except Exception as e:
+                        r = (500, JSON_CT, _dumps({"error": str(e)}))
+                    writer.write(self._response(r[0], r[1], r[2], method == b"HEAD", keep))
+                await writer.drain()
+                if not keep:
+                    break
+        except (ConnectionError, OSError):
+            pass
+        finally:
+            try:
+                writer.close()
+            except Exception:
+                pass
 
-            def do_POST(self):
-                outer.requests += 1
-                self._send(405, JSON_CT, _dumps({"error": "GET and OPTIONS only"}))
-
-            do_PUT = do_DELETE = do_PATCH = do_POST
-
-            def _events(self):
-                q: "queue.Queue[bytes]" = queue.Queue(maxsize=64)
-                with outer._sse_lock:
-                    outer._sse.add(q)
-                try:
-                    self.send_response(200)
-                    self.send_header("Access-Control-Allow-Origin", cfg.server.cors_origin)
-                    self.send_header("Content-Type", "text/event-stream; charset=utf-8")
-                    self.send_header("Cache-Control", "no-store")
-                    self.send_header("Connection", "close")
-                    self.end_headers()
-                    self.close_connection = True
-                    self.wfile.write(b"event: alerts\ndata: " + _dumps(outer.monitor.alerts_public()) + b"\n\n")
-                    self.wfile.flush()
-                    while not outer._closing:
-                        try:
-                            msg = q.get(timeout=10.0)
-                        except queue.Empty:
-                            msg = b": keep-alive\n\n"
-                        self.wfile.write(msg)
-                        self.wfile.flush()
-                except (BrokenPipeError, ConnectionResetError, OSError):
-                    pass
-                finally:
-                    with outer._sse_lock:
-                        outer._sse.discard(q)
-
-        return Handler
-
-    _closing = False
+    async def _events(self, writer) -> None:
+        import asyncio
+        writer.write(b"HTTP/1.1 200 OK\r\n" + self._head_cors + b"Content-Type: text/event-stream; charset=utf-8\r\n"
+                     b"Cache-Control: no-store\r\nConnection: close\r\n\r\n")
+        writer.write(b"event: alerts\ndata: " + _dumps(self.monitor.alerts_public()) + b"\n\n")
+        self._sse.add(writer)
+        try:
+            while not self._closing and not writer.is_closing():
+                await writer.drain()
+                await asyncio.sleep(10.0)
+                writer.write(b": keep-alive\n\n")
+        except (ConnectionError, OSError, asyncio.CancelledError):
+            pass
+        finally:
+            self._sse.discard(writer)
+            try:
+                writer.close()
+            except Exception:
+                pass
 
     # ---- lifecycle -------------------------------------------------------------------------
+    def _run(self) -> None:
+        import asyncio
+        asyncio.set_event_loop(self._loop)
+
+        async def boot():
+            self._server = await asyncio.start_server(self._handle, sock=self._sock, limit=self.MAX_HEADER)
+            self._ready.set()
+
+        self._loop.run_until_complete(boot())
+        try:
+            self._loop.run_forever()
+        finally:
+            try:
+                pending = [t for t in asyncio.all_tasks(self._loop) if not t.done()]
+                for t in pending:
+                    t.cancel()
+                if pending:
+                    self._loop.run_until_complete(asyncio.gather(*pending, return_exceptions=True))
+                self._loop.run_until_complete(self._loop.shutdown_asyncgens())
+            finally:
+                self._loop.close()
+
     def start(self) -> "MonitorServer":
-        self._th = threading.Thread(target=self.httpd.serve_forever, name="klm-http", daemon=True)
+        self._th = threading.Thread(target=self._run, name="klm-http", daemon=True)
         self._th.start()
+        self._ready.wait(timeout=5)
         return self
 
     def serve_forever(self) -> None:
-        self.httpd.serve_forever()
+        self.start()
+        while self._th is not None and self._th.is_alive():
+            self._th.join(timeout=0.5)
 
     def stop(self) -> None:
+        if self._closing:
+            return
         self._closing = True
-        self.httpd.shutdown()
-        self.httpd.server_close()
+
+        def shutdown():
+            if self._server is not None:
+                self._server.close()
+            for w in list(self._sse):
+                try:
+                    w.close()
+                except Exception:
+                    pass
+            self._loop.stop()
+
+        try:
+            self._loop.call_soon_threadsafe(shutdown)
+        except RuntimeError:
+            pass
         if self._th:
-            self._th.join(timeout=2)
+            self._th.join(timeout=3)
+        try:
+            self._sock.close()
+        except OSError:
+            pass
 
     @property
     def url(self) -> str:
@@ -251,6 +350,17 @@ class MonitorServer:
         if host in ("0.0.0.0", "::", ""):
             host = "127.0.0.1"
         return f"http://{host}:{self.port}"
+
+
+def redacted_config(cfg: Config) -> Dict[str, Any]:
+    """The running configuration without anything that can carry a credential."""
+    d = cfg.to_dict()
+    url = d.get("notify", {}).get("webhook_url") or ""
+    if url:
+        from urllib.parse import urlsplit
+        u = urlsplit(url)
+        d["notify"]["webhook_url"] = f"{u.scheme}://{u.hostname or ''}{':%d' % u.port if u.port else ''}/..."
+    return d
 
 
 def validation_report_path() -> str:

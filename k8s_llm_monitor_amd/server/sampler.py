@@ -160,12 +160,15 @@ class Monitor:
         self._history_mode = c.sources.history
         self._prom_ok: Optional[bool] = None
         self._prom_checked = 0.0
+        self._hist_cache = None
+        self._hist_lock = threading.Lock()
 
         self._lock = threading.RLock()
         self._snap: Dict[str, Any] = {"host": {"cpu": {}, "memory": {}, "disk": {}}, "gpus": [], "pods": [],
                                       "vllm": {"available": False}, "alerts": empty_alerts(),
                                       "t_host": 0.0, "t_gpu": 0.0, "t_pods": 0.0, "t_vllm": 0.0, "t_alerts": 0.0}
         self._alert_state = AlertState()
+        self.version = 0            # bumped whenever the snapshot changes (HTTP body cache key)
         self.book = AlertBook(hold_s=c.periods.alert_hold, debounce_s=c.notify.debounce_s)
         self.notifier = None
         if c.notify.webhook_url:
@@ -239,6 +242,7 @@ class Monitor:
         with self._lock:
             self._snap["host"], self._snap["gpus"] = host, gpus
             self._snap["t_host"] = self._snap["t_gpu"] = now
+            self.version += 1
             vllm = self._snap["vllm"]
         self.store.record(now, hist.history_values(host, gpus, vllm if vllm.get("available") else None))
         self._evaluate(now)
@@ -249,6 +253,7 @@ class Monitor:
         now = self.clock()
         with self._lock:
             self._snap["pods"], self._snap["t_pods"] = pods, now
+            self.version += 1
         self._evaluate(now)
         self._emit("pods", pods)
 
@@ -257,6 +262,7 @@ class Monitor:
         now = self.clock()
         with self._lock:
             self._snap["vllm"], self._snap["t_vllm"] = v, now
+            self.version += 1
 
     def tick_all(self) -> None:
         """One synchronous pass over every source (tests, first paint before the threads run)."""
@@ -272,6 +278,7 @@ class Monitor:
             shown = self.book.update(alerts, now)
             before = {a.get("key") for t in s["alerts"].values() for a in t}
             s["alerts"], s["t_alerts"] = shown, now
+            self.version += 1
             new = [a for t in shown.values() for a in t if a.get("key") not in before]
         if new:
             self._emit("alerts", shown)
@@ -346,15 +353,27 @@ class Monitor:
         if mode == "auto":
             mode = "prometheus" if self.prometheus_available() else "local"
         if mode == "prometheus":
-            out = self.prom_history.payload()
-            # MI355X extras always come from the local ring (no PromQL configured for them)
-            local = self.local_history.payload()
-            for k, v in local.items():
-                out.setdefault(k, v)
-            out["source"] = "prometheus"
-            return out
+            # N open dashboards must not become 6N range queries: one result serves everybody for
+            # a few seconds (the data has a 30 s step; the page asks every 30 s)
+            ttl = min(5.0, self.cfg.periods.history_step / 2)
+            now = time.monotonic()
+            with self._hist_lock:
+                if self._hist_cache is not None and now - self._hist_cache[0] < ttl:
+                    return self._hist_cache[1]
+                out = self._history_from_prometheus()
+                self._hist_cache = (time.monotonic(), out)
+                return out
         out = self.local_history.payload()
         out["source"] = "local"
+        return out
+
+    def _history_from_prometheus(self) -> Dict[str, Any]:
+        out = self.prom_history.payload()
+        # MI355X extras always come from the local ring (no PromQL configured for them)
+        local = self.local_history.payload()
+        for k, v in local.items():
+            out.setdefault(k, v)
+        out["source"] = "prometheus"
         return out
 
     def stats(self) -> Dict[str, Any]:

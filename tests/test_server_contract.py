@@ -165,3 +165,92 @@ def test_missing_page_is_fatal_like_the_reference(tmp_path):
     with pytest.raises(FileNotFoundError):
         MonitorServer(mon, cfg)                                              # readFileSync at :241
     mon.stop()
+
+
+def _raw(server, payload: bytes, want: int = 1, timeout=5.0) -> bytes:
+    import socket
+    s = socket.create_connection(("127.0.0.1", server.port), timeout=timeout)
+    s.sendall(payload)
+    buf = b""
+    try:
+        while buf.count(b"HTTP/1.1 ") < want or not _complete(buf):
+            chunk = s.recv(65536)
+            if not chunk:
+                break
+            buf += chunk
+    finally:
+        s.close()
+    return buf
+
+
+def _complete(buf: bytes) -> bool:
+    """Every response in `buf` has its full body."""
+    rest = buf
+    while rest:
+        head, sep, tail = rest.partition(b"\r\n\r\n")
+        if not sep:
+            return False
+        m = re.search(rb"content-length: (\d+)", head.lower())
+        n = int(m.group(1)) if m else 0
+        if b"HEAD-MARK" in head:
+            n = 0
+        if len(tail) < n:
+            return False
+        rest = tail[n:]
+    return True
+
+
+def test_keep_alive_serves_several_requests_on_one_connection(server):
+    req = b"GET /api/host/metrics HTTP/1.1\r\nHost: x\r\n\r\n" + b"GET /healthz?x=1 HTTP/1.1\r\nHost: x\r\n\r\n" + \
+          b"GET /nope HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n"
+    buf = _raw(server, req, want=3)
+    assert buf.count(b"HTTP/1.1 200 OK") == 2 and buf.count(b"HTTP/1.1 404 Not Found") == 1
+    assert buf.count(b"Connection: keep-alive") == 2 and buf.endswith(b"Not Found")
+
+
+def test_head_has_headers_only_and_post_body_is_drained(server):
+    import socket
+    s = socket.create_connection(("127.0.0.1", server.port), timeout=5)
+    s.sendall(b"HEAD /api/gpu/metrics HTTP/1.1\r\nHost: x\r\n\r\n")
+    head = b""
+    while b"\r\n\r\n" not in head:
+        head += s.recv(4096)
+    assert head.endswith(b"\r\n\r\n") and int(re.search(rb"Content-Length: (\d+)", head).group(1)) > 1000
+    s.sendall(b"POST /api/alerts HTTP/1.1\r\nHost: x\r\nContent-Length: 5\r\n\r\nhelloGET /healthz HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n")
+    buf = b""
+    while True:
+        c = s.recv(4096)
+        if not c:
+            break
+        buf += c
+    s.close()
+    assert buf.startswith(b"HTTP/1.1 405") and b"HTTP/1.1 200 OK" in buf and b'"ok":true' in buf
+
+
+def test_oversized_header_and_garbage_do_not_kill_the_server(server):
+    assert b" 431 " in _raw(server, b"GET / HTTP/1.1\r\nX: " + b"a" * 40000 + b"\r\n\r\n")
+    assert b" 400 " in _raw(server, b"\r\n\r\n")
+    assert get(server, "/healthz")[0] == 200
+
+
+def test_bodies_are_cached_per_snapshot_version(server):
+    m = server.monitor
+    for t in m.tasks.values():
+        t.stop()
+    time.sleep(0.15)
+    a = get(server, "/api/gpu/metrics")[2]
+    v = m.version
+    assert server._cache["/api/gpu/metrics"][0] == v and get(server, "/api/gpu/metrics")[2] == a
+    m.tick_realtime()
+    assert m.version > v
+    b = get(server, "/api/gpu/metrics")[2]
+    assert server._cache["/api/gpu/metrics"][0] == m.version and json.loads(b)[0]["timestamp"] != json.loads(a)[0]["timestamp"]
+    for t in m.tasks.values():
+        t._stop.clear(); t.start()
+
+
+def test_config_endpoint_redacts_the_webhook():
+    from k8s_llm_monitor_amd.server.http import redacted_config
+    cfg = demo_config(notify={"webhook_url": "https://hooks.example.com:8443/services/T000/B000/secret-token?x=1"})
+    d = redacted_config(cfg)
+    assert d["notify"]["webhook_url"] == "https://hooks.example.com:8443/..." and "secret-token" not in json.dumps(d)

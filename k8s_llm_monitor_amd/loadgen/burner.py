@@ -39,8 +39,11 @@ def plan_window(duty: float, period_s: float, kernel_s: float) -> int:
 
 
 class Burner:
+    GRAPH_CHUNK = 32          # kernels per captured hipGraph
+    GRAPH_BELOW_S = 100e-6    # "auto": capture when one kernel is shorter than this (launch-bound)
+
     def __init__(self, kind: str = "gemm_bf16", size: int = 8192, duty: float = 100.0, period_ms: float = 100.0,
-                 device: int = 0, hbm_bytes: int = 2 * GIB):
+                 device: int = 0, hbm_bytes: int = 2 * GIB, graph: Any = "auto"):
         if kind not in KINDS:
             raise ValueError(f"unknown burner kind {kind!r}; have {KINDS}")
         if not (0.0 <= duty <= 100.0):
@@ -75,6 +78,12 @@ class Burner:
                 self.bytes = float(n)
             self.sink = torch.zeros(4, dtype=torch.int32, device=self.dev)
         self.kernel_s = self.calibrate()
+        # Short kernels are launch-bound from Python (a ctypes call + a HIP launch per kernel is
+        # ~10 us): capture GRAPH_CHUNK launches into one hipGraph and replay that instead.
+        self.graph = None
+        if graph is True or (graph == "auto" and self.kernel_s < self.GRAPH_BELOW_S):
+            self._capture()
+            self.kernel_s = self.calibrate()
         self._stop = threading.Event()
         self._th: Optional[threading.Thread] = None
         self._lock = threading.Lock()
@@ -96,15 +105,36 @@ class Burner:
         else:
             ops.spin(2_400_000, 1024, self.dev)      # ~1 ms (s_memtime ticks ~2.4 GHz here); calibrated anyway
 
+    def _capture(self) -> None:
+        torch = self.torch
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.stream):
+            self.launch()                       # first launch outside capture (one-time function attributes)
+            self.stream.synchronize()
+            with torch.cuda.graph(g, stream=self.stream):
+                for _ in range(self.GRAPH_CHUNK):
+                    self.launch()
+        self.graph = g
+
+    def launch_many(self, n: int) -> None:
+        """`n` kernels on the burner's stream: whole graph chunks, then single launches."""
+        if self.graph is not None:
+            while n >= self.GRAPH_CHUNK:
+                self.graph.replay()
+                n -= self.GRAPH_CHUNK
+        for _ in range(n):
+            self.launch()
+
     def calibrate(self, iters: int = 10) -> float:
         torch = self.torch
         with torch.cuda.stream(self.stream):
             for _ in range(3):
                 self.launch()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if getattr(self, "graph", None) is not None:
+                iters = max(iters, 4 * self.GRAPH_CHUNK)
             e0.record(self.stream)
-            for _ in range(iters):
-                self.launch()
+            self.launch_many(iters) if hasattr(self, "graph") else [self.launch() for _ in range(iters)]
             e1.record(self.stream)
         e1.synchronize()
         return e0.elapsed_time(e1) / 1e3 / iters
@@ -152,8 +182,7 @@ class Burner:
                 if n_per:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
-                    for _ in range(n_per):
-                        self.launch()
+                    self.launch_many(n_per)
                     e1.record(self.stream)
                     pending.append((e0, e1, n_per))
                     if full:
@@ -179,6 +208,7 @@ class Burner:
         st = st or self._stats
         wall, busy = max(st["wall_s"], 1e-9), max(st["busy_s"], 1e-12)
         out = {"kind": self.kind, "size": self.size, "duty_target": self.duty, "period_ms": self.period_s * 1e3,
+               "hip_graph": self.graph is not None,
                "kernel_ms": self.kernel_s * 1e3, "kernels": st["kernels"], "wall_s": wall,
                "duty_achieved": min(100.0, st["busy_s"] / wall * 100.0)}
         if self.flops:

@@ -92,6 +92,20 @@ def test_full_duty_burner_rates(torch_dev):
     assert out["TBps_busy"] > 3.0
 
 
+def test_small_kernels_run_from_a_hip_graph_and_hold_their_duty(torch_dev):
+    from k8s_llm_monitor_amd.loadgen.burner import Burner
+    plain = Burner("gemm_bf16", size=512, duty=100.0, graph=False)
+    graphed = Burner("gemm_bf16", size=512, duty=100.0)              # auto: a 512^3 kernel takes a few microseconds
+    assert graphed.graph is not None and plain.graph is None
+    a, b = plain.run(1.0), graphed.run(1.0)
+    print("512^3 kernels/s: plain %.0f, graph %.0f" % (a["kernels"] / a["wall_s"], b["kernels"] / b["wall_s"]))
+    assert b["hip_graph"] and b["kernels"] / b["wall_s"] > 0.95 * a["kernels"] / a["wall_s"]   # never slower; faster when launch-bound
+    half = Burner("gemm_bf16", size=1024, duty=50.0, period_ms=20.0).run(2.0)
+    assert abs(half["duty_achieved"] - 50.0) < 5.0
+    big = Burner("gemm_bf16", size=8192, duty=100.0)
+    assert big.graph is None                                                  # 0.75 ms kernels are not launch-bound
+
+
 def test_hbm_hold_moves_the_amdsmi_reading_and_releases(torch_dev):
     torch, dev = torch_dev
     from k8s_llm_monitor_amd.collectors.gpu import open_gpu_source

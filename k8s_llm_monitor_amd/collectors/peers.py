@@ -14,7 +14,7 @@ import socket
 import time
 import urllib.request
 from concurrent.futures import ThreadPoolExecutor
-from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence
+from typing import Any, Callable, Dict, Mapping, Optional, Sequence
 
 
 def digest(summary: Mapping[str, Any]) -> Dict[str, Any]:

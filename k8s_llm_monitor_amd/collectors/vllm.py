@@ -24,7 +24,7 @@ import math
 import re
 import time
 import urllib.request
-from typing import Any, Callable, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
+from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 from .counters import RateTracker
 

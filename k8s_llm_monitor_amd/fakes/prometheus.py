@@ -11,7 +11,7 @@ import math
 import threading
 import urllib.parse
 from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
-from typing import Callable, Dict, List, Optional
+from typing import Callable, List, Optional
 
 Resolver = Callable[[str, float], Optional[float]]
 

@@ -7,7 +7,7 @@ self-defined baseline figures (sampling overhead).
 """
 from __future__ import annotations
 
-from typing import Any, Dict, Iterable, List, Mapping, Optional, Tuple
+from typing import Any, Dict, List, Mapping, Optional
 
 
 def _esc(v: Any) -> str:

@@ -6,9 +6,8 @@ overhead, alert latency and the RCCL bus bandwidth at N GPUs.
 """
 from __future__ import annotations
 
-import threading
 import time
-from typing import Any, Dict, Optional
+from typing import Any, Dict
 
 
 def _sync_all(torch, dist, world):

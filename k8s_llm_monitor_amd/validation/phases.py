@@ -21,7 +21,6 @@ from __future__ import annotations
 import json
 import os
 import sys
-import threading
 import time
 import urllib.request
 from typing import Any, Dict, List, Optional

@@ -23,7 +23,7 @@ import os
 import shutil
 import subprocess
 import sys
-from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Iterable, List, Optional, Sequence
 
 SLOTS = {"SQ_": 8, "TCC_": 4, "TCP_": 4, "TA_": 2, "TD_": 2, "GRBM_": 2}
 TCC_COST = {"FETCH_SIZE": 3, "WRITE_SIZE": 2}

@@ -169,3 +169,22 @@ def test_real_hbm_crossing_raises_the_alert_over_http(torch_dev):
     finally:
         srv.stop()
         mon.stop()
+
+
+def test_standalone_cpp_burner(torch_dev):
+    """klm_burner needs neither Python nor PyTorch on the node: duty control, fp8, HBM hold."""
+    from k8s_llm_monitor_amd.build import artifact
+    exe = str(artifact("klm_burner"))
+
+    def run(*args):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return [json.loads(l) for l in r.stdout.strip().splitlines()]
+
+    out = run("--kind", "gemm_bf16", "--duty", "50", "--seconds", "2.5", "--period-ms", "50")
+    fin = out[-1]
+    assert abs(fin["duty_achieved"] - 50.0) < 5.0 and fin["tflops_busy"] > 900 and any("t" in l for l in out[:-1])
+    fin = run("--kind", "gemm_fp8", "--seconds", "1.5")[-1]
+    assert fin["duty_achieved"] > 97.0 and fin["tflops_avg"] > 1500
+    out = run("--kind", "hbm_copy", "--seconds", "1.5", "--hbm-gib", "8")
+    assert out[0] == {"hbm_hold_gib": 8.0} and out[-1]["TBps_busy"] > 3.5

@@ -142,7 +142,9 @@ def activity_fidelity(torch, dev, src, smi_idx: int, duties=(25.0, 50.0, 75.0, 1
 def mem_activity(torch, dev, src, smi_idx: int, seconds: float = 4.0) -> Dict[str, Any]:
     from ..loadgen.burner import Burner
     rows = []
-    for kind in ("hbm_copy", "hbm_read", "hbm_fill"):
+    # "spin" keeps waves resident with no memory traffic and no matrix work: GFX activity reads
+    # 100 % at near-idle power, the case that shows activity is not utilisation
+    for kind in ("hbm_copy", "hbm_read", "hbm_fill", "spin"):
         b = Burner(kind, duty=100.0, device=dev.index or 0, hbm_bytes=4 * GIB)
         b.start(seconds + 60.0)
         time.sleep(0.5)

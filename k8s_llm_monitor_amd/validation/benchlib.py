@@ -105,6 +105,17 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         except Exception as e:
             extras["rccl_allreduce"] = {"error": f"{type(e).__name__}: {e}"}
 
+    if world > 1 and not a.no_validation:
+        # xGMI counter fidelity: only measurable with peers (every rank takes part in the collectives)
+        try:
+            from . import phases as _ph
+            xf = _ph.xgmi_fidelity(torch, dist, dev, rank, world)
+            if rank == 0:
+                extras["xgmi_fidelity"] = xf
+        except Exception as e:
+            if rank == 0:
+                extras["xgmi_fidelity"] = {"error": f"{type(e).__name__}: {e}"}
+
     if not a.no_validation and rank == 0:
         # the other validation-load kernels, 1 s each (outside the timed region)
         try:

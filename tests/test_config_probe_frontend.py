@@ -141,3 +141,13 @@ def test_page_script_parses_with_node_if_present(page, tmp_path):
     f.write_text(js)
     r = subprocess.run([node, "--check", str(f)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_xgmi_expected_volume_and_counter_totals():
+    from k8s_llm_monitor_amd.validation.phases import xgmi_expected_bytes, xgmi_link_totals
+    assert xgmi_expected_bytes(1, 1 << 20, 10) == 0.0
+    assert xgmi_expected_bytes(2, 1 << 20, 10) == 10 * (1 << 20)
+    assert xgmi_expected_bytes(8, 1 << 28, 40) == 2 * 7 / 8 * (1 << 28) * 40
+    t = xgmi_link_totals({"xgmi": {"links": [{"txBytes": 10, "rxBytes": 4, "state": "up"}, {"txBytes": None, "rxBytes": 6, "state": "down"}]}})
+    assert t["tx"] == 10 and t["rx"] == 10 and t["links_up"] == 1 and t["per_link_tx"] == [10.0, 0.0]
+    assert xgmi_link_totals({})["tx"] == 0.0

@@ -42,6 +42,9 @@ def parse_args():
                     help="skip the fidelity / overhead / alert-latency phases")
     ap.add_argument("--no-probe", action="store_true", help="skip the RCCL all-reduce size sweep (N > 1)")
     ap.add_argument("--probe-max-bytes", type=int, default=1 << 28)
+    ap.add_argument("--cpu-rehearsal", action="store_true",
+                    help="run the same step loop on CPU with gloo and a torch.matmul stand-in (tests the launch / "
+                         "reduction / JSON contract without a GPU; the number it prints is not a benchmark)")
     ap.add_argument("--sample-period", type=float, default=0.0,
                     help="telemetry period in s during the timed region (0 = config default 5 s)")
     return ap.parse_args()
@@ -59,12 +62,19 @@ def main():
     if world != a.gpus:
         if rank == 0:
             print(f"[bench] note: WORLD_SIZE={world} but --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if a.cpu_rehearsal:
+        dev = torch.device("cpu")
+        a.no_sampler = a.no_validation = a.no_probe = True
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.cpu_rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from k8s_llm_monitor_amd.validation import benchlib
     result = benchlib.run(a, rank=rank, world=world, dev=dev, ops=ops)

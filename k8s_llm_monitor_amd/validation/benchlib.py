@@ -36,7 +36,7 @@ def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int) -
     _sync_all(torch, dist, world)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=load.a.device, dtype=torch.float64)
+        t = torch.tensor([dt], device=load.x.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -65,7 +65,10 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     import torch.distributed as dist
 
     size = a.size
-    load = _Load(torch, dist, ops, dev, world, size)
+    gemm = None
+    if dev.type != "cuda":                      # --cpu-rehearsal
+        gemm = lambda x, w, out: out.copy_(x.float() @ w.float().t())
+    load = _Load(torch, dist, ops, dev, world, size, gemm=gemm)
     extras: Dict[str, Any] = {}
 
     sampler = None
@@ -158,7 +161,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
-        "data": "synthetic (uniform [-1,1) operands, random init)",
+        "data": "synthetic (uniform [-1,1) operands, random init)" + ("; CPU REHEARSAL, not a benchmark" if dev.type != "cuda" else ""),
         "config": {
             "model": "klm bf16 GEMM burner, one %dx%d linear layer: fwd+dgrad+wgrad (hand-written gfx950 MFMA kernel) + RCCL all-reduce of dW" % (size, size),
             "global_batch": world,

@@ -246,40 +246,59 @@ def xgmi_link_totals(sample: Dict[str, Any]) -> Dict[str, float]:
             "per_link_tx": [float(l.get("txBytes") or 0) for l in links], "links_up": sum(1 for l in links if l.get("state") == "up")}
 
 
-def xgmi_fidelity(torch, dist, dev, rank: int, world: int, nbytes: int = 1 << 28, iters: int = 40) -> Dict[str, Any]:
+def xgmi_fidelity(torch, dist, dev, rank: int, world: int, nbytes: int = 1 << 28, iters: int = 40,
+                  settle_s: float = 1.2) -> Dict[str, Any]:
     """Multi-GPU only: every rank all-reduces a known volume; rank 0 compares the growth of its
-    amdsmi xGMI byte counters with the volume the algorithm must move. Called by ALL ranks."""
-    from ..collectors.gpu import open_gpu_source
+    amdsmi xGMI byte counters with the volume the algorithm must move. Called by ALL ranks; the
+    collectives are unconditional, so a telemetry failure on rank 0 cannot leave the others hanging."""
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    src, idx, err = None, 0, None
+    if rank == 0:
+        try:
+            from ..collectors.gpu import open_gpu_source
+            src = open_gpu_source("amdsmi")
+            idx = _smi_index_for(torch, dev, src)
+        except Exception as e:
+            src, err = None, f"{type(e).__name__}: {e}"
     x = torch.ones(nbytes // 2, dtype=torch.bfloat16, device=dev)
-    src = open_gpu_source("amdsmi") if rank == 0 else None
-    idx = _smi_index_for(torch, dev, src) if src is not None else 0
     for _ in range(3):
         dist.all_reduce(x)
         x.fill_(1.0)
-    torch.cuda.synchronize(dev)
+    sync()
     dist.barrier()
-    before = xgmi_link_totals(_gpu_sample(src, idx)) if src is not None else None
+    before = None
+    if src is not None:
+        s0 = _gpu_sample(src, idx)
+        before = xgmi_link_totals(s0) if s0 else None
     t0 = time.perf_counter()
     for _ in range(iters):
         dist.all_reduce(x)
-    torch.cuda.synchronize(dev)
+        x.fill_(1.0)
+    sync()
     dist.barrier()
     dt = time.perf_counter() - t0
-    out: Dict[str, Any] = {}
-    if src is not None:
-        time.sleep(1.2)                                   # the firmware publishes its counters about once a second
-        after = xgmi_link_totals(_gpu_sample(src, idx))
-        src.close()
-        want = xgmi_expected_bytes(world, nbytes, iters)
-        tx, rx = after["tx"] - before["tx"], after["rx"] - before["rx"]
-        per_link = [a - b for a, b in zip(after["per_link_tx"], before["per_link_tx"])]
-        out = {"world": world, "allreduce_bytes": nbytes, "iters": iters, "seconds": dt, "expected_bytes_per_gpu": want,
-               "counter_tx_bytes": tx, "counter_rx_bytes": rx, "links_up": after["links_up"],
-               "tx_error_pct": abs(tx - want) / want * 100.0 if want else None,
-               "rx_error_pct": abs(rx - want) / want * 100.0 if want else None,
-               "per_link_tx_GB": [round(v / 1e9, 3) for v in per_link],
-               "link_imbalance": (max(per_link) / (sum(per_link) / len(per_link))) if per_link and sum(per_link) > 0 else None,
-               "busbw_GBps": want / dt / 1e9 if dt > 0 else None}
+    if rank != 0:
+        return {}
+    want = xgmi_expected_bytes(world, nbytes, iters)
+    out: Dict[str, Any] = {"world": world, "allreduce_bytes": nbytes, "iters": iters, "seconds": dt,
+                           "expected_bytes_per_gpu": want, "busbw_GBps": want / dt / 1e9 if dt > 0 else None}
+    if src is None or before is None:
+        out["error"] = err or "no telemetry sample"
+        return out
+    time.sleep(settle_s)                                  # the firmware publishes its counters about once a second
+    s1 = _gpu_sample(src, idx)
+    src.close()
+    after = xgmi_link_totals(s1) if s1 else before
+    tx, rx = after["tx"] - before["tx"], after["rx"] - before["rx"]
+    per_link = [a - b for a, b in zip(after["per_link_tx"], before["per_link_tx"])]
+    out.update({"counter_tx_bytes": tx, "counter_rx_bytes": rx, "links_up": after["links_up"],
+                "tx_error_pct": abs(tx - want) / want * 100.0 if want else None,
+                "rx_error_pct": abs(rx - want) / want * 100.0 if want else None,
+                "per_link_tx_GB": [round(v / 1e9, 3) for v in per_link],
+                "link_imbalance": (max(per_link) / (sum(per_link) / len(per_link))) if per_link and sum(per_link) > 0 else None})
     return out
 
 

@@ -41,6 +41,13 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64)
     ts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(ts, t)
+    # 3. the xGMI fidelity phase: collectives on every rank, telemetry (absent here) on rank 0 only
+    from k8s_llm_monitor_amd.validation import phases
+    xf = phases.xgmi_fidelity(torch, dist, dev, rank, world, nbytes=1 << 16, iters=3, settle_s=0.0)
+    if rank == 0:
+        out["xgmi"] = {k: xf.get(k) for k in ("world", "expected_bytes_per_gpu", "error")}
+    else:
+        assert xf == {}
     if rank == 0:
         out["steps_s"] = dt
         out["same_time_on_all_ranks"] = all(float(x) == float(ts[0]) for x in ts)

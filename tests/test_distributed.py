@@ -35,6 +35,7 @@ def test_probe_and_bench_loop_on_two_ranks():
     assert out["curve"]["n_gpus"] == 2 and out["curve"]["verified"] and out["curve"]["executor"] == "torch.distributed/gloo"
     assert out["checks"] == ["ok", "ok", "ok"] and out["bytes"] == [1024, 4096, 65536]
     assert out["curve"]["peak_busbw_GBps"] > 0 and out["allgather"] and out["reducescatter"] and out["alltoall"]
+    assert out["xgmi"]["world"] == 2 and out["xgmi"]["expected_bytes_per_gpu"] == 3 * (1 << 16) and out["xgmi"]["error"]   # no amdsmi here
     assert out["allreduce_ok"] and out["same_time_on_all_ranks"] and out["i"] == 4 and out["steps_s"] > 0
 
 
@@ -47,3 +48,39 @@ def test_dist_probe_cli_writes_dashboard_results(tmp_path):
     doc = json.loads(out.read_text())
     assert doc["curves"][0]["n_gpus"] == 2 and doc["scaling"][0]["ceiling_mesh_GBps"] == 153.0
     assert [p["bytes"] for p in doc["curves"][0]["points"]] == [1024, 4096, 16384]
+
+
+REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+            "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict}
+
+
+def check_bench_line(stdout: str, n: int, steps: int, warmup: int):
+    # exactly ONE JSON line, from rank 0 (gloo's C++ layer prints its own "[Gloo] Rank ..." chatter on CPU)
+    lines = [l[l.index('{"metric"'):] for l in stdout.splitlines() if '{"metric"' in l]
+    assert len(lines) == 1, stdout
+    d = json.loads(lines[0])
+    for k, t in REQUIRED.items():
+        assert isinstance(d[k], t), (k, d[k])
+    assert "vs_baseline" in d and d["vs_baseline"] is None            # BASELINE.md has no number to divide by
+    assert d["n_gpus"] == n and d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "bf16" and "synthetic" in d["data"]
+    assert set(d["config"]) >= {"model", "global_batch", "seq_len", "parallelism"} and d["config"]["parallelism"] == (f"dp{n}" if n > 1 else "single")
+    # value is the whole-job aggregate: n ranks x FLOP per step / step time
+    assert d["value"] == pytest.approx(n * d["flop_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12, rel=2e-2)
+    return d
+
+
+@pytest.mark.timeout(240)
+def test_bench_contract_single_process_rehearsal():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-rehearsal", "--size", "256", "--steps", "3", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    check_bench_line(r.stdout, 1, 3, 1)
+
+
+@pytest.mark.timeout(240)
+def test_bench_contract_two_ranks_rehearsal():
+    r = torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-rehearsal", "--size", "256", "--steps", "4", "--warmup", "2"])
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = check_bench_line(r.stdout, 2, 4, 2)
+    assert d["allreduce_bytes_per_step"] == 256 * 256 * 2 and d["allreduce_busbw_GBps_overlapped"] > 0

@@ -112,7 +112,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--force", action="store_true")
     p.add_argument("targets", nargs="*")
     p = sub.add_parser("burner")
-    p.add_argument("--kind", default="gemm_bf16", choices=["gemm_bf16", "gemm_fp8", "hbm_copy", "hbm_read", "hbm_fill", "spin"])
+    p.add_argument("--kind", default="gemm_bf16", choices=["gemm_bf16", "gemm_fp8", "gemm_fp4", "hbm_copy", "hbm_read", "hbm_fill", "spin"])
     p.add_argument("--duty", type=float, default=100.0, help="busy share in percent")
     p.add_argument("--period-ms", type=float, default=100.0, help="duty-cycle period")
     p.add_argument("--seconds", type=float, default=10.0)

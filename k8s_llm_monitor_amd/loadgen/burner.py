@@ -2,7 +2,7 @@
 
 No reference counterpart (BASELINE.json north_star item 4). Kinds:
 
-  gemm_bf16 / gemm_fp8   the hand-written MFMA GEMM kernels (ops.gemm_bf16 / ops.gemm_fp8)
+  gemm_bf16 / gemm_fp8 / gemm_fp4   the hand-written MFMA GEMM kernels (ops.gemm_bf16 / gemm_fp8 / gemm_fp4)
   hbm_copy / hbm_read / hbm_fill   HBM bandwidth burners (known MEM/UMC activity)
   spin                   busy waves with no memory traffic and no matrix work
 
@@ -23,7 +23,7 @@ import threading
 import time
 from typing import Any, Callable, Dict, List, Optional
 
-KINDS = ("gemm_bf16", "gemm_fp8", "hbm_copy", "hbm_read", "hbm_fill", "spin")
+KINDS = ("gemm_bf16", "gemm_fp8", "gemm_fp4", "hbm_copy", "hbm_read", "hbm_fill", "spin")
 GIB = 1 << 30
 
 
@@ -58,7 +58,13 @@ class Burner:
         g.manual_seed(4321)
         self.flops = 0.0          # per kernel
         self.bytes = 0.0          # HBM bytes moved per kernel
-        if kind in ("gemm_bf16", "gemm_fp8"):
+        if kind == "gemm_fp4":
+            # every byte is two valid e2m1 codes: random bytes are random fp4 operands
+            self.a = torch.randint(0, 256, (size, size // 2), device=self.dev, generator=g, dtype=torch.uint8)
+            self.b = torch.randint(0, 256, (size, size // 2), device=self.dev, generator=g, dtype=torch.uint8)
+            self.c = torch.empty(size, size, device=self.dev, dtype=torch.bfloat16)
+            self.flops = 2.0 * size ** 3
+        elif kind in ("gemm_bf16", "gemm_fp8"):
             a = torch.rand(size, size, device=self.dev, generator=g) * 2 - 1
             b = torch.rand(size, size, device=self.dev, generator=g) * 2 - 1
             if kind == "gemm_bf16":
@@ -96,6 +102,8 @@ class Burner:
             ops.gemm_bf16(self.a, self.b, out=self.c)
         elif k == "gemm_fp8":
             ops.gemm_fp8(self.a, self.b, out=self.c)
+        elif k == "gemm_fp4":
+            ops.gemm_fp4(self.a, self.b, out=self.c)
         elif k == "hbm_copy":
             ops.hbm_copy(self.y, self.x)
         elif k == "hbm_read":

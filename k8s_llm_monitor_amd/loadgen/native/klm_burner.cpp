@@ -4,7 +4,7 @@
 //
 // No reference counterpart (BASELINE.json north_star item 4).
 //
-//   klm_burner --kind gemm_bf16|gemm_fp8|hbm_copy|hbm_read|hbm_fill|spin
+//   klm_burner --kind gemm_bf16|gemm_fp8|gemm_fp4|hbm_copy|hbm_read|hbm_fill|spin
 //              [--size 8192] [--duty 100] [--period-ms 100] [--seconds 10]
 //              [--hbm-gib G]   also allocate and touch G GiB (HBM exhaustion injector)
 //              [--device 0]
@@ -64,6 +64,14 @@ __global__ void fill_fp8_uniform(uint8_t* p, size_t n, uint32_t seed) {
   }
 }
 
+__global__ void fill_bytes_random(uint8_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2246822519u ^ seed;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    p[i] = (uint8_t)(x >> 11);
+  }
+}
+
 struct Args {
   std::string kind = "gemm_bf16";
   int size = 8192, device = 0;
@@ -97,8 +105,8 @@ int main(int argc, char** argv) {
   hipStream_t s;
   HIPCHECK(hipStreamCreate(&s));
 
-  const bool gemm = a.kind == "gemm_bf16" || a.kind == "gemm_fp8";
-  const bool fp8 = a.kind == "gemm_fp8";
+  const bool gemm = a.kind == "gemm_bf16" || a.kind == "gemm_fp8" || a.kind == "gemm_fp4";
+  const bool fp8 = a.kind == "gemm_fp8", fp4 = a.kind == "gemm_fp4";
   const bool hbm = a.kind.rfind("hbm_", 0) == 0;
   if (!gemm && !hbm && a.kind != "spin") {
     printf("{\"error\":\"unknown kind %s\"}\n", a.kind.c_str());
@@ -108,11 +116,14 @@ int main(int argc, char** argv) {
   double flops = 0, bytes = 0;
   const size_t n2 = (size_t)a.size * a.size;
   if (gemm) {
-    const size_t esz = fp8 ? 1 : 2;
-    HIPCHECK(hipMalloc(&A, n2 * esz));
-    HIPCHECK(hipMalloc(&B, n2 * esz));
+    const size_t abytes = fp4 ? n2 / 2 : fp8 ? n2 : n2 * 2;
+    HIPCHECK(hipMalloc(&A, abytes));
+    HIPCHECK(hipMalloc(&B, abytes));
     HIPCHECK(hipMalloc(&C, n2 * 2));
-    if (fp8) {
+    if (fp4) {   // every byte is two valid e2m1 codes: random bytes are random fp4 operands
+      hipLaunchKernelGGL(fill_bytes_random, dim3(2048), dim3(256), 0, s, (uint8_t*)A, abytes, 1u);
+      hipLaunchKernelGGL(fill_bytes_random, dim3(2048), dim3(256), 0, s, (uint8_t*)B, abytes, 2u);
+    } else if (fp8) {
       hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)A, n2, 1u);
       hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)B, n2, 2u);
     } else {
@@ -153,6 +164,7 @@ int main(int argc, char** argv) {
   }
 
   auto launch = [&]() -> int {
+    if (fp4) return klm_gemm_fp4(A, B, C, a.size, a.size, a.size, 0, s);
     if (gemm) return fp8 ? klm_gemm_fp8(A, B, C, a.size, a.size, a.size, 0, s) : klm_gemm_bf16(A, B, C, a.size, a.size, a.size, 1, s);
     if (a.kind == "hbm_copy") return klm_hbm_copy(Y, X, (size_t)2 << 30, s);
     if (a.kind == "hbm_read") return klm_hbm_read(X, (size_t)2 << 30, sink, s);

@@ -54,6 +54,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         if hasattr(lib, "klm_gemm_fp8"):
             lib.klm_gemm_fp8.argtypes = [vp, vp, vp, i, i, i, i, vp]
             lib.klm_gemm_fp8.restype = i
+        if hasattr(lib, "klm_gemm_fp4"):
+            lib.klm_gemm_fp4.argtypes = [vp, vp, vp, i, i, i, i, vp]
+            lib.klm_gemm_fp4.restype = i
         lib.klm_hbm_fill.argtypes = [vp, sz, u32, vp]
         lib.klm_hbm_fill.restype = i
         lib.klm_hbm_copy.argtypes = [vp, vp, sz, vp]
@@ -139,6 +142,41 @@ def gemm_fp8(a, b, out=None, variant: int = 0):
         raise KlmOpsError("libklm_ops.so was built without the fp8 kernel")
     rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
     _check(rc, f"klm_gemm_fp8(M={M},N={N},K={K})")
+    return out
+
+
+#: the 16 e2m1 code points (sign, 2-bit exponent, 1-bit mantissa), index = the 4-bit code
+FP4_VALUES = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0)
+
+
+def fp4_decode(packed):
+    """uint8 [.., K/2] (two e2m1 codes per byte, low nibble first) -> float32 [.., K]."""
+    import torch
+    lut = torch.tensor(FP4_VALUES, dtype=torch.float32, device=packed.device)
+    p = packed.view(torch.uint8).to(torch.int64)
+    lo, hi = lut[p & 15], lut[p >> 4]
+    return torch.stack((lo, hi), dim=-1).reshape(*packed.shape[:-1], packed.shape[-1] * 2)
+
+
+def gemm_fp4(a, b, out=None):
+    """``out[M,N] (bf16) = A[M,K] @ B[N,K].T`` with e2m1 (fp4) inputs packed two per byte:
+    `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2]."""
+    import torch
+    _require_cuda(a, b)
+    ok = (torch.uint8, getattr(torch, "float4_e2m1fn_x2", torch.uint8))
+    if a.dtype not in ok or b.dtype not in ok:
+        raise KlmOpsError("gemm_fp4 needs packed uint8 / float4_e2m1fn_x2 inputs")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise KlmOpsError("gemm_fp4 shapes do not match")
+    M, Kb = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    lib = load()
+    if not hasattr(lib, "klm_gemm_fp4"):
+        raise KlmOpsError("libklm_ops.so was built without the fp4 kernel")
+    rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, 0, _stream(a))
+    _check(rc, f"klm_gemm_fp4(M={M},N={N},K={Kb * 2})")
     return out
 
 

@@ -1,22 +1,26 @@
-// fp8 (OCP e4m3fn) MFMA GEMM burner kernel for MI355X (gfx950, CDNA4).
+// MX-format MFMA GEMM burner kernels for MI355X (gfx950, CDNA4): fp8 (OCP e4m3) and fp4 (e2m1).
 //
-//   C[M][N] (bf16) = A[M][K] (e4m3) * B[N][K]^T (e4m3), fp32 accumulate.
+//   C[M][N] (bf16) = A[M][K] * B[N][K]^T, fp32 accumulate, on the block-scaled MFMA
+//   v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales (2^0 for every 32-element block).
+//   fp8: 2x the bf16 MFMA rate;  fp4 (two elements per byte): 4x.
 //
-// No reference counterpart: the fp8 variant of the "known, steady
-// GFX load" of BASELINE.json north_star item 4.
+// No reference counterpart: the low-precision variants of the "known,
+// steady GFX load" of BASELINE.json north_star item 4.
 //
 // Same structure as gemm_bf16_256 (gemm_bf16.hip): 256x256 output tile, 8 waves (2x4),
 // 128 KiB LDS as a ring of 2 stages x 4 half-tile slots, LDS-DMA staging with counted
-// vmcnt, two wave groups staggered by one barrier. A K tile is 128 BYTES per row in both
-// kernels, so staging, slot layout and swizzle are byte-identical; here those 128 bytes
-// are 128 fp8 elements and one v_mfma_scale_f32_16x16x128_f8f6f4 (block-scaled MX form,
-// unit scales, 2x the bf16 rate) consumes the whole row per 16x16 tile:
-//   bf16: 16 x mfma_16x16x32 per phase per wave;  fp8: 8 x mfma_scale_16x16x128.
+// vmcnt, two wave groups staggered by one barrier. A K tile is 128 BYTES per row in all three
+// kernels, so staging, slot layout and swizzle are byte-identical; what differs is how many
+// elements those 128 bytes hold and how many MFMAs consume them per 16x16 tile:
+//   bf16:  64 elements, 2 x mfma_16x16x32        (16 bytes per lane each)
+//   fp8:  128 elements, 1 x mfma_scale_16x16x128 (32 bytes per lane)
+//   fp4:  256 elements, 2 x mfma_scale_16x16x128 (16 bytes per lane each)
 //
-// Operand k-mapping: lane l (row l&15, lane group g = l>>4) supplies the two 16-byte chunks
-// g and g+4 of the 128-byte row, for A and for B alike. The hardware multiplies A's
-// (lane group, byte j) with B's (lane group, byte j), so any assignment of k to (group, byte)
-// gives the same sum as long as both operands use it. This one makes the LDS read pattern
+// Operand k-mapping: lane l (row l&15, lane group g = l>>4) supplies 16-byte chunk(s) of the
+// 128-byte row, for A and for B alike: fp8 chunks g and g+4, fp4 chunk 4*ks+g for MFMA ks.
+// The hardware multiplies A's (lane group, byte j) with B's (lane group, byte j), so any
+// assignment of k to (group, byte) gives the same sum as long as both operands use it (and,
+// for fp4, whichever nibble of a byte is "first"). These assignments make the LDS read pattern
 // identical to the bf16 kernel's (chunk index = 4*h + g), which rocprofv3 shows free of bank
 // conflicts; "32 consecutive bytes per lane" (chunks 2g, 2g+1) measured 0.64 conflict
 // cycles per active instruction (profiles/r1_prof/pmc_summary.json).
@@ -70,9 +74,11 @@ __device__ __forceinline__ void store_c4(uint16_t* C, size_t idx, const f32x4& v
 #define KLM_SLOT_A1 49152
 #define KLM_UNIT_SCALE 0x7f7f7f7f  // four E8M0 scales of 2^0
 
-__global__ __launch_bounds__(512) void gemm_fp8_256(const uint8_t* __restrict__ A,
-                                                    const uint8_t* __restrict__ B,
-                                                    uint16_t* __restrict__ C, int M, int N, int K) {
+// FMT: the MFMA's operand format code, 0 = fp8 e4m3, 4 = fp4 e2m1. K is the row length in BYTES.
+template <int FMT>
+__global__ __launch_bounds__(512) void gemm_mx_256(const uint8_t* __restrict__ A,
+                                                   const uint8_t* __restrict__ B,
+                                                   uint16_t* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,25 +123,44 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const uint8_t* __restrict__ 
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[i][j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  i32x8 a[4], b0[2], b1[2];
+  // Fragments as [ks][tile]: fp8 uses ks = 0 only and all 8 registers (chunks g, g+4); fp4 uses
+  // ks = 0, 1 with the low 4 registers each (chunk 4*ks+g); the compiler drops what a format
+  // does not touch (the fp4 form of the instruction reads v[0:3] only).
+  i32x8 a[2][4], b0[2][2], b1[2][2];
 
-#define KLM_LOAD32(dst, base)                                                  \
-  do {                                                                         \
-    const i32x4 lo_ = *reinterpret_cast<const i32x4*>((base) + c0);            \
-    const i32x4 hi_ = *reinterpret_cast<const i32x4*>((base) + c1);            \
-    dst = i32x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]}; \
+#define KLM_LOAD_FRAG(dst, base)                                                 \
+  do {                                                                           \
+    const i32x4 lo_ = *reinterpret_cast<const i32x4*>((base) + c0);              \
+    const i32x4 hi_ = *reinterpret_cast<const i32x4*>((base) + c1);              \
+    if (FMT == 0) {                                                              \
+      dst[0] = i32x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]}; \
+    } else {                                                                     \
+      dst[0] = i32x8{lo_[0], lo_[1], lo_[2], lo_[3], 0, 0, 0, 0};                \
+      dst[1] = i32x8{hi_[0], hi_[1], hi_[2], hi_[3], 0, 0, 0, 0};                \
+    }                                                                            \
   } while (0)
-#define KLM_READ_A(slot_base) \
-  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) KLM_LOAD32(a[mi], (slot_base) + a_row + mi * 2048)
-#define KLM_READ_B(bv, slot_base) \
-  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) KLM_LOAD32(bv[ni], (slot_base) + b_row + ni * 2048)
+#define KLM_READ_A(slot_base)                                              \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                       \
+    i32x8 f_[2];                                                           \
+    KLM_LOAD_FRAG(f_, (slot_base) + a_row + mi * 2048);                    \
+    a[0][mi] = f_[0];                                                      \
+    if (FMT != 0) a[1][mi] = f_[1];                                        \
+  }
+#define KLM_READ_B(bv, slot_base)                                          \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                       \
+    i32x8 f_[2];                                                           \
+    KLM_LOAD_FRAG(f_, (slot_base) + b_row + ni * 2048);                    \
+    bv[0][ni] = f_[0];                                                     \
+    if (FMT != 0) bv[1][ni] = f_[1];                                       \
+  }
 #define KLM_MFMA8(ah, bh, bv)                                                            \
   do {                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < (FMT == 0 ? 1 : 2); ++ks)                    \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                     \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                     \
       acc[ah][bh][mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(            \
-          bv[ni], a[mi], acc[ah][bh][mi][ni], 0, 0, 0, KLM_UNIT_SCALE, 0, KLM_UNIT_SCALE); \
+          bv[ks][ni], a[ks][mi], acc[ah][bh][mi][ni], FMT, FMT, 0, KLM_UNIT_SCALE, 0, KLM_UNIT_SCALE); \
     __builtin_amdgcn_s_setprio(0);                                                       \
   } while (0)
 
@@ -218,21 +243,39 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const uint8_t* __restrict__ 
         }
 }
 
-extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int variant,
-                            void* stream) {
-  if (!A || !B || !C) return KLM_ERR_ARG;
-  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
-  if (variant != 0) return KLM_ERR_VARIANT;
-  if (M <= 0 || N <= 0 || K <= 0 || (M & 255) || (N & 255) || (K & 127) || K < 256) return KLM_ERR_SHAPE;
-  static bool attr_set = false;
+template <int FMT>
+static int launch_mx(const void* A, const void* B, void* C, int M, int N, int Kbytes, void* stream) {
+  static bool attr_set = false;          // one flag per instantiation
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_fp8_256, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)gemm_mx_256<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             131072) != hipSuccess)
       return KLM_ERR_HIP;
     attr_set = true;
   }
   const int grid = (M >> 8) * (N >> 8);
-  hipLaunchKernelGGL(gemm_fp8_256, dim3(grid), dim3(512), 131072, (hipStream_t)stream,
-                     (const uint8_t*)A, (const uint8_t*)B, (uint16_t*)C, M, N, K);
+  hipLaunchKernelGGL((gemm_mx_256<FMT>), dim3(grid), dim3(512), 131072, (hipStream_t)stream,
+                     (const uint8_t*)A, (const uint8_t*)B, (uint16_t*)C, M, N, Kbytes);
   return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+}
+
+static int check_mx(const void* A, const void* B, const void* C, int M, int N, int Kbytes, int variant) {
+  if (!A || !B || !C) return KLM_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
+  if (variant != 0) return KLM_ERR_VARIANT;
+  if (M <= 0 || N <= 0 || Kbytes <= 0 || (M & 255) || (N & 255) || (Kbytes & 127) || Kbytes < 256) return KLM_ERR_SHAPE;
+  return KLM_OK;
+}
+
+extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int variant,
+                            void* stream) {
+  if (int e = check_mx(A, B, C, M, N, K, variant)) return e;
+  return launch_mx<0>(A, B, C, M, N, K, stream);
+}
+
+// K counts fp4 ELEMENTS; rows are K/2 bytes, two elements per byte.
+extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
+                            void* stream) {
+  if (K <= 0 || (K & 1)) return KLM_ERR_SHAPE;
+  if (int e = check_mx(A, B, C, M, N, K >> 1, variant)) return e;
+  return launch_mx<4>(A, B, C, M, N, K >> 1, stream);
 }

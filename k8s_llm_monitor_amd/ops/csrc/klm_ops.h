@@ -39,6 +39,13 @@ int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, in
 int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                  void* stream);
 
+// fp4 (e2m1, two elements per byte) GEMM on the same MX MFMA at 4x the bf16 rate, unit scales.
+// A is [M][K/2] bytes, B is [N][K/2] bytes, K counts ELEMENTS. Which nibble of a byte is the
+// "first" element does not matter to the product as long as A and B are packed alike.
+// Requirements: M,N % 256 == 0, K % 256 == 0 and K >= 512.
+int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
+                 void* stream);
+
 // HBM helpers. `bytes` must be a multiple of 16 and pointers 16-byte aligned.
 int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream);   // write-only
 int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stream);    // read+write

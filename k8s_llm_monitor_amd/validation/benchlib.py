@@ -124,13 +124,13 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         try:
             from ..loadgen.burner import Burner
             k = {}
-            for kind in ("gemm_fp8", "hbm_read", "hbm_fill", "hbm_copy"):
+            for kind in ("gemm_fp8", "gemm_fp4", "hbm_read", "hbm_fill", "hbm_copy"):
                 b = Burner(kind, size=size, duty=100.0, device=dev.index or 0)
                 o = b.run(1.0)
                 k[kind] = round(o.get("tflops_busy") or o.get("TBps_busy") or 0.0, 2)
                 del b
             torch.cuda.empty_cache()
-            extras["other_kernels"] = dict(k, units={"gemm_fp8": "TFLOP/s", "hbm_*": "TB/s"})
+            extras["other_kernels"] = dict(k, units={"gemm_*": "TFLOP/s", "hbm_*": "TB/s"})
         except Exception as e:
             extras["other_kernels"] = {"error": f"{type(e).__name__}: {e}"}
 

@@ -71,6 +71,15 @@ def main():
             res[f"tf_torch_fp8_{M}"] = fl / ms / 1e9
         except Exception as e:
             print("torch._scaled_mm unavailable:", type(e).__name__, str(e)[:120], flush=True)
+    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (8192, 8192, 16384)]:
+        a4 = torch.randint(0, 256, (M, K // 2), device=dev, dtype=torch.uint8); b4 = torch.randint(0, 256, (N, K // 2), device=dev, dtype=torch.uint8)
+        c4 = ops.gemm_fp4(a4, b4)
+        ref = ops.fp4_decode(a4[:256]).double() @ ops.fp4_decode(b4).double().t()
+        ok = torch.equal(c4[:256], ref.float().to(torch.bfloat16))
+        fl = 2.0 * M * N * K
+        ms = bench(lambda: ops.gemm_fp4(a4, b4, out=c4))
+        print(f"klm fp4 {M}x{N}x{K}: {ms:.3f} ms {fl/ms/1e9:.1f} TF exact={ok}", flush=True)
+        res[f"tf_fp4_{M}_{K}"] = fl / ms / 1e9; res[f"fp4_exact_{M}_{K}"] = ok
     a8 = (torch.rand(2048, 4096, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
     b8 = (torch.rand(2048, 4096, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
     c0 = ops.gemm_fp8(a8, b8).clone()

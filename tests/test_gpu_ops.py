@@ -85,6 +85,32 @@ def test_gemm_fp8_exact_on_small_integers(env):
     assert torch.equal(c, (a @ b.t()).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 512), (512, 768, 1024), (1024, 512, 8192)])
+def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
+    """e2m1 values are multiples of 0.5 up to 6: products and fp32 sums of a few thousand of them are
+    exact, so the only rounding is the bf16 store."""
+    torch, ops, dev = env
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(K)
+    a = torch.randint(0, 256, (M, K // 2), device=dev, generator=g, dtype=torch.uint8)
+    b = torch.randint(0, 256, (N, K // 2), device=dev, generator=g, dtype=torch.uint8)
+    a[:, 3] = (torch.arange(M, device=dev) % 251).to(torch.uint8)            # position- and row-dependent bytes
+    b[:, K // 2 - 5] = (torch.arange(N, device=dev) % 239).to(torch.uint8)
+    c = ops.gemm_fp4(a, b)
+    ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
+    assert torch.equal(c, ref.float().to(torch.bfloat16))
+    if hasattr(torch, "float4_e2m1fn_x2"):
+        assert torch.equal(ops.gemm_fp4(a.view(torch.float4_e2m1fn_x2), b.view(torch.float4_e2m1fn_x2)), c)
+
+
+def test_fp4_decode_table(env):
+    torch, ops, dev = env
+    codes = torch.arange(256, device=dev, dtype=torch.uint8).reshape(1, 256)
+    v = ops.fp4_decode(codes)[0]
+    assert v.shape == (512,) and v[2 * 0x21].item() == 0.5 and v[2 * 0x21 + 1].item() == 1.0     # low nibble first
+    assert sorted(set(v.abs().tolist())) == [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]
+
+
 def test_shape_and_dtype_errors_are_raised_not_launched(env):
     torch, ops, dev = env
     a = torch.zeros(100, 64, device=dev, dtype=torch.bfloat16)

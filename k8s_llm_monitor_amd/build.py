@@ -58,7 +58,7 @@ def hipcc() -> Optional[str]:
 def targets() -> List[Target]:
     ops = PKG / "ops" / "csrc"
     hdr = ops / "klm_ops.h"
-    ops_src = [ops / "gemm_bf16.hip", ops / "gemm_mx.hip", ops / "hbm.hip"]
+    ops_src = [ops / "gemm_bf16.hip", ops / "gemm_mx.hip", ops / "hbm.hip", ops / "llm.hip"]
     ops_src = [s for s in ops_src if s.exists()]
     out: List[Target] = [
         Target("klm_ops", LIB_DIR / "libklm_ops.so", ops_src, "hip-shared", deps=[hdr]),

@@ -62,6 +62,38 @@ int klm_hbm_checksum(const void* src, size_t bytes, void* sum64, void* stream);
 // traffic and ~0 MFMA work, used to tell "GFX activity" apart from useful work.
 int klm_spin(uint64_t cycles, int blocks, void* stream);
 
+// ---- LLM serving kernels (llm.hip): bf16, head_dim 128, KV blocks of 16 tokens --------------
+// K cache [num_blocks][n_kv][16][128], V cache [num_blocks][n_kv][128][16] (transposed), both
+// bf16 and zero-initialised by the caller (stale slots are read and multiplied by zero).
+//
+// out = rmsnorm(x) * weight; with `residual` != NULL: residual <- x + residual first, and the
+// norm is taken of the new residual. H % 8 == 0, H <= 8192.
+int klm_rmsnorm(const void* x, void* residual, const void* weight, void* out, int T, int H, float eps,
+                void* stream);
+// out[T][F] = silu(gate_up[T][0:F]) * gate_up[T][F:2F]; F % 8 == 0.
+int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream);
+// RoPE (rotate-half) on the q and k heads of qkv[T][n_q + 2 n_kv][128] in place, with
+// cos_sin[max_pos][128] fp32 (64 cos | 64 sin); k and v of token t go to cache slot slots[t]
+// (= block * 16 + offset; a negative slot skips the write).
+int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
+                   void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
+                   void* stream);
+// Decode attention: q (row b at q + b*q_stride elements, n_q heads of 128), block_tables[B][max_blocks],
+// ctx_lens[B] -> out[B][n_q][128]. q_stride lets q be a view of the fused qkv activation.
+// num_splits > 1 splits each context over that many blocks (flash decoding); then
+// tmp_o[B][n_q][num_splits][128] and tmp_ml[B][n_q][num_splits][2] (fp32) are scratch.
+int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                          const int32_t* ctx_lens, void* out, float* tmp_o, float* tmp_ml, int B, int q_stride,
+                          int n_q, int n_kv, int max_blocks, int num_blocks_total, int num_splits, float scale,
+                          void* stream);
+// Causal prefill over the paged cache (the keys of the queries are already in it).
+// seq_info[n_seqs][3] = {q_start, q_len, ctx_len}; tiles[n_tiles][2] = {sequence, first query
+// token of the tile}; a tile covers 64 / (n_q / n_kv) query tokens.
+int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                           const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
+                           int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,
+                           void* stream);
+
 const char* klm_version(void);
 
 #ifdef __cplusplus

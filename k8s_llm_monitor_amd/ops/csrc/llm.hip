@@ -1,0 +1,563 @@
+// LLM serving kernels for MI355X (gfx950, CDNA4): the GPU side of the vLLM-compatible
+// load generator (k8s_llm_monitor_amd/serving), used to validate the dashboard's vLLM panel
+// (TTFT, tokens/s, KV-cache usage) against a server whose ground truth is known.
+//
+// No reference counterpart: vLLM appears in the reference only as a README bullet
+// (README.md:73; SURVEY.md 2.4 N7, BASELINE.json config 4).
+//
+// All tensors are bf16, math is fp32. head_dim is 128, a KV block holds 16 tokens.
+//
+//   K cache  [num_blocks][n_kv][16 tokens][128 dims]   one token row = 256 contiguous bytes
+//   V cache  [num_blocks][n_kv][128 dims][16 tokens]   TRANSPOSED: the 16 tokens of one dim are
+//                                                      32 contiguous bytes
+//
+// The V layout is what makes the attention kernels free of LDS traffic and of cross-lane
+// data movement: with 64-wide waves and v_mfma_f32_16x16x32_bf16 (first operand X: lane
+// holds row lane&15, k = (lane>>4)*8..+8; result D[x_row = (lane>>4)*4+i][y_row = lane&15]):
+//
+//   S^T tile = mfma(X = K tile (16 tokens x 32 dims), Y = Q (16 query rows x 32 dims))
+//       lane (fr, fq) receives, for query row fr, the scores of token rows fq*4+i.
+//       K tile T of a 32-token step holds token (r/4)*8 + T*4 + r%4 in its row r, so the two
+//       tiles together give lane (fr, fq) the scores of the 8 CONSECUTIVE tokens fq*8 .. fq*8+7,
+//   O^T tile = mfma(X = V^T tile (16 dims x 32 tokens), Y = P (16 query rows x 32 tokens))
+//       needs, in lane (fr, fq), P[row fr][tokens fq*8..+8]  -> exactly the registers the
+//       softmax just produced, and V^T[dim fr][tokens fq*8..+8] -> one 16-byte load from the
+//       transposed cache.
+//
+// A query "row" is a (token, head-of-the-GQA-group) pair: one kv head serves G = n_q/n_kv
+// query heads, so a 16-row tile is 16/G tokens x G heads and K/V are read once per group.
+// Decode (one token per sequence) uses G of the 16 rows; the kernel is HBM-bound and the
+// MFMA time is noise (16 MFMAs per 16 KiB of cache read).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "klm_ops.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int HD = 128;               // head dim
+constexpr int BLK = 16;               // tokens per KV block
+constexpr int BLK_ELEMS = HD * BLK;   // elements of one (block, kv head) slab
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ void unpack8(const uint4& a, float* v) {
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  uint4 r;
+  r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  r.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  r.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------
+// RMSNorm (optionally fused with the residual add): one 256-thread block per token, the
+// row stays in registers between the sum of squares and the scaled write (H <= 8192).
+//   RES: residual <- bf16(x + residual); out <- rmsnorm(residual) * w
+//  !RES:                                 out <- rmsnorm(x) * w
+// ------------------------------------------------------------------------------------
+template <bool RES>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict__ x,
+                                                      uint16_t* __restrict__ res,
+                                                      const uint16_t* __restrict__ w,
+                                                      uint16_t* __restrict__ out, int H, float eps) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * H;
+  const int tid = threadIdx.x;
+  float v[4][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int e = (c * 256 + tid) * 8;
+    if (e < H) {
+      const uint4 a = *reinterpret_cast<const uint4*>(x + base + e);
+      unpack8(a, v[c]);
+      if (RES) {
+        const uint4 r = *reinterpret_cast<const uint4*>(res + base + e);
+        float rv[8];
+        unpack8(r, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c][j] = bf2f(f2bf(v[c][j] + rv[j]));
+        *reinterpret_cast<uint4*>(res + base + e) = pack8(v[c]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  ss = red[0] + red[1] + red[2] + red[3];
+  const float inv = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int e = (c * 256 + tid) * 8;
+    if (e < H) {
+      const uint4 wa = *reinterpret_cast<const uint4*>(w + e);
+      float wv[8], o[8];
+      unpack8(wa, wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = v[c][j] * inv * wv[j];
+      *reinterpret_cast<uint4*>(out + base + e) = pack8(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// SwiGLU activation: out[t][f] = silu(gate_up[t][f]) * gate_up[t][F + f].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gu,
+                                                       uint16_t* __restrict__ out, int F8, size_t total) {
+  // F8 = F / 8; `total` = T * F8 vectors of 8
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t t = i / F8, f = i - t * F8;
+    const uint16_t* row = gu + t * (size_t)F8 * 16;
+    const uint4 g = *reinterpret_cast<const uint4*>(row + f * 8);
+    const uint4 u = *reinterpret_cast<const uint4*>(row + (size_t)F8 * 8 + f * 8);
+    float gv[8], uv[8], o[8];
+    unpack8(g, gv);
+    unpack8(u, uv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = gv[j] / (1.f + __expf(-gv[j])) * uv[j];
+    *reinterpret_cast<uint4*>(out + i * 8) = pack8(o);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// RoPE (rotate-half pairing i <-> i+64, cos/sin from a table) on the q and k heads of a fused
+// qkv activation, in place, and the write of k / v into the paged cache. One wave per
+// (token, head).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv,
+                                                         const float* __restrict__ cos_sin,
+                                                         const int* __restrict__ positions,
+                                                         const int* __restrict__ slots,
+                                                         uint16_t* __restrict__ kc,
+                                                         uint16_t* __restrict__ vc, int T, int n_q,
+                                                         int n_kv, int max_pos, int num_slots) {
+  const int lane = threadIdx.x & 63;
+  const int heads = n_q + 2 * n_kv;
+  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= (long)T * heads) return;
+  const int t = (int)(gw / heads), hs = (int)(gw - (long)t * heads);
+  uint16_t* row = qkv + ((size_t)t * heads + hs) * HD;
+  int pos = positions[t];
+  pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+  const int slot = slots[t];
+  const bool cache_ok = slot >= 0 && slot < num_slots;
+  const uint16_t r1 = row[lane], r2 = row[lane + 64];
+  if (hs < n_q + n_kv) {
+    const float x1 = bf2f(r1), x2 = bf2f(r2);
+    const float c = cos_sin[(size_t)pos * HD + lane], s = cos_sin[(size_t)pos * HD + 64 + lane];
+    const uint16_t b1 = f2bf(x1 * c - x2 * s), b2 = f2bf(x2 * c + x1 * s);
+    row[lane] = b1;
+    row[lane + 64] = b2;
+    if (hs >= n_q && cache_ok) {
+      uint16_t* dst = kc + ((size_t)(slot / BLK) * n_kv + (hs - n_q)) * BLK_ELEMS + (slot % BLK) * HD;
+      dst[lane] = b1;
+      dst[lane + 64] = b2;
+    }
+  } else if (cache_ok) {
+    uint16_t* dst = vc + ((size_t)(slot / BLK) * n_kv + (hs - n_q - n_kv)) * BLK_ELEMS + (slot % BLK);
+    dst[lane * BLK] = r1;
+    dst[(lane + 64) * BLK] = r2;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Attention over the paged cache.
+// ------------------------------------------------------------------------------------
+struct KvView {
+  const uint16_t* kc;   // K cache + kv head offset
+  const uint16_t* vc;   // V cache + kv head offset
+  const int* bt;        // block table row of this sequence
+  size_t blk_stride;    // n_kv * BLK_ELEMS
+  int last_blk;         // index (in the table) of the last block that holds a token
+  int nb_total;         // blocks in the cache (ids are clamped to it)
+};
+
+struct Frags {
+  bf16x8 k[2][4];
+  bf16x8 v[8];
+};
+
+__device__ __forceinline__ void load_step(const KvView& kv, int step, int fr, int fq, Frags& f) {
+  int i0 = step * 2, i1 = step * 2 + 1;
+  i0 = i0 > kv.last_blk ? kv.last_blk : i0;
+  i1 = i1 > kv.last_blk ? kv.last_blk : i1;
+  int b0 = kv.bt[i0], b1 = kv.bt[i1];
+  b0 = b0 < 0 ? 0 : (b0 >= kv.nb_total ? kv.nb_total - 1 : b0);
+  b1 = b1 < 0 ? 0 : (b1 >= kv.nb_total ? kv.nb_total - 1 : b1);
+  const uint16_t* kp = kv.kc + (size_t)((fr >> 3) ? b1 : b0) * kv.blk_stride +
+                       ((((fr >> 2) & 1) << 3) + (fr & 3)) * HD + fq * 8;
+  const uint16_t* vp = kv.vc + (size_t)((fq >> 1) ? b1 : b0) * kv.blk_stride + fr * BLK + (fq & 1) * 8;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      f.k[t][s] = *reinterpret_cast<const bf16x8*>(kp + t * 4 * HD + s * 32);
+#pragma unroll
+  for (int n = 0; n < 8; ++n) f.v[n] = *reinterpret_cast<const bf16x8*>(vp + n * 16 * BLK);
+}
+
+struct Acc {
+  f32x4 o[8];
+  float m, l;
+};
+
+// One 32-token step of online softmax attention for the wave's 16 query rows.
+// qpos: position of this lane's query row (-1 = row not in use); keys at positions <= qpos count.
+__device__ __forceinline__ void attend_step(const Frags& f, const bf16x8 (&qf)[4], int step, int fq,
+                                            int qpos, float scale_log2, Acc& a) {
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.k[0][s], qf[s], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.k[1][s], qf[s], s1, 0, 0, 0);
+  }
+  const int tk0 = step * 32 + fq * 8;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    x[j] = (tk0 + j <= qpos) ? s0[j] * scale_log2 : -INFINITY;
+    x[j + 4] = (tk0 + 4 + j <= qpos) ? s1[j] * scale_log2 : -INFINITY;
+  }
+  float mx = x[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) mx = fmaxf(mx, x[j]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float m_new = fmaxf(a.m, mx);
+  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+  const float alpha = fast_exp2(a.m - m_use);
+  bf16x8 p;
+  float rs = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 pb = (__bf16)fast_exp2(x[j] - m_use);
+    p[j] = pb;
+    rs += (float)pb;
+  }
+  rs += __shfl_xor(rs, 16);
+  rs += __shfl_xor(rs, 32);
+  a.l = a.l * alpha + rs;
+  a.m = m_new;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    a.o[n] *= alpha;
+    a.o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[n], p, a.o[n], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void load_q(const uint16_t* qrow, bool valid, int fq, bf16x8 (&qf)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (valid) {
+      qf[s] = *reinterpret_cast<const bf16x8*>(qrow + s * 32 + fq * 8);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)0.f;
+    }
+  }
+}
+
+// Runs steps st0, st0+stride, ... < st_end with the loads of the next step in flight.
+__device__ __forceinline__ void attend_range(const KvView& kv, const bf16x8 (&qf)[4], int st0, int st_end,
+                                             int stride, int fr, int fq, int qpos, float scale_log2,
+                                             Acc& a) {
+  if (st0 >= st_end) return;
+  Frags cur;
+  load_step(kv, st0, fr, fq, cur);
+  for (int st = st0; st < st_end; st += stride) {
+    Frags nxt;
+    const int nx = st + stride;
+    load_step(kv, nx < st_end ? nx : st, fr, fq, nxt);   // last iteration re-reads (cached), unused
+    attend_step(cur, qf, st, fq, qpos, scale_log2, a);
+    cur = nxt;
+  }
+}
+
+constexpr int OPAD = HD + 4;
+
+// Decode: one token per sequence. Block = (kv head, sequence, split); its 4 waves take the
+// 32-token steps of the split round-robin and are combined through LDS.
+__global__ __launch_bounds__(256) void paged_attn_decode_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+    const int* __restrict__ block_tables, const int* __restrict__ ctx_lens, uint16_t* __restrict__ out,
+    float* __restrict__ tmp_o, float* __restrict__ tmp_ml, int q_stride, int n_q, int n_kv, int G,
+    int max_blocks, int nb_total, int num_splits, float scale_log2) {
+  __shared__ float sm_o[4][16][OPAD];
+  __shared__ float sm_m[4][16], sm_l[4][16];
+  const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  int ctx = ctx_lens[b];
+  ctx = ctx < 0 ? 0 : (ctx > max_blocks * BLK ? max_blocks * BLK : ctx);
+  const int total_steps = (ctx + 31) >> 5;
+  const int sps = (total_steps + num_splits - 1) / num_splits;
+  const int s_begin = split * sps;
+  const int s_end = (s_begin + sps) < total_steps ? (s_begin + sps) : total_steps;
+
+  KvView kv;
+  kv.kc = kc + (size_t)h * BLK_ELEMS;
+  kv.vc = vc + (size_t)h * BLK_ELEMS;
+  kv.bt = block_tables + (size_t)b * max_blocks;
+  kv.blk_stride = (size_t)n_kv * BLK_ELEMS;
+  kv.last_blk = ctx > 0 ? (ctx - 1) / BLK : 0;
+  kv.nb_total = nb_total;
+
+  const bool valid = fr < G;
+  bf16x8 qf[4];
+  load_q(q + (size_t)b * q_stride + ((size_t)h * G + (valid ? fr : 0)) * HD, valid, fq, qf);
+  const int qpos = valid ? ctx - 1 : -1;
+
+  Acc a;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) a.o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  a.m = -INFINITY;
+  a.l = 0.f;
+  attend_range(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, scale_log2, a);
+
+#pragma unroll
+  for (int n = 0; n < 8; ++n) *reinterpret_cast<f32x4*>(&sm_o[w][fr][n * 16 + fq * 4]) = a.o[n];
+  if (fq == 0) {
+    sm_m[w][fr] = a.m;
+    sm_l[w][fr] = a.l;
+  }
+  __syncthreads();
+
+  const int row = tid >> 4, d0 = (tid & 15) * 8;
+  if (row < G) {
+    float mt = fmaxf(fmaxf(sm_m[0][row], sm_m[1][row]), fmaxf(sm_m[2][row], sm_m[3][row]));
+    const float mu = (mt == -INFINITY) ? 0.f : mt;
+    float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const float wgt = fast_exp2(sm_m[ww][row] - mu);
+      L += sm_l[ww][row] * wgt;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += sm_o[ww][row][d0 + j] * wgt;
+    }
+    const size_t head = (size_t)b * n_q + (size_t)h * G + row;
+    if (num_splits == 1) {
+      const float inv = L > 0.f ? 1.f / L : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] *= inv;
+      *reinterpret_cast<uint4*>(out + head * HD + d0) = pack8(o);
+    } else {
+      float* po = tmp_o + (head * num_splits + split) * HD + d0;
+      *reinterpret_cast<f32x4*>(po) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(po + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      if ((tid & 15) == 0) {
+        tmp_ml[(head * num_splits + split) * 2] = mt;
+        tmp_ml[(head * num_splits + split) * 2 + 1] = L;
+      }
+    }
+  }
+}
+
+// Merges the partial results of the splits: one 128-thread block per (sequence, query head).
+__global__ __launch_bounds__(128) void paged_attn_reduce_kernel(const float* __restrict__ tmp_o,
+                                                                const float* __restrict__ tmp_ml,
+                                                                uint16_t* __restrict__ out, int num_splits) {
+  const size_t head = blockIdx.x;
+  const int d = threadIdx.x;
+  float mt = -INFINITY;
+  for (int s = 0; s < num_splits; ++s) mt = fmaxf(mt, tmp_ml[(head * num_splits + s) * 2]);
+  const float mu = (mt == -INFINITY) ? 0.f : mt;
+  float L = 0.f, o = 0.f;
+  for (int s = 0; s < num_splits; ++s) {
+    const float wgt = fast_exp2(tmp_ml[(head * num_splits + s) * 2] - mu);
+    L += tmp_ml[(head * num_splits + s) * 2 + 1] * wgt;
+    o += tmp_o[(head * num_splits + s) * HD + d] * wgt;
+  }
+  out[head * HD + d] = f2bf(L > 0.f ? o / L : 0.f);
+}
+
+// Prefill / chunked prefill: the queries are the LAST q_len tokens of a context of ctx_len
+// tokens that is already in the cache (rope_cache runs first). Block = (tile, kv head); a tile
+// is 4 waves x 16/G consecutive query tokens of one sequence; each wave walks the keys up to
+// its own causal limit, so there is no cross-wave exchange.
+//   seq_info[s] = {q_start (row of the first query in q/out), q_len, ctx_len}
+//   tiles[t]    = {sequence, first query token of the tile (0-based inside the sequence's queries)}
+__global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+    const int* __restrict__ block_tables, const int* __restrict__ seq_info, const int* __restrict__ tiles,
+    uint16_t* __restrict__ out, int n_seqs, int q_stride, int n_q, int n_kv, int G, int g_shift,
+    int max_blocks, int nb_total, float scale_log2) {
+  const int tile = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  int seq = tiles[tile * 2];
+  seq = seq < 0 ? 0 : (seq >= n_seqs ? n_seqs - 1 : seq);
+  const int tok0 = tiles[tile * 2 + 1];
+  const int q_start = seq_info[seq * 3], q_len = seq_info[seq * 3 + 1];
+  int ctx = seq_info[seq * 3 + 2];
+  ctx = ctx < 0 ? 0 : (ctx > max_blocks * BLK ? max_blocks * BLK : ctx);
+  const int tpw = 16 >> g_shift;                    // query tokens per wave
+  const int wtok0 = tok0 + w * tpw;
+  if (tok0 < 0 || wtok0 >= q_len || q_len > ctx) return;   // wave-uniform
+
+  KvView kv;
+  kv.kc = kc + (size_t)h * BLK_ELEMS;
+  kv.vc = vc + (size_t)h * BLK_ELEMS;
+  kv.bt = block_tables + (size_t)seq * max_blocks;
+  kv.blk_stride = (size_t)n_kv * BLK_ELEMS;
+  kv.last_blk = ctx > 0 ? (ctx - 1) / BLK : 0;
+  kv.nb_total = nb_total;
+
+  const int tq = wtok0 + (fr >> g_shift);
+  const bool valid = tq < q_len;
+  const size_t qrow = (size_t)(q_start + (valid ? tq : wtok0));
+  const size_t qhead = (size_t)h * G + (fr & (G - 1));
+  bf16x8 qf[4];
+  load_q(q + qrow * q_stride + qhead * HD, valid, fq, qf);
+  const int qpos = valid ? ctx - q_len + tq : -1;
+  int last_tq = wtok0 + tpw - 1;
+  last_tq = last_tq < q_len ? last_tq : q_len - 1;
+  const int n_steps = ((ctx - q_len + last_tq) >> 5) + 1;
+
+  Acc a;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) a.o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  a.m = -INFINITY;
+  a.l = 0.f;
+  attend_range(kv, qf, 0, n_steps, 1, fr, fq, qpos, scale_log2, a);
+
+  if (valid) {
+    const float inv = a.l > 0.f ? 1.f / a.l : 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      bf16x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (__bf16)(a.o[n][i] * inv);
+      *reinterpret_cast<bf16x4*>(out + (qrow * n_q + qhead) * HD + n * 16 + fq * 4) = o;
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int group_shift(int G) {
+  switch (G) {
+    case 1: return 0;
+    case 2: return 1;
+    case 4: return 2;
+    case 8: return 3;
+    case 16: return 4;
+    default: return -1;
+  }
+}
+inline int launch_status() { return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP; }
+
+}  // namespace
+
+extern "C" {
+
+int klm_rmsnorm(const void* x, void* residual, const void* weight, void* out, int T, int H, float eps,
+                void* stream) {
+  if (T <= 0 || H <= 0 || H % 8 != 0 || H > 8192) return KLM_ERR_SHAPE;
+  if (!x || !weight || !out) return KLM_ERR_ARG;
+  if (!aligned16(x) || !aligned16(weight) || !aligned16(out) || !aligned16(residual)) return KLM_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (residual)
+    hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(T), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)residual,
+                       (const uint16_t*)weight, (uint16_t*)out, H, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(T), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)nullptr,
+                       (const uint16_t*)weight, (uint16_t*)out, H, eps);
+  return launch_status();
+}
+
+int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream) {
+  if (T <= 0 || F <= 0 || F % 8 != 0) return KLM_ERR_SHAPE;
+  if (!gate_up || !out) return KLM_ERR_ARG;
+  if (!aligned16(gate_up) || !aligned16(out)) return KLM_ERR_ALIGN;
+  const size_t total = (size_t)T * (F / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const uint16_t*)gate_up, (uint16_t*)out, F / 8, total);
+  return launch_status();
+}
+
+int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
+                   void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
+                   void* stream) {
+  if (T <= 0 || n_q <= 0 || n_kv <= 0 || max_pos <= 0 || num_slots <= 0 || num_slots > INT32_MAX)
+    return KLM_ERR_SHAPE;
+  if (!qkv || !cos_sin || !positions || !slots || !k_cache || !v_cache) return KLM_ERR_ARG;
+  const long waves = (long)T * (n_q + 2 * n_kv);
+  const long blocks = (waves + 3) / 4;
+  if (blocks > INT32_MAX) return KLM_ERR_SHAPE;
+  hipLaunchKernelGGL(rope_cache_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (uint16_t*)qkv, cos_sin, positions, slots, (uint16_t*)k_cache, (uint16_t*)v_cache, T, n_q,
+                     n_kv, max_pos, (int)num_slots);
+  return launch_status();
+}
+
+int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                          const int32_t* ctx_lens, void* out, float* tmp_o, float* tmp_ml, int B, int q_stride,
+                          int n_q, int n_kv, int max_blocks, int num_blocks_total, int num_splits, float scale,
+                          void* stream) {
+  if (q_stride < n_q * HD || q_stride % 8 != 0) return KLM_ERR_SHAPE;
+  if (B <= 0 || B > 65535 || n_q <= 0 || n_kv <= 0 || n_q % n_kv != 0 || max_blocks <= 0 || num_blocks_total <= 0)
+    return KLM_ERR_SHAPE;
+  const int G = n_q / n_kv;
+  if (group_shift(G) < 0) return KLM_ERR_SHAPE;
+  if (num_splits < 1 || num_splits > 256) return KLM_ERR_ARG;
+  if (!q || !k_cache || !v_cache || !block_tables || !ctx_lens || !out) return KLM_ERR_ARG;
+  if (num_splits > 1 && (!tmp_o || !tmp_ml)) return KLM_ERR_ARG;
+  if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out) || !aligned16(tmp_o))
+    return KLM_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float scale_log2 = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(paged_attn_decode_kernel, dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
+                     (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, ctx_lens, (uint16_t*)out,
+                     tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2);
+  if (hipGetLastError() != hipSuccess) return KLM_ERR_HIP;
+  if (num_splits > 1)
+    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)B * n_q), dim3(128), 0, s, tmp_o, tmp_ml,
+                       (uint16_t*)out, num_splits);
+  return launch_status();
+}
+
+int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
+                           const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
+                           int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,
+                           void* stream) {
+  if (q_stride < n_q * HD || q_stride % 8 != 0) return KLM_ERR_SHAPE;
+  if (n_tiles <= 0 || n_seqs <= 0 || n_q <= 0 || n_kv <= 0 || n_kv > 65535 || n_q % n_kv != 0 ||
+      max_blocks <= 0 || num_blocks_total <= 0)
+    return KLM_ERR_SHAPE;
+  const int G = n_q / n_kv, gs = group_shift(G);
+  if (gs < 0) return KLM_ERR_SHAPE;
+  if (!q || !k_cache || !v_cache || !block_tables || !seq_info || !tiles || !out) return KLM_ERR_ARG;
+  if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) return KLM_ERR_ALIGN;
+  const float scale_log2 = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(paged_attn_prefill_kernel, dim3(n_tiles, n_kv), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const uint16_t*)q, (const uint16_t*)k_cache,
+                     (const uint16_t*)v_cache, block_tables, seq_info, tiles, (uint16_t*)out, n_seqs, q_stride, n_q, n_kv, G,
+                     gs, max_blocks, num_blocks_total, scale_log2);
+  return launch_status();
+}
+
+}  // extern "C"

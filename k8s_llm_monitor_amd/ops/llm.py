@@ -1,0 +1,223 @@
+"""LLM serving ops: RMSNorm, SwiGLU, RoPE + paged-cache write, paged attention (decode, prefill).
+
+On a GPU every call runs the hand-written gfx950 kernel of ``csrc/llm.hip`` (ctypes, current
+torch stream, no allocation inside the launcher, so the calls can be captured into a hipGraph);
+a missing library is an error there. On CPU tensors the fp32 reference of ``ops.ref`` runs, which
+is what lets the serving engine be tested without a GPU.
+
+No reference counterpart (vLLM is a README bullet in the reference, README.md:73).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import KlmOpsError, _check, _stream, load
+from . import ref
+
+HEAD_DIM = ref.HEAD_DIM
+BLOCK = ref.BLOCK
+rope_table = ref.rope_table
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = load()
+    if not _bound:
+        vp, i, f, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+        if not hasattr(lib, "klm_paged_attn_decode"):
+            raise KlmOpsError("libklm_ops.so was built without llm.hip: run `python -m k8s_llm_monitor_amd.build --force`")
+        lib.klm_rmsnorm.argtypes = [vp, vp, vp, vp, i, i, f, vp]
+        lib.klm_silu_mul.argtypes = [vp, vp, i, i, vp]
+        lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, vp]
+        lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
+        lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
+        for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill"):
+            getattr(lib, n).restype = i
+        _bound = True
+    return lib
+
+
+def _bf16(*ts) -> None:
+    for t in ts:
+        if t.dtype != torch.bfloat16:
+            raise KlmOpsError("llm ops need bfloat16 tensors")
+
+
+def _i32(*ts) -> None:
+    for t in ts:
+        if t.dtype != torch.int32 or not t.is_contiguous() or not t.is_cuda:
+            raise KlmOpsError("index tensors must be contiguous int32 on the GPU")
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5,
+            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out = rmsnorm(x) * weight``; with `residual`: ``residual += x`` in place first and the
+    norm is taken of the sum (the fused add of every transformer sub-layer)."""
+    if not x.is_cuda:
+        o, r = ref.rmsnorm(x, weight, eps, residual)
+        if residual is not None:
+            residual.copy_(r)
+        if out is not None:
+            out.copy_(o)
+            return out
+        return o
+    _bf16(x, weight)
+    if x.dim() != 2 or not x.is_contiguous() or weight.shape != (x.shape[1],):
+        raise KlmOpsError(f"rmsnorm: x {tuple(x.shape)} / weight {tuple(weight.shape)}")
+    if residual is not None and (residual.shape != x.shape or not residual.is_contiguous() or residual.dtype != x.dtype):
+        raise KlmOpsError("rmsnorm: residual must match x")
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or not out.is_contiguous() or out.dtype != x.dtype:
+        raise KlmOpsError("rmsnorm: bad out")
+    T, H = x.shape
+    rc = _lib().klm_rmsnorm(x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                            weight.data_ptr(), out.data_ptr(), T, H, float(eps), _stream(x))
+    _check(rc, f"klm_rmsnorm(T={T},H={H})")
+    return out
+
+
+def silu_mul(gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``silu(gate_up[:, :F]) * gate_up[:, F:]``."""
+    if not gate_up.is_cuda:
+        return ref.silu_mul(gate_up)
+    _bf16(gate_up)
+    if gate_up.dim() != 2 or not gate_up.is_contiguous() or gate_up.shape[1] % 16:
+        raise KlmOpsError(f"silu_mul: gate_up {tuple(gate_up.shape)}")
+    T, F2 = gate_up.shape
+    if out is None:
+        out = torch.empty((T, F2 // 2), dtype=gate_up.dtype, device=gate_up.device)
+    _check(_lib().klm_silu_mul(gate_up.data_ptr(), out.data_ptr(), T, F2 // 2, _stream(gate_up)), "klm_silu_mul")
+    return out
+
+
+def _check_caches(k_cache: torch.Tensor, v_cache: torch.Tensor, n_kv: int) -> int:
+    nb = k_cache.shape[0]
+    if tuple(k_cache.shape) != (nb, n_kv, BLOCK, HEAD_DIM) or tuple(v_cache.shape) != (nb, n_kv, HEAD_DIM, BLOCK):
+        raise KlmOpsError(f"cache shapes: K {tuple(k_cache.shape)} V {tuple(v_cache.shape)} for n_kv={n_kv}")
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()):
+        raise KlmOpsError("caches must be contiguous")
+    return nb
+
+
+def rope_cache(qkv: torch.Tensor, cos_sin: torch.Tensor, positions: torch.Tensor, slots: torch.Tensor,
+               k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int) -> torch.Tensor:
+    """RoPE on q and k of the fused qkv activation (in place) and k/v -> cache slot ``slots[t]``."""
+    T = qkv.shape[0]
+    nb = _check_caches(k_cache, v_cache, n_kv)
+    if qkv.dim() != 2 or qkv.shape[1] != (n_q + 2 * n_kv) * HEAD_DIM or not qkv.is_contiguous():
+        raise KlmOpsError(f"rope_cache: qkv {tuple(qkv.shape)}")
+    if positions.shape != (T,) or slots.shape != (T,):
+        raise KlmOpsError("rope_cache: positions / slots must be [T]")
+    if cos_sin.dim() != 2 or cos_sin.shape[1] != HEAD_DIM or cos_sin.dtype != torch.float32 or not cos_sin.is_contiguous():
+        raise KlmOpsError("rope_cache: cos_sin must be fp32 [max_pos, 128]")
+    if not qkv.is_cuda:
+        r = ref.rope(qkv, cos_sin, positions, n_q, n_kv)
+        qkv.copy_(r)
+        ref.cache_write(qkv, slots, k_cache, v_cache, n_q, n_kv)
+        return qkv
+    _bf16(qkv, k_cache, v_cache)
+    _i32(positions, slots)
+    rc = _lib().klm_rope_cache(qkv.data_ptr(), cos_sin.data_ptr(), positions.data_ptr(), slots.data_ptr(),
+                               k_cache.data_ptr(), v_cache.data_ptr(), T, n_q, n_kv, cos_sin.shape[0],
+                               nb * BLOCK, _stream(qkv))
+    _check(rc, f"klm_rope_cache(T={T})")
+    return qkv
+
+
+def pick_splits(batch: int, n_kv: int, max_ctx: int, target_blocks: int = 1024) -> int:
+    """Flash-decoding split count: enough blocks to fill 256 CUs, at least 4 steps of 32 tokens each."""
+    by_fill = -(-target_blocks // max(1, batch * n_kv))
+    by_len = max(1, max_ctx // 128)
+    return int(max(1, min(by_fill, by_len, 64)))
+
+
+class DecodeWorkspace:
+    """Scratch of the split reduction, allocated once (hipGraph capture needs stable pointers)."""
+
+    def __init__(self, max_batch: int, n_q: int, max_splits: int, device):
+        self.max_batch, self.n_q, self.max_splits = max_batch, n_q, max_splits
+        self.tmp_o = torch.empty((max_batch, n_q, max_splits, HEAD_DIM), dtype=torch.float32, device=device)
+        self.tmp_ml = torch.empty((max_batch, n_q, max_splits, 2), dtype=torch.float32, device=device)
+
+
+def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
+                      ctx_lens: torch.Tensor, scale: float, n_q: int, out: Optional[torch.Tensor] = None,
+                      num_splits: int = 1, workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+    """One query token per sequence. `q` is [B, >= n_q*128] with unit inner stride (a view of the
+    fused qkv activation is fine); returns [B, n_q*128]."""
+    B = block_tables.shape[0]
+    n_kv = k_cache.shape[1]
+    nb = _check_caches(k_cache, v_cache, n_kv)
+    if q.dim() != 2 or q.shape[0] != B or q.shape[1] < n_q * HEAD_DIM or q.stride(1) != 1:
+        raise KlmOpsError(f"paged_attn_decode: q {tuple(q.shape)} strides {q.stride()}")
+    if ctx_lens.shape != (B,):
+        raise KlmOpsError("paged_attn_decode: ctx_lens must be [B]")
+    if not q.is_cuda:
+        o = ref.paged_attn_decode(q[:, : n_q * HEAD_DIM], k_cache, v_cache, block_tables, ctx_lens, scale)
+        if out is not None:
+            out.copy_(o)
+            return out
+        return o
+    _bf16(q, k_cache, v_cache)
+    _i32(block_tables, ctx_lens)
+    if out is None:
+        out = torch.empty((B, n_q * HEAD_DIM), dtype=q.dtype, device=q.device)
+    elif tuple(out.shape) != (B, n_q * HEAD_DIM) or not out.is_contiguous():
+        raise KlmOpsError("paged_attn_decode: bad out")
+    tmp_o = tmp_ml = None
+    if num_splits > 1:
+        if workspace is None:
+            workspace = DecodeWorkspace(B, n_q, num_splits, q.device)
+        if workspace.max_batch < B or workspace.n_q != n_q or workspace.max_splits < num_splits:
+            raise KlmOpsError("paged_attn_decode: workspace too small")
+        tmp_o, tmp_ml = workspace.tmp_o.data_ptr(), workspace.tmp_ml.data_ptr()
+    rc = _lib().klm_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
+                                      ctx_lens.data_ptr(), out.data_ptr(), tmp_o, tmp_ml, B, q.stride(0), n_q, n_kv,
+                                      block_tables.shape[1], nb, int(num_splits), float(scale), _stream(q))
+    _check(rc, f"klm_paged_attn_decode(B={B},splits={num_splits})")
+    return out
+
+
+def prefill_tiles(q_lens: Sequence[int], group: int) -> torch.Tensor:
+    """Host-side tile table of the prefill kernel: int32 [n_tiles, 2] = (sequence, first query token);
+    one tile = 64 / group query tokens."""
+    per = 64 // group
+    rows: List[Tuple[int, int]] = []
+    for s, n in enumerate(q_lens):
+        rows.extend((s, t) for t in range(0, int(n), per))
+    return torch.tensor(rows, dtype=torch.int32).reshape(-1, 2)
+
+
+def paged_attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
+                       seq_info: torch.Tensor, tiles: torch.Tensor, scale: float, n_q: int,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal attention of the last ``q_len`` tokens of each sequence over its paged context.
+    q [T, >= n_q*128]; seq_info int32 [S, 3] = (q_start, q_len, ctx_len); tiles from prefill_tiles()."""
+    n_kv = k_cache.shape[1]
+    nb = _check_caches(k_cache, v_cache, n_kv)
+    S = seq_info.shape[0]
+    if q.dim() != 2 or q.shape[1] < n_q * HEAD_DIM or q.stride(1) != 1:
+        raise KlmOpsError(f"paged_attn_prefill: q {tuple(q.shape)}")
+    if seq_info.shape != (S, 3) or block_tables.shape[0] != S or tiles.dim() != 2 or tiles.shape[1] != 2:
+        raise KlmOpsError("paged_attn_prefill: seq_info [S,3], block_tables [S,*], tiles [n,2]")
+    if not q.is_cuda:
+        o = ref.paged_attn_prefill(q[:, : n_q * HEAD_DIM], k_cache, v_cache, block_tables, seq_info, scale)
+        if out is not None:
+            out.copy_(o)
+            return out
+        return o
+    _bf16(q, k_cache, v_cache)
+    _i32(block_tables, seq_info, tiles)
+    if out is None:
+        out = torch.zeros((q.shape[0], n_q * HEAD_DIM), dtype=q.dtype, device=q.device)
+    rc = _lib().klm_paged_attn_prefill(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
+                                       seq_info.data_ptr(), tiles.data_ptr(), out.data_ptr(), tiles.shape[0], S,
+                                       q.stride(0), n_q, n_kv, block_tables.shape[1], nb, float(scale), _stream(q))
+    _check(rc, f"klm_paged_attn_prefill(tiles={tiles.shape[0]})")
+    return out

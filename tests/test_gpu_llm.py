@@ -1,0 +1,151 @@
+"""Numerics of the LLM serving kernels (ops/csrc/llm.hip) against the fp32 PyTorch references of
+ops/ref.py on the same inputs. GPU only; the CPU dispatch of the same functions is covered by
+tests/test_llm_cpu.py."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from k8s_llm_monitor_amd.ops import llm, ref  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rand(*shape, scale=1.0):
+    return (torch.randn(*shape, device=DEV) * scale).to(torch.bfloat16)
+
+
+def _close(a, b, atol, rtol=2e-2):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    assert bool((err <= bound).all()), f"max err {err.max().item():.4g} (at |ref| {b.abs().flatten()[err.argmax()].item():.4g})"
+
+
+@pytest.mark.parametrize("T,H", [(37, 4096), (3, 256), (130, 8192)])
+def test_rmsnorm_matches_reference(T, H):
+    torch.manual_seed(1)
+    x, w = _rand(T, H), _rand(H)
+    o = llm.rmsnorm(x, w, 1e-5)
+    r, _ = ref.rmsnorm(x, w, 1e-5)
+    _close(o, r, 2e-2)
+    res = _rand(T, H)
+    res0 = res.clone()
+    o2 = llm.rmsnorm(x, w, 1e-5, residual=res)
+    r2, nr = ref.rmsnorm(x, w, 1e-5, residual=res0)
+    assert torch.equal(res, nr)                       # the residual update is exact (one bf16 rounding)
+    _close(o2, r2, 2e-2)
+
+
+def test_silu_mul_matches_reference():
+    torch.manual_seed(2)
+    gu = _rand(33, 2 * 14336, scale=2.0)
+    _close(llm.silu_mul(gu), ref.silu_mul(gu), 1e-2)
+
+
+def _caches(nb, n_kv, fill=True):
+    if fill:   # random everywhere: stale slots hold finite garbage, which the kernels must mask
+        return _rand(nb, n_kv, 16, 128), _rand(nb, n_kv, 128, 16)
+    z = torch.zeros
+    return z(nb, n_kv, 16, 128, device=DEV, dtype=torch.bfloat16), z(nb, n_kv, 128, 16, device=DEV, dtype=torch.bfloat16)
+
+
+def test_rope_and_cache_write_match_reference():
+    torch.manual_seed(3)
+    T, n_q, n_kv, nb = 50, 32, 8, 40
+    qkv = _rand(T, (n_q + 2 * n_kv) * 128)
+    cs = llm.rope_table(4096, 500000.0, DEV)
+    pos = torch.randint(0, 4096, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(nb * 16, device=DEV)[:T].to(torch.int32)
+    slots[7] = -1                                       # padding row: no cache write
+    kc, vc = _caches(nb, n_kv, fill=False)
+    kr, vr = kc.clone(), vc.clone()
+    want = ref.rope(qkv, cs, pos, n_q, n_kv)
+    ref.cache_write(want, slots, kr, vr, n_q, n_kv)
+    got = qkv.clone()
+    llm.rope_cache(got, cs, pos, slots, kc, vc, n_q, n_kv)
+    _close(got, want, 1e-2, 1e-2)
+    _close(kc, kr, 1e-2, 1e-2)
+    assert torch.equal(vc, vr)                          # v is copied, bit for bit
+    assert float(kc.float().abs().sum()) > 0
+
+
+def _tables(ctx_lens, nb, max_blocks):
+    perm = torch.randperm(nb)
+    bt = torch.full((len(ctx_lens), max_blocks), -7, dtype=torch.int32)   # unused entries hold junk ids
+    at = 0
+    for i, c in enumerate(ctx_lens):
+        n = (c + 15) // 16
+        bt[i, :n] = perm[at:at + n].to(torch.int32)
+        at += n
+    return bt.to(DEV)
+
+
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (4, 4), (16, 2), (16, 1)])
+@pytest.mark.parametrize("splits", [1, 4, 0])
+def test_paged_decode_attention_matches_reference(n_q, n_kv, splits):
+    torch.manual_seed(4)
+    ctx = [1, 15, 16, 17, 33, 700, 129, 0]
+    nb, mb = 80, 48
+    kc, vc = _caches(nb, n_kv)
+    bt = _tables(ctx, nb, mb)
+    cl = torch.tensor(ctx, dtype=torch.int32, device=DEV)
+    B = len(ctx)
+    qkv = _rand(B, (n_q + 2 * n_kv) * 128)
+    q = qkv[:, : n_q * 128]                              # strided view, as the model passes it
+    scale = 1.0 / math.sqrt(128)
+    ns = splits or llm.pick_splits(B, n_kv, mb * 16)
+    got = llm.paged_attn_decode(q, kc, vc, bt, cl, scale, n_q, num_splits=ns)
+    want = ref.paged_attn_decode(q, kc, vc, bt, cl, scale)
+    _close(got, want, 2e-2)
+    assert float(got[-1].float().abs().sum()) == 0.0     # ctx 0 -> zeros
+
+
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (2, 2), (8, 1)])
+def test_paged_prefill_attention_matches_reference(n_q, n_kv):
+    torch.manual_seed(5)
+    # (q_len, ctx_len): fresh prompts, and chunks whose earlier context is already cached
+    seqs = [(5, 5), (64, 64), (100, 100), (17, 300), (1, 40), (33, 64)]
+    nb, mb = 60, 24
+    kc, vc = _caches(nb, n_kv)
+    bt = _tables([c for _, c in seqs], nb, mb)
+    T = sum(q for q, _ in seqs)
+    info, at = [], 0
+    for ql, c in seqs:
+        info.append((at, ql, c))
+        at += ql
+    seq_info = torch.tensor(info, dtype=torch.int32, device=DEV)
+    tiles = llm.prefill_tiles([q for q, _ in seqs], n_q // n_kv).to(DEV)
+    qkv = _rand(T, (n_q + 2 * n_kv) * 128)
+    q = qkv[:, : n_q * 128]
+    scale = 1.0 / math.sqrt(128)
+    got = llm.paged_attn_prefill(q, kc, vc, bt, seq_info, tiles, scale, n_q)
+    want = ref.paged_attn_prefill(q, kc, vc, bt, seq_info, scale)
+    _close(got, want, 2e-2)
+
+
+def test_decode_attention_can_be_captured_in_a_hip_graph():
+    torch.manual_seed(6)
+    n_q, n_kv, nb, mb, B = 32, 8, 64, 16, 4
+    kc, vc = _caches(nb, n_kv)
+    bt = _tables([200, 50, 256, 3], nb, mb)
+    cl = torch.tensor([200, 50, 256, 3], dtype=torch.int32, device=DEV)
+    q = _rand(B, n_q * 128)
+    out = torch.empty_like(q)
+    ws = llm.DecodeWorkspace(B, n_q, 8, DEV)
+    scale = 1.0 / math.sqrt(128)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        llm.paged_attn_decode(q, kc, vc, bt, cl, scale, n_q, out=out, num_splits=8, workspace=ws)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        llm.paged_attn_decode(q, kc, vc, bt, cl, scale, n_q, out=out, num_splits=8, workspace=ws)
+    q.copy_(_rand(B, n_q * 128))
+    cl.copy_(torch.tensor([100, 50, 256, 1], dtype=torch.int32, device=DEV))
+    g.replay()
+    torch.cuda.synchronize()
+    _close(out, ref.paged_attn_decode(q, kc, vc, bt, cl, scale), 2e-2)

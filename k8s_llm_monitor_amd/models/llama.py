@@ -1,0 +1,189 @@
+"""Llama-3 family decoder on the hand-written gfx950 kernels (random-initialised weights).
+
+BASELINE.json config 4 names "vLLM-ROCm Llama-3-8B pod"; there is no vLLM, no checkpoint and no
+network in the build environment, so the serving workload whose metrics the monitor scrapes is
+this model of the same architecture with random weights of the same shapes: the GPU work per
+token (weight bytes streamed, KV bytes read, FLOPs) is that of the real model, which is what a
+telemetry check needs. No reference counterpart (vLLM is a README bullet, reference README.md:73).
+
+MI355X-first choices:
+  * 288 GB of HBM3E: 8B (16 GB) and 70B (141 GB) both fit ONE GPU in bf16, so replicas scale as
+    one process per GPU (data parallel serving) and no tensor-parallel all-reduce sits on the
+    token path; the KV cache gets the rest of the HBM.
+  * attention, RMSNorm(+residual), RoPE+cache write and SwiGLU are the kernels of ops/csrc/llm.hip;
+    the projections are plain library GEMMs (hipBLASLt through torch.matmul), fused where the
+    operands allow it (one qkv GEMM, one gate_up GEMM).
+  * decode is launch-bound at small batch (about 10 launches x layers), so the engine captures it
+    in a hipGraph per batch bucket (serving/engine.py); everything here is capture-safe: no
+    host synchronisation and no shape-dependent Python branching inside ``decode``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from ..ops import llm
+
+HEAD_DIM = llm.HEAD_DIM
+BLOCK = llm.BLOCK
+
+
+@dataclass(frozen=True)
+class LlamaConfig:
+    name: str
+    vocab: int
+    hidden: int
+    layers: int
+    n_q: int
+    n_kv: int
+    ffn: int
+    rope_theta: float = 500000.0
+    eps: float = 1e-5
+    max_pos: int = 8192
+
+    @property
+    def q_dim(self) -> int:
+        return self.n_q * HEAD_DIM
+
+    @property
+    def qkv_dim(self) -> int:
+        return (self.n_q + 2 * self.n_kv) * HEAD_DIM
+
+    def params(self) -> int:
+        per_layer = self.hidden * self.qkv_dim + self.q_dim * self.hidden + 3 * self.hidden * self.ffn + 2 * self.hidden
+        return self.layers * per_layer + 2 * self.vocab * self.hidden + self.hidden
+
+    def kv_bytes_per_token(self) -> int:
+        return self.layers * 2 * self.n_kv * HEAD_DIM * 2
+
+    def flops_per_token(self, ctx: int = 0) -> float:
+        """Forward FLOPs of one token (GEMMs + attention over `ctx` keys), embedding lookup excluded."""
+        gemm = 2.0 * (self.params() - self.vocab * self.hidden)
+        attn = 4.0 * self.layers * self.n_q * HEAD_DIM * ctx
+        return gemm + attn
+
+
+PRESETS: Dict[str, LlamaConfig] = {
+    "llama3-8b": LlamaConfig("llama3-8b", vocab=128256, hidden=4096, layers=32, n_q=32, n_kv=8, ffn=14336),
+    "llama3-70b": LlamaConfig("llama3-70b", vocab=128256, hidden=8192, layers=80, n_q=64, n_kv=8, ffn=28672),
+    # same block structure, sized for CPU tests and smoke runs
+    "tiny": LlamaConfig("tiny", vocab=512, hidden=256, layers=2, n_q=4, n_kv=2, ffn=512, max_pos=1024),
+    "small": LlamaConfig("small", vocab=32000, hidden=2048, layers=4, n_q=16, n_kv=4, ffn=8192, max_pos=8192),
+}
+
+
+class KVCache:
+    """Paged cache of every layer: K [L, blocks, n_kv, 16, 128], V [L, blocks, n_kv, 128, 16]; zero
+    initialised (the attention kernels read stale slots and multiply them by zero)."""
+
+    def __init__(self, cfg: LlamaConfig, num_blocks: int, device, dtype=torch.bfloat16):
+        self.num_blocks = int(num_blocks)
+        self.k = torch.zeros((cfg.layers, num_blocks, cfg.n_kv, BLOCK, HEAD_DIM), dtype=dtype, device=device)
+        self.v = torch.zeros((cfg.layers, num_blocks, cfg.n_kv, HEAD_DIM, BLOCK), dtype=dtype, device=device)
+
+    @staticmethod
+    def bytes_per_block(cfg: LlamaConfig) -> int:
+        return cfg.kv_bytes_per_token() * BLOCK
+
+    @property
+    def nbytes(self) -> int:
+        return self.k.numel() * self.k.element_size() * 2
+
+
+@dataclass
+class DecodeMeta:
+    block_tables: torch.Tensor          # int32 [B, max_blocks]
+    ctx_lens: torch.Tensor              # int32 [B]  (context length INCLUDING the token being decoded)
+    num_splits: int = 1
+    workspace: Optional[llm.DecodeWorkspace] = None
+
+
+@dataclass
+class PrefillMeta:
+    block_tables: torch.Tensor          # int32 [S, max_blocks]
+    seq_info: torch.Tensor              # int32 [S, 3] = (q_start, q_len, ctx_len)
+    tiles: torch.Tensor                 # int32 [n_tiles, 2]
+    last_rows: torch.Tensor             # int64 [S]: row of each sequence's last token
+
+
+class LlamaModel:
+    def __init__(self, cfg: LlamaConfig, device="cuda", seed: int = 0, dtype=torch.bfloat16):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+
+        def w(*shape, std=0.02):
+            return torch.empty(shape, dtype=dtype, device=self.device).normal_(0.0, std, generator=g)
+
+        def ones(n):
+            return torch.ones(n, dtype=dtype, device=self.device)
+
+        self.embed = w(cfg.vocab, cfg.hidden)
+        self.lm_head = w(cfg.vocab, cfg.hidden)
+        self.final_norm = ones(cfg.hidden)
+        out_std = 0.02 / math.sqrt(2 * cfg.layers)
+        self.layers: List[Dict[str, torch.Tensor]] = []
+        for _ in range(cfg.layers):
+            self.layers.append({
+                "norm1": ones(cfg.hidden), "norm2": ones(cfg.hidden),
+                "wqkv": w(cfg.qkv_dim, cfg.hidden),
+                "wo": w(cfg.hidden, cfg.q_dim, std=out_std),
+                "w_gate_up": w(2 * cfg.ffn, cfg.hidden),
+                "w_down": w(cfg.hidden, cfg.ffn, std=out_std),
+            })
+        self.cos_sin = llm.rope_table(cfg.max_pos, cfg.rope_theta, self.device)
+        self.scale = 1.0 / math.sqrt(HEAD_DIM)
+
+    def weight_bytes(self) -> int:
+        n = self.embed.numel() + self.lm_head.numel() + self.final_norm.numel()
+        for L in self.layers:
+            n += sum(t.numel() for t in L.values())
+        return n * 2
+
+    def new_cache(self, num_blocks: int) -> KVCache:
+        return KVCache(self.cfg, num_blocks, self.device, self.dtype)
+
+    # ------------------------------------------------------------------ the decoder stack
+    def _stack(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
+        cfg = self.cfg
+        h = self.embed[tokens]                                   # [T, hidden]
+        residual = None
+        for li, L in enumerate(self.layers):
+            if residual is None:
+                residual = h
+                x = llm.rmsnorm(h, L["norm1"], cfg.eps)
+            else:
+                x = llm.rmsnorm(h, L["norm1"], cfg.eps, residual=residual)
+            qkv = torch.matmul(x, L["wqkv"].t())
+            llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
+            a = attend(qkv, cache.k[li], cache.v[li])
+            h = torch.matmul(a, L["wo"].t())
+            x = llm.rmsnorm(h, L["norm2"], cfg.eps, residual=residual)
+            act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
+            h = torch.matmul(act, L["w_down"].t())
+        return llm.rmsnorm(h, self.final_norm, cfg.eps, residual=residual)
+
+    def decode(self, tokens, positions, slots, cache: KVCache, meta: DecodeMeta) -> torch.Tensor:
+        """One token per sequence -> greedy next token ids [B] (int64). Capture-safe."""
+        cfg = self.cfg
+
+        def attend(qkv, kc, vc):
+            return llm.paged_attn_decode(qkv, kc, vc, meta.block_tables, meta.ctx_lens, self.scale, cfg.n_q,
+                                         num_splits=meta.num_splits, workspace=meta.workspace)
+
+        x = self._stack(tokens, positions, slots, cache, attend)
+        return torch.matmul(x, self.lm_head.t()).argmax(dim=-1)
+
+    def prefill(self, tokens, positions, slots, cache: KVCache, meta: PrefillMeta) -> torch.Tensor:
+        """Variable-length batch of prompts (or prompt chunks) -> next token id of each sequence [S]."""
+        cfg = self.cfg
+
+        def attend(qkv, kc, vc):
+            return llm.paged_attn_prefill(qkv, kc, vc, meta.block_tables, meta.seq_info, meta.tiles, self.scale,
+                                          cfg.n_q)
+
+        x = self._stack(tokens, positions, slots, cache, attend)
+        return torch.matmul(x[meta.last_rows], self.lm_head.t()).argmax(dim=-1)

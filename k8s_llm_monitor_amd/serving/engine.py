@@ -1,0 +1,400 @@
+"""Continuous-batching LLM engine on one MI355X: paged KV cache, iteration-level scheduling,
+prefill-first admission, recompute preemption, hipGraph decode.
+
+This is the "vLLM-ROCm pod" of BASELINE.json config 4 as a self-contained load generator: it
+serves a Llama-3 architecture model with random weights (models/llama.py), exposes vLLM's
+metric names (serving/metrics.py) and knows its own ground truth, so the monitor's vLLM panel
+can be validated on hardware without vLLM, a checkpoint or a network. No reference counterpart
+(the reference only mentions vLLM, README.md:73).
+
+Scheduling (one `step()` = one model launch):
+  1. while requests wait and blocks / sequence slots / the token budget allow: admit them and
+     run ONE variable-length prefill batch; each admitted request gets its first token (TTFT);
+  2. otherwise decode one token for every running sequence. A sequence that needs a new block
+     when none is free preempts the most recently admitted sequence (its blocks are freed, it
+     re-enters the queue at the front and is recomputed from prompt + generated tokens).
+Decode runs from a hipGraph captured per batch-size bucket (launch-bound otherwise: ~10 kernel
+launches per layer); the graph's inputs are static device buffers that each step refills.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Callable, Deque, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..models.llama import BLOCK, PRESETS, DecodeMeta, KVCache, LlamaConfig, LlamaModel, PrefillMeta
+from ..ops import llm
+from .metrics import EngineMetrics
+
+
+@dataclass
+class EngineConfig:
+    model: str = "llama3-8b"
+    device: str = "cuda"
+    max_num_seqs: int = 256
+    max_model_len: int = 4096
+    max_num_batched_tokens: int = 8192
+    kv_blocks: int = 0                 # 0: size the cache from kv_fraction of the free HBM
+    kv_fraction: float = 0.5
+    use_graphs: bool = True
+    seed: int = 0
+
+
+class BlockAllocator:
+    def __init__(self, num_blocks: int):
+        self.total = int(num_blocks)
+        self._free: List[int] = list(range(num_blocks - 1, -1, -1))
+
+    @property
+    def free(self) -> int:
+        return len(self._free)
+
+    @property
+    def usage(self) -> float:
+        return 1.0 - len(self._free) / self.total if self.total else 0.0
+
+    def alloc(self, n: int) -> List[int]:
+        if n > len(self._free):
+            raise MemoryError(f"{n} blocks wanted, {len(self._free)} free")
+        out = self._free[-n:] if n else []
+        del self._free[len(self._free) - n:]
+        return out
+
+    def release(self, blocks: Sequence[int]) -> None:
+        self._free.extend(blocks)
+
+
+@dataclass
+class Request:
+    rid: int
+    prompt: List[int]
+    max_tokens: int
+    arrival: float
+    out: List[int] = field(default_factory=list)
+    blocks: List[int] = field(default_factory=list)
+    t_first: Optional[float] = None
+    t_last: Optional[float] = None
+    t_done: Optional[float] = None
+    preempted: int = 0
+    error: Optional[str] = None
+    done: threading.Event = field(default_factory=threading.Event)
+
+    @property
+    def n_tokens(self) -> int:
+        return len(self.prompt) + len(self.out)
+
+    @property
+    def ttft(self) -> Optional[float]:
+        return None if self.t_first is None else self.t_first - self.arrival
+
+
+def _buckets(limit: int) -> List[int]:
+    out, b = [], 1
+    while b < limit:
+        out.append(b)
+        b *= 2
+    out.append(limit)
+    return out
+
+
+class Engine:
+    def __init__(self, cfg: Optional[EngineConfig] = None, model: Optional[LlamaModel] = None,
+                 clock: Callable[[], float] = time.monotonic):
+        self.cfg = cfg or EngineConfig()
+        self.clock = clock
+        mcfg: LlamaConfig = model.cfg if model is not None else PRESETS[self.cfg.model]
+        self.device = torch.device(self.cfg.device)
+        self.on_gpu = self.device.type == "cuda"
+        self.max_len = min(self.cfg.max_model_len, mcfg.max_pos)
+        self.model = model or LlamaModel(mcfg, self.device, seed=self.cfg.seed)
+        self.mcfg = mcfg
+        self.max_blocks = -(-self.max_len // BLOCK)
+        nblocks = self.cfg.kv_blocks or self._auto_blocks()
+        self.cache: KVCache = self.model.new_cache(nblocks)
+        self.alloc = BlockAllocator(nblocks)
+        self.metrics = EngineMetrics(mcfg.name, clock=clock)
+        self.waiting: Deque[Request] = deque()
+        self.running: List[Request] = []
+        self._lock = threading.Lock()
+        self._next_id = 0
+        self._wake = threading.Event()
+        self._thread: Optional[threading.Thread] = None
+        self._stop = threading.Event()
+        self.step_seconds = {"prefill": 0.0, "decode": 0.0}
+        self.step_counts = {"prefill": 0, "decode": 0}
+        # decode: static device inputs (graph capture needs stable pointers) + pinned host mirrors
+        B = self.cfg.max_num_seqs
+        self.buckets = _buckets(B)
+        dev = self.device
+        self._d_tokens = torch.zeros(B, dtype=torch.int64, device=dev)
+        self._d_i32 = torch.zeros((3, B), dtype=torch.int32, device=dev)      # positions, slots, ctx lens
+        self._d_i32[1].fill_(-1)
+        self._d_pos, self._d_slots, self._d_ctx = self._d_i32[0], self._d_i32[1], self._d_i32[2]
+        self._d_bt = torch.zeros((B, self.max_blocks), dtype=torch.int32, device=dev)
+        self._d_next = torch.zeros(B, dtype=torch.int64, device=dev)
+
+        def host(*shape, dtype):
+            t = torch.zeros(shape, dtype=dtype)
+            return t.pin_memory() if self.on_gpu else t
+
+        self._h_tokens_t = host(B, dtype=torch.int64)
+        self._h_i32_t = host(3, B, dtype=torch.int32)
+        self._h_bt_t = host(B, self.max_blocks, dtype=torch.int32)
+        self._h_tokens, self._h_i32, self._h_bt = (self._h_tokens_t.numpy(), self._h_i32_t.numpy(),
+                                                   self._h_bt_t.numpy())
+        self._graphs: Dict[int, object] = {}
+        self._workspace = llm.DecodeWorkspace(B, mcfg.n_q, 64, dev) if self.on_gpu else None
+
+    # ------------------------------------------------------------------ sizing
+    def _auto_blocks(self) -> int:
+        per_block = KVCache.bytes_per_block(self.mcfg)
+        if self.on_gpu:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            n = int(free * self.cfg.kv_fraction) // per_block
+        else:
+            n = 256
+        return max(n, self.max_blocks + 1)
+
+    @property
+    def kv_capacity_tokens(self) -> int:
+        return self.alloc.total * BLOCK
+
+    # ------------------------------------------------------------------ submission
+    def submit(self, prompt: Sequence[int], max_tokens: int = 16) -> Request:
+        now = self.clock()
+        with self._lock:
+            r = Request(self._next_id, [int(t) % self.mcfg.vocab for t in prompt], int(max_tokens), now)
+            self._next_id += 1
+            if not r.prompt or r.max_tokens < 1 or len(r.prompt) + 1 > self.max_len or \
+                    -(-(len(r.prompt) + 1) // BLOCK) > self.alloc.total:
+                r.error = "prompt empty or longer than max_model_len"
+                r.t_done = now
+                r.done.set()
+                self.metrics.on_reject()
+                return r
+            r.max_tokens = min(r.max_tokens, self.max_len - len(r.prompt),
+                               self.alloc.total * BLOCK - len(r.prompt))
+            self.waiting.append(r)
+            self.metrics.set_queue(len(self.running), len(self.waiting), self.alloc.usage)
+        self._wake.set()
+        return r
+
+    def idle(self) -> bool:
+        with self._lock:
+            return not self.waiting and not self.running
+
+    # ------------------------------------------------------------------ one iteration
+    def step(self) -> int:
+        """Run one model launch; returns the number of tokens it produced (0 = nothing to do)."""
+        batch: List[Request] = []
+        with self._lock:
+            tokens = 0
+            while self.waiting and len(self.running) + len(batch) < self.cfg.max_num_seqs:
+                r = self.waiting[0]
+                n = r.n_tokens
+                need = -(-(n + 1) // BLOCK)
+                if batch and tokens + n > self.cfg.max_num_batched_tokens:
+                    break
+                if need > self.alloc.free:
+                    break
+                r.blocks = self.alloc.alloc(need)
+                self.waiting.popleft()
+                batch.append(r)
+                tokens += n
+        if batch:
+            return self._prefill(batch)
+        if self.running:
+            return self._decode()
+        return 0
+
+    def _finish(self, r: Request, now: float) -> None:
+        r.t_done = now
+        self.alloc.release(r.blocks)
+        r.blocks = []
+        self.metrics.on_finish(now - r.arrival)
+        r.done.set()
+
+    def _prefill(self, batch: List[Request]) -> int:
+        t0 = self.clock()
+        toks: List[int] = []
+        pos: List[int] = []
+        slots: List[int] = []
+        info, last_rows = [], []
+        bt = np.zeros((len(batch), self.max_blocks), dtype=np.int32)
+        for i, r in enumerate(batch):
+            seq = r.prompt + r.out
+            n = len(seq)
+            info.append((len(toks), n, n))
+            toks.extend(seq)
+            pos.extend(range(n))
+            blk = np.asarray(r.blocks, dtype=np.int64)
+            idx = np.arange(n)
+            slots.extend((blk[idx // BLOCK] * BLOCK + idx % BLOCK).tolist())
+            bt[i, :len(r.blocks)] = r.blocks
+            last_rows.append(len(toks) - 1)
+        dev = self.device
+        meta = PrefillMeta(
+            block_tables=torch.from_numpy(bt).to(dev),
+            seq_info=torch.tensor(info, dtype=torch.int32, device=dev),
+            tiles=llm.prefill_tiles([n for (_, n, _) in info], self.mcfg.n_q // self.mcfg.n_kv).to(dev),
+            last_rows=torch.tensor(last_rows, dtype=torch.int64, device=dev))
+        nxt = self.model.prefill(torch.tensor(toks, dtype=torch.int64, device=dev),
+                                 torch.tensor(pos, dtype=torch.int32, device=dev),
+                                 torch.tensor(slots, dtype=torch.int32, device=dev), self.cache, meta)
+        nxt = nxt.tolist()                      # synchronises
+        now = self.clock()
+        new_prompt = 0
+        with self._lock:
+            for r, t in zip(batch, nxt):
+                if r.t_first is None:
+                    r.t_first = now
+                    self.metrics.on_first_token(now - r.arrival)
+                    new_prompt += len(r.prompt)
+                else:
+                    self.metrics.on_token_gap(now - (r.t_last or now))
+                r.out.append(int(t))
+                r.t_last = now
+                if len(r.out) >= r.max_tokens:
+                    self._finish(r, now)
+                else:
+                    self.running.append(r)
+            self.metrics.on_step(len(batch), new_prompt, len(self.running), len(self.waiting), self.alloc.usage)
+        self.step_seconds["prefill"] += now - t0
+        self.step_counts["prefill"] += 1
+        return len(batch)
+
+    def _make_room(self) -> None:
+        """Give every running sequence the block its next token needs, preempting from the back."""
+        i = 0
+        while i < len(self.running):
+            r = self.running[i]
+            need = -(-r.n_tokens // BLOCK)
+            if len(r.blocks) >= need:
+                i += 1
+                continue
+            if self.alloc.free == 0:
+                victim = self.running.pop()          # most recently admitted
+                self.alloc.release(victim.blocks)
+                victim.blocks = []
+                victim.preempted += 1
+                self.waiting.appendleft(victim)
+                self.metrics.on_preempt()
+                if victim is r:
+                    break
+                continue
+            r.blocks.extend(self.alloc.alloc(1))
+            i += 1
+
+    def _decode(self) -> int:
+        t0 = self.clock()
+        with self._lock:
+            self._make_room()
+            seqs = list(self.running)
+        n = len(seqs)
+        if n == 0:
+            return 0
+        b = next(x for x in self.buckets if x >= n)
+        ht, hv, hb = self._h_tokens, self._h_i32, self._h_bt
+        ht[:b] = 0
+        hv[:, :b] = 0
+        hv[1, :b] = -1                                    # padded rows write no cache slot
+        for i, r in enumerate(seqs):
+            nt = r.n_tokens
+            ht[i] = r.out[-1]
+            hv[0, i] = nt - 1
+            hv[1, i] = r.blocks[(nt - 1) // BLOCK] * BLOCK + (nt - 1) % BLOCK
+            hv[2, i] = nt
+            hb[i, :len(r.blocks)] = r.blocks
+        # the pinned host buffers are not touched again before the .tolist() below has synchronised
+        self._d_tokens[:b].copy_(self._h_tokens_t[:b], non_blocking=True)
+        self._d_i32.copy_(self._h_i32_t, non_blocking=True)
+        self._d_bt[:b].copy_(self._h_bt_t[:b], non_blocking=True)
+        self._run_decode(b)
+        nxt = self._d_next[:n].tolist()         # synchronises
+        now = self.clock()
+        with self._lock:
+            still: List[Request] = []
+            for r, t in zip(seqs, nxt):
+                self.metrics.on_token_gap(now - (r.t_last or now))
+                r.out.append(int(t))
+                r.t_last = now
+                if len(r.out) >= r.max_tokens or r.n_tokens >= self.max_len:
+                    self._finish(r, now)
+                else:
+                    still.append(r)
+            self.running = still
+            self.metrics.on_step(n, 0, len(self.running), len(self.waiting), self.alloc.usage)
+        self.step_seconds["decode"] += now - t0
+        self.step_counts["decode"] += 1
+        return n
+
+    def _decode_call(self, b: int) -> None:
+        meta = DecodeMeta(self._d_bt[:b], self._d_ctx[:b],
+                          num_splits=llm.pick_splits(b, self.mcfg.n_kv, self.max_len) if self.on_gpu else 1,
+                          workspace=self._workspace)
+        out = self.model.decode(self._d_tokens[:b], self._d_pos[:b], self._d_slots[:b], self.cache, meta)
+        self._d_next[:b].copy_(out)
+
+    def _run_decode(self, b: int) -> None:
+        if not (self.on_gpu and self.cfg.use_graphs):
+            self._decode_call(b)
+            return
+        g = self._graphs.get(b)
+        if g is None:
+            # warm up on a side stream (library handles, allocator pools), then capture
+            s = torch.cuda.Stream(self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                self._decode_call(b)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_call(b)
+            self._graphs[b] = g
+        g.replay()
+
+    def warmup(self, buckets: Optional[Sequence[int]] = None) -> None:
+        """Capture the decode graphs ahead of traffic (padded rows only: no cache slot is written)."""
+        if not (self.on_gpu and self.cfg.use_graphs):
+            return
+        self._d_i32.zero_()
+        self._d_i32[1].fill_(-1)
+        for b in (buckets or self.buckets):
+            self._run_decode(b)
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ background loop
+    def start(self) -> "Engine":
+        if self._thread is None:
+            self._stop.clear()
+            self._thread = threading.Thread(target=self._loop, name="klm-llm-engine", daemon=True)
+            self._thread.start()
+        return self
+
+    def _loop(self) -> None:
+        if self.on_gpu:
+            torch.cuda.set_device(self.device)
+        while not self._stop.is_set():
+            if self.step() == 0:
+                self._wake.wait(0.05)
+                self._wake.clear()
+
+    def stop(self) -> None:
+        self._stop.set()
+        self._wake.set()
+        if self._thread is not None:
+            self._thread.join(timeout=30)
+            self._thread = None
+
+    def describe(self) -> Dict[str, object]:
+        return {"model": self.mcfg.name, "params": self.mcfg.params(), "weight_bytes": self.model.weight_bytes(),
+                "kv_blocks": self.alloc.total, "kv_capacity_tokens": self.kv_capacity_tokens,
+                "kv_bytes": self.cache.nbytes, "max_num_seqs": self.cfg.max_num_seqs, "max_model_len": self.max_len,
+                "graphs": sorted(self._graphs), "device": str(self.device),
+                "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts)}

@@ -1,0 +1,217 @@
+"""The Llama decoder and the serving engine on CPU (tiny model, fp32): the paged, batched,
+preempting engine must generate exactly the tokens of a dense full-recompute forward, and its
+vLLM-named metrics must be readable by the monitor's scraper (collectors/vllm.py)."""
+import json
+import math
+import urllib.request
+
+import pytest
+import torch
+
+from k8s_llm_monitor_amd.collectors.vllm import VllmDirectSource, parse_exposition
+from k8s_llm_monitor_amd.models.llama import PRESETS, LlamaConfig, LlamaModel
+from k8s_llm_monitor_amd.ops import llm, ref
+from k8s_llm_monitor_amd.serving import BlockAllocator, Engine, EngineConfig, exact_quantile
+from k8s_llm_monitor_amd.serving.loadclient import OpenLoopLoad
+from k8s_llm_monitor_amd.serving.server import LlmServer
+
+TINY = PRESETS["tiny"]
+
+
+@pytest.fixture(scope="module")
+def model():
+    torch.manual_seed(0)
+    return LlamaModel(TINY, "cpu", seed=1, dtype=torch.float32)
+
+
+def dense_next(model, seq):
+    """Full-sequence forward without a cache, written independently of the paged path."""
+    cfg = model.cfg
+    T = len(seq)
+    h = model.embed[torch.tensor(seq)]
+    pos = torch.arange(T)
+    for L in model.layers:
+        x = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + cfg.eps) * L["norm1"]
+        qkv = ref.rope(x @ L["wqkv"].t(), model.cos_sin, pos, cfg.n_q, cfg.n_kv).view(T, -1, 128)
+        q, k, v = qkv[:, :cfg.n_q], qkv[:, cfg.n_q:cfg.n_q + cfg.n_kv], qkv[:, cfg.n_q + cfg.n_kv:]
+        g = cfg.n_q // cfg.n_kv
+        k, v = k.repeat_interleave(g, 1), v.repeat_interleave(g, 1)
+        s = torch.einsum("thd,chd->htc", q, k) / math.sqrt(128)
+        s = s.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1)[None], float("-inf"))
+        a = torch.einsum("htc,chd->thd", torch.softmax(s, -1), v).reshape(T, -1)
+        h = h + a @ L["wo"].t()
+        x = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + cfg.eps) * L["norm2"]
+        gu = x @ L["w_gate_up"].t()
+        h = h + (torch.nn.functional.silu(gu[:, :cfg.ffn]) * gu[:, cfg.ffn:]) @ L["w_down"].t()
+    x = h[-1] * torch.rsqrt(h[-1].pow(2).mean(-1, keepdim=True) + cfg.eps) * model.final_norm
+    return int((x @ model.lm_head.t()).argmax())
+
+
+def dense_generate(model, prompt, n):
+    seq = list(prompt)
+    for _ in range(n):
+        seq.append(dense_next(model, seq))
+    return seq[len(prompt):]
+
+
+def _engine(model, **kw):
+    cfg = EngineConfig(model="tiny", device="cpu", max_num_seqs=kw.pop("max_num_seqs", 8),
+                       max_model_len=kw.pop("max_model_len", 256), kv_blocks=kw.pop("kv_blocks", 64),
+                       max_num_batched_tokens=kw.pop("max_num_batched_tokens", 512), use_graphs=False)
+    return Engine(cfg, model=model)
+
+
+def _drain(eng, limit=2000):
+    n = 0
+    while not eng.idle():
+        eng.step()
+        n += 1
+        assert n < limit, "engine did not drain"
+    return n
+
+
+def test_presets_have_the_published_shapes():
+    c = PRESETS["llama3-8b"]
+    assert (c.hidden, c.layers, c.n_q, c.n_kv, c.ffn, c.vocab) == (4096, 32, 32, 8, 14336, 128256)
+    assert abs(c.params() / 1e9 - 8.03) < 0.01                      # Llama-3-8B: 8.03 B parameters
+    assert c.kv_bytes_per_token() == 131072                          # 128 KiB of KV per token in bf16
+    assert abs(PRESETS["llama3-70b"].params() / 1e9 - 70.55) < 0.05
+
+
+def test_block_allocator():
+    a = BlockAllocator(4)
+    x = a.alloc(3)
+    assert len(set(x)) == 3 and a.free == 1 and a.usage == 0.75
+    with pytest.raises(MemoryError):
+        a.alloc(2)
+    a.release(x)
+    assert a.free == 4 and a.usage == 0.0
+
+
+def test_single_request_matches_the_dense_forward(model):
+    eng = _engine(model)
+    prompt = [5, 17, 300, 2, 9, 44, 101]
+    r = eng.submit(prompt, 12)
+    _drain(eng)
+    assert r.done.is_set() and r.error is None
+    assert r.out == dense_generate(model, prompt, 12)
+    assert eng.alloc.free == eng.alloc.total                         # every block came back
+
+
+def test_batched_requests_of_mixed_length_match_the_dense_forward(model):
+    eng = _engine(model)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, TINY.vocab, (n,), generator=g).tolist() for n in (1, 15, 16, 17, 40, 3)]
+    reqs = [eng.submit(p, m) for p, m in zip(prompts, (5, 9, 1, 20, 7, 33))]
+    _drain(eng)
+    for p, r in zip(prompts, reqs):
+        assert r.out == dense_generate(model, p, r.max_tokens), f"request {r.rid}"
+    t = eng.metrics.truth()
+    assert t["totals"]["generation_tokens"] == sum(len(r.out) for r in reqs)
+    assert t["totals"]["prompt_tokens"] == sum(len(p) for p in prompts)
+    assert t["totals"]["finished"] == len(reqs)
+
+
+def test_late_arrivals_join_the_running_batch(model):
+    eng = _engine(model)
+    a = eng.submit([1, 2, 3, 4, 5], 10)
+    for _ in range(4):
+        eng.step()
+    b = eng.submit([9, 8, 7], 6)                                      # arrives while `a` decodes
+    _drain(eng)
+    assert a.out == dense_generate(model, [1, 2, 3, 4, 5], 10)
+    assert b.out == dense_generate(model, [9, 8, 7], 6)
+
+
+def test_preemption_recomputes_and_still_matches(model):
+    # 6 blocks = 96 token slots for three requests that grow to 3 x 40 tokens: someone must be preempted
+    eng = _engine(model, kv_blocks=6, max_model_len=64)
+    prompts = [[3] * 10, [4] * 10, [5] * 10]
+    reqs = [eng.submit(p, 30) for p in prompts]
+    _drain(eng)
+    assert eng.metrics.preemptions >= 1 and sum(r.preempted for r in reqs) >= 1
+    for p, r in zip(prompts, reqs):
+        assert r.out == dense_generate(model, p, 30)
+    assert eng.alloc.free == eng.alloc.total
+
+
+def test_oversized_and_empty_prompts_are_rejected(model):
+    eng = _engine(model, max_model_len=32)
+    assert eng.submit([], 4).error
+    assert eng.submit([1] * 32, 4).error
+    ok = eng.submit([1] * 31, 100)
+    assert ok.error is None and ok.max_tokens == 1                    # clipped to the model length
+    _drain(eng)
+    assert len(ok.out) == 1 and eng.metrics.rejected == 2
+
+
+def test_metrics_text_is_what_the_monitor_scrapes(model):
+    t = [100.0]
+    eng = Engine(EngineConfig(model="tiny", device="cpu", max_num_seqs=4, max_model_len=128, kv_blocks=32,
+                              use_graphs=False), model=model, clock=lambda: t[0])
+    src = VllmDirectSource(["fake://engine/metrics"], fetch=lambda _u: eng.metrics.render(), clock=lambda: t[0])
+    s0 = src.sample()
+    assert s0["available"] and s0["running"] == 0 and s0["models"] == ["tiny"]
+    reqs = [eng.submit([7] * 20, 40) for _ in range(3)]
+    for _ in range(11):                                                # 1 prefill + 10 decode steps, 0.1 s each
+        t[0] += 0.1
+        eng.step()
+    s1 = src.sample()
+    assert s1["running"] == 3 and s1["waiting"] == 0
+    assert s1["kvCachePercent"] == pytest.approx(eng.alloc.usage * 100)
+    # 3 first tokens + 30 decoded tokens in 1.1 s
+    assert s1["tokensPerSec"] == pytest.approx(33 / 1.1, rel=1e-6)
+    assert s1["promptTokensPerSec"] == pytest.approx(60 / 1.1, rel=1e-6)
+    assert 0.08 <= s1["ttftP50"] <= 0.1                                # exact 0.1, bucket (0.08, 0.1]
+    truth = eng.metrics.truth()
+    assert truth["ttft_p50"] == pytest.approx(0.1) and truth["itl_p50"] == pytest.approx(0.1)
+    names = {n for (n, _, _) in parse_exposition(eng.metrics.render())}
+    for want in ("vllm:num_requests_running", "vllm:num_requests_waiting", "vllm:kv_cache_usage_perc",
+                 "vllm:gpu_cache_usage_perc", "vllm:generation_tokens_total", "vllm:prompt_tokens_total",
+                 "vllm:time_to_first_token_seconds_bucket", "vllm:e2e_request_latency_seconds_bucket",
+                 "vllm:inter_token_latency_seconds_bucket", "vllm:num_preemptions_total"):
+        assert want in names, want
+    del reqs
+
+
+def test_http_server_and_open_loop_load(model):
+    eng = _engine(model).start()
+    try:
+        with LlmServer(eng) as srv:
+            body = json.dumps({"prompt": [1, 2, 3], "max_tokens": 5}).encode()
+            req = urllib.request.Request(srv.url + "/v1/completions", data=body, headers={"Content-Type": "application/json"})
+            out = json.load(urllib.request.urlopen(req, timeout=30))
+            assert out["choices"][0]["token_ids"] == dense_generate(model, [1, 2, 3], 5)
+            assert out["usage"] == {"prompt_tokens": 3, "completion_tokens": 5, "total_tokens": 8}
+            req = urllib.request.Request(srv.url + "/v1/completions", data=b'{"max_tokens": 2}')
+            with pytest.raises(urllib.error.HTTPError) as e:
+                urllib.request.urlopen(req, timeout=30)
+            assert e.value.code == 400
+            load = OpenLoopLoad(eng, rate_rps=50, prompt_len=12, output_len=6, seed=1).start(0.4)
+            load.join(5)
+            assert load.wait_all(60) and len(load.requests) >= 3
+            text = urllib.request.urlopen(srv.url + "/metrics", timeout=5).read().decode()
+            assert 'vllm:generation_tokens_total{model_name="tiny"}' in text
+            st = json.load(urllib.request.urlopen(srv.url + "/stats?window=60", timeout=5))
+            assert st["truth"]["totals"]["finished"] == len(load.requests) + 1
+            assert st["engine"]["model"] == "tiny"
+            assert json.load(urllib.request.urlopen(srv.url + "/v1/models", timeout=5))["data"][0]["id"] == "tiny"
+    finally:
+        eng.stop()
+
+
+def test_exact_quantile():
+    assert exact_quantile([], 0.5) is None
+    assert exact_quantile([1.0, 2.0, 3.0, 4.0], 0.5) == 2.5
+    assert exact_quantile([5.0], 0.99) == 5.0
+
+
+def test_cpu_dispatch_of_the_ops_matches_the_reference():
+    torch.manual_seed(0)
+    x, w, res = torch.randn(5, 256), torch.randn(256), torch.randn(5, 256)
+    r0 = res.clone()
+    o = llm.rmsnorm(x, w, 1e-5, residual=res)
+    want, nr = ref.rmsnorm(x, w, 1e-5, residual=r0)
+    assert torch.equal(o, want) and torch.equal(res, nr)
+    assert llm.prefill_tiles([5, 40], 4).tolist() == [[0, 0], [1, 0], [1, 16], [1, 32]]
+    assert llm.pick_splits(1, 8, 8192) == 64 and llm.pick_splits(256, 8, 8192) == 1 and llm.pick_splits(1, 8, 256) == 2

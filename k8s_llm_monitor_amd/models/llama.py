@@ -10,9 +10,13 @@ MI355X-first choices:
   * 288 GB of HBM3E: 8B (16 GB) and 70B (141 GB) both fit ONE GPU in bf16, so replicas scale as
     one process per GPU (data parallel serving) and no tensor-parallel all-reduce sits on the
     token path; the KV cache gets the rest of the HBM.
-  * attention, RMSNorm(+residual), RoPE+cache write and SwiGLU are the kernels of ops/csrc/llm.hip;
-    the projections are plain library GEMMs (hipBLASLt through torch.matmul), fused where the
-    operands allow it (one qkv GEMM, one gate_up GEMM).
+  * attention, RMSNorm(+residual), RoPE+cache write and SwiGLU are the kernels of ops/csrc/llm.hip.
+    At batch <= 16 (decode is then a pure weight-streaming problem) the projections run on the
+    skinny MFMA kernel with the norm, the residual add and SwiGLU fused into it: 4 weight passes
+    + rope + attention per layer. Larger batches and prefill use plain library GEMMs (hipBLASLt
+    through torch.matmul), fused where the operands allow it (one qkv GEMM, one gate_up GEMM).
+  * weight layout chosen for those kernels: RMSNorm gains are folded into the columns of the
+    projection that consumes the norm, and gate/up rows are interleaved by 8 (ops.llm.interleave_gate_up).
   * decode is launch-bound at small batch (about 10 launches x layers), so the engine captures it
     in a hipGraph per batch bucket (serving/engine.py); everything here is capture-safe: no
     host synchronisation and no shape-dependent Python branching inside ``decode``.
@@ -118,27 +122,24 @@ class LlamaModel:
         def w(*shape, std=0.02):
             return torch.empty(shape, dtype=dtype, device=self.device).normal_(0.0, std, generator=g)
 
-        def ones(n):
-            return torch.ones(n, dtype=dtype, device=self.device)
-
         self.embed = w(cfg.vocab, cfg.hidden)
-        self.lm_head = w(cfg.vocab, cfg.hidden)
-        self.final_norm = ones(cfg.hidden)
+        self.lm_head = w(cfg.vocab, cfg.hidden)                    # final norm gain folded in
+        # the norm gains live inside wqkv / w_gate_up / lm_head; the stand-alone norm kernel gets ones
+        self.unit_gain = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
         out_std = 0.02 / math.sqrt(2 * cfg.layers)
         self.layers: List[Dict[str, torch.Tensor]] = []
         for _ in range(cfg.layers):
             self.layers.append({
-                "norm1": ones(cfg.hidden), "norm2": ones(cfg.hidden),
                 "wqkv": w(cfg.qkv_dim, cfg.hidden),
                 "wo": w(cfg.hidden, cfg.q_dim, std=out_std),
-                "w_gate_up": w(2 * cfg.ffn, cfg.hidden),
+                "w_gate_up": w(2 * cfg.ffn, cfg.hidden),            # gate/up rows interleaved by 8
                 "w_down": w(cfg.hidden, cfg.ffn, std=out_std),
             })
         self.cos_sin = llm.rope_table(cfg.max_pos, cfg.rope_theta, self.device)
         self.scale = 1.0 / math.sqrt(HEAD_DIM)
 
     def weight_bytes(self) -> int:
-        n = self.embed.numel() + self.lm_head.numel() + self.final_norm.numel()
+        n = self.embed.numel() + self.lm_head.numel()
         for L in self.layers:
             n += sum(t.numel() for t in L.values())
         return n * 2
@@ -148,23 +149,42 @@ class LlamaModel:
 
     # ------------------------------------------------------------------ the decoder stack
     def _stack(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
-        cfg = self.cfg
+        """Library-GEMM path (prefill, decode at batch > 16) -> the final residual stream's norm."""
+        cfg, g = self.cfg, self.unit_gain
         h = self.embed[tokens]                                   # [T, hidden]
         residual = None
         for li, L in enumerate(self.layers):
             if residual is None:
                 residual = h
-                x = llm.rmsnorm(h, L["norm1"], cfg.eps)
+                x = llm.rmsnorm(h, g, cfg.eps)
             else:
-                x = llm.rmsnorm(h, L["norm1"], cfg.eps, residual=residual)
+                x = llm.rmsnorm(h, g, cfg.eps, residual=residual)
             qkv = torch.matmul(x, L["wqkv"].t())
             llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
             a = attend(qkv, cache.k[li], cache.v[li])
             h = torch.matmul(a, L["wo"].t())
-            x = llm.rmsnorm(h, L["norm2"], cfg.eps, residual=residual)
+            x = llm.rmsnorm(h, g, cfg.eps, residual=residual)
             act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
             h = torch.matmul(act, L["w_down"].t())
-        return llm.rmsnorm(h, self.final_norm, cfg.eps, residual=residual)
+        return llm.rmsnorm(h, g, cfg.eps, residual=residual)
+
+    def _stack_skinny(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
+        """Batch <= 16: every projection is one pass of the skinny kernel over its weights, with the
+        norm / residual add / SwiGLU fused in; `h` is the residual stream, updated in place."""
+        cfg = self.cfg
+        h = self.embed[tokens]
+        for li, L in enumerate(self.layers):
+            qkv = llm.skinny_linear(h, L["wqkv"], rms=True, eps=cfg.eps)
+            llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
+            a = attend(qkv, cache.k[li], cache.v[li])
+            llm.skinny_linear(a, L["wo"], epilogue="residual", residual=h, out=h)
+            act = llm.skinny_linear(h, L["w_gate_up"], rms=True, epilogue="swiglu", eps=cfg.eps)
+            llm.skinny_linear(act, L["w_down"], epilogue="residual", residual=h, out=h)
+        return h
+
+    def skinny(self, batch: int) -> bool:
+        c = self.cfg
+        return batch <= llm.SKINNY_MAX_ROWS and c.hidden % 128 == 0 and c.ffn % 128 == 0 and c.vocab % 16 == 0
 
     def decode(self, tokens, positions, slots, cache: KVCache, meta: DecodeMeta) -> torch.Tensor:
         """One token per sequence -> greedy next token ids [B] (int64). Capture-safe."""
@@ -174,6 +194,9 @@ class LlamaModel:
             return llm.paged_attn_decode(qkv, kc, vc, meta.block_tables, meta.ctx_lens, self.scale, cfg.n_q,
                                          num_splits=meta.num_splits, workspace=meta.workspace)
 
+        if self.skinny(tokens.shape[0]):
+            h = self._stack_skinny(tokens, positions, slots, cache, attend)
+            return llm.skinny_linear(h, self.lm_head, rms=True, eps=cfg.eps).argmax(dim=-1)
         x = self._stack(tokens, positions, slots, cache, attend)
         return torch.matmul(x, self.lm_head.t()).argmax(dim=-1)
 

@@ -70,7 +70,7 @@ int klm_spin(uint64_t cycles, int blocks, void* stream);
 // norm is taken of the new residual. H % 8 == 0, H <= 8192.
 int klm_rmsnorm(const void* x, void* residual, const void* weight, void* out, int T, int H, float eps,
                 void* stream);
-// out[T][F] = silu(gate_up[T][0:F]) * gate_up[T][F:2F]; F % 8 == 0.
+// out[T][8j+c] = silu(gate_up[T][16j+c]) * gate_up[T][16j+8+c] (gate/up interleaved by 8); F % 8 == 0.
 int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream);
 // RoPE (rotate-half) on the q and k heads of qkv[T][n_q + 2 n_kv][128] in place, with
 // cos_sin[max_pos][128] fp32 (64 cos | 64 sin); k and v of token t go to cache slot slots[t]
@@ -93,6 +93,15 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
                            const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
                            int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,
                            void* stream);
+
+// Skinny linear layer for decode (M <= 16): out[M][N] = x[M][K] . W[N][K]^T, W streamed once.
+// rms != 0: rows are scaled by rsqrt(mean(x^2) + eps) (RMSNorm whose gain is folded into W).
+// epilogue 0: none; 1: out = residual + product (out may alias residual); 2: SwiGLU over gate/up
+// rows interleaved by 8, out is [M][N/2]. N % 16 == 0, K % 128 == 0; x rows are x_stride elements
+// apart. Tuning: waves = waves per block that split K (1, 2, 4, 8, 16; 0 = default), row_tiles =
+// 16-row tiles of W per block (1 or 4; 0 = chosen from M and N).
+int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, const void* residual, int M, int N,
+                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, void* stream);
 
 const char* klm_version(void);
 

@@ -121,16 +121,17 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------
-// SwiGLU activation: out[t][f] = silu(gate_up[t][f]) * gate_up[t][F + f].
+// SwiGLU activation on the fused gate_up projection, whose output columns are interleaved in
+// groups of 8 (columns 16j..16j+7 = gate 8j..8j+7, columns 16j+8..16j+15 = up 8j..8j+7; the
+// weight rows are stored in that order so that the skinny kernel's 16-column tile holds both):
+//   out[t][8j + c] = silu(gu[t][16j + c]) * gu[t][16j + 8 + c]
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gu,
-                                                       uint16_t* __restrict__ out, int F8, size_t total) {
-  // F8 = F / 8; `total` = T * F8 vectors of 8
+                                                       uint16_t* __restrict__ out, size_t total) {
+  // `total` = T * F / 8 output vectors of 8; vector i reads the 32 contiguous bytes at gu + 16 i
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t t = i / F8, f = i - t * F8;
-    const uint16_t* row = gu + t * (size_t)F8 * 16;
-    const uint4 g = *reinterpret_cast<const uint4*>(row + f * 8);
-    const uint4 u = *reinterpret_cast<const uint4*>(row + (size_t)F8 * 8 + f * 8);
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + i * 16);
+    const uint4 u = *reinterpret_cast<const uint4*>(gu + i * 16 + 8);
     float gv[8], uv[8], o[8];
     unpack8(g, gv);
     unpack8(u, uv);
@@ -375,20 +376,54 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
 }
 
 // Merges the partial results of the splits: one 128-thread block per (sequence, query head).
+// Only the splits that hold tokens are read (the split count is fixed per hipGraph, the context
+// length is not); their (m, l) pairs are loaded by different threads and the dim loop runs four
+// independent loads deep, so the kernel costs one memory round trip rather than one per split.
 __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(const float* __restrict__ tmp_o,
                                                                 const float* __restrict__ tmp_ml,
-                                                                uint16_t* __restrict__ out, int num_splits) {
+                                                                const int* __restrict__ ctx_lens,
+                                                                uint16_t* __restrict__ out, int n_q,
+                                                                int max_blocks, int num_splits) {
+  __shared__ float sw[256];
+  __shared__ float red[4];
   const size_t head = blockIdx.x;
-  const int d = threadIdx.x;
-  float mt = -INFINITY;
-  for (int s = 0; s < num_splits; ++s) mt = fmaxf(mt, tmp_ml[(head * num_splits + s) * 2]);
+  const int d = threadIdx.x, wv = d >> 6;
+  int ctx = ctx_lens[head / n_q];
+  ctx = ctx < 0 ? 0 : (ctx > max_blocks * BLK ? max_blocks * BLK : ctx);
+  const int total_steps = (ctx + 31) >> 5;
+  const int sps = (total_steps + num_splits - 1) / num_splits;
+  const int active = sps > 0 ? (total_steps + sps - 1) / sps : 0;
+  const float* ml = tmp_ml + head * num_splits * 2;
+  float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+  if (d < active) { m0 = ml[d * 2]; l0 = ml[d * 2 + 1]; }
+  if (d + 128 < active) { m1 = ml[(d + 128) * 2]; l1 = ml[(d + 128) * 2 + 1]; }
+  float mt = fmaxf(m0, m1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mt = fmaxf(mt, __shfl_xor(mt, o));
+  if ((d & 63) == 0) red[wv] = mt;
+  __syncthreads();
+  mt = fmaxf(red[0], red[1]);
   const float mu = (mt == -INFINITY) ? 0.f : mt;
-  float L = 0.f, o = 0.f;
-  for (int s = 0; s < num_splits; ++s) {
-    const float wgt = fast_exp2(tmp_ml[(head * num_splits + s) * 2] - mu);
-    L += tmp_ml[(head * num_splits + s) * 2 + 1] * wgt;
-    o += tmp_o[(head * num_splits + s) * HD + d] * wgt;
+  const float w0 = fast_exp2(m0 - mu), w1 = fast_exp2(m1 - mu);
+  if (d < active) sw[d] = w0;
+  if (d + 128 < active) sw[d + 128] = w1;
+  float L = l0 * w0 + l1 * w1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o);
+  if ((d & 63) == 0) red[2 + wv] = L;
+  __syncthreads();
+  L = red[2] + red[3];
+  const float* po = tmp_o + head * num_splits * HD + d;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int sidx = 0;
+  for (; sidx + 4 <= active; sidx += 4) {
+    a0 += po[(sidx + 0) * HD] * sw[sidx + 0];
+    a1 += po[(sidx + 1) * HD] * sw[sidx + 1];
+    a2 += po[(sidx + 2) * HD] * sw[sidx + 2];
+    a3 += po[(sidx + 3) * HD] * sw[sidx + 3];
   }
+  for (; sidx < active; ++sidx) a0 += po[sidx * HD] * sw[sidx];
+  const float o = (a0 + a1) + (a2 + a3);
   out[head * HD + d] = f2bf(L > 0.f ? o / L : 0.f);
 }
 
@@ -455,6 +490,122 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Skinny linear layer for decode at small batch (M <= 16 rows): out[M][N] = x[M][K] . W[N][K]^T.
+// The weight matrix is streamed from HBM exactly once, straight into MFMA operand registers
+// (no LDS staging): a block owns 16 output columns (16 rows of W), its waves split K, every
+// wave issues 16-byte loads of W[n0 + lane&15][k + (lane>>4)*8 ..] and of the matching x
+// fragment (L1/L2 resident, M*K*2 bytes), and one v_mfma_f32_16x16x32_bf16 per 1 KiB of W keeps
+// the math invisible next to the memory time. There is NO per-element VALU work in the loop:
+//   RMS      : the row's sum of squares is a second MFMA, x . x^T, whose diagonal is read at the
+//              end; the product is then scaled by rsqrt(mean(x^2) + eps). The norm's gain is
+//              folded into W's columns when the model is built.
+//   EPI_RES  : out = res + product  (the residual add; out may alias res)
+//   EPI_SWIGLU: W rows are gate/up interleaved by 8 (see silu_mul_kernel), the tile's 8 gate and
+//              8 up columns meet through one cross-lane exchange: out[M][N/2] = silu(g) * u
+// so a decoder layer at small batch is 4 of these + rope + attention. The K split is reduced
+// through LDS (deterministic, no atomics).
+// ------------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_RES = 1, EPI_SWIGLU = 2 };
+
+// RT = 16-row tiles of W per block: the x fragment is loaded once per RT weight fragments, which
+// matters when M is large enough for the x traffic (M*K*2 bytes per block, from L2) to rival the
+// block's weight traffic (16*RT*K*2 bytes).
+template <bool RMS, int EPI, int RT>
+__global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
+    const uint16_t* __restrict__ x, int x_stride, const uint16_t* __restrict__ W, uint16_t* out,
+    const uint16_t* res, int M, int N, int K, int kslice, float eps) {
+  constexpr int MAXW = RT == 1 ? 16 : 8;
+  __shared__ f32x4 part[MAXW][RT][64];
+  __shared__ float ssq[MAXW][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 16 * RT;
+  const int k0 = w * kslice + fq * 8;
+  const uint16_t* wp = W + (size_t)(n0 + fr) * K + k0;
+  const size_t tile_stride = (size_t)16 * K;
+  const bool valid = fr < M;
+  const uint16_t* xp = x + (size_t)(valid ? fr : 0) * x_stride + k0;
+  f32x4 acc[RT], sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 zero;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f;
+
+#define KLM_SKINNY_CHUNK(c)                                                                        \
+  {                                                                                                \
+    bf16x8 wf[RT][4], xf[4];                                                                       \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                 \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                \
+        wf[r][s] = *reinterpret_cast<const bf16x8*>(wp + r * tile_stride + (c) + s * 32);          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                  \
+        xf[s] = valid ? *reinterpret_cast<const bf16x8*>(xp + (c) + s * 32) : zero;                \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
+      _Pragma("unroll") for (int r = 0; r < RT; ++r)                                               \
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r][s], xf[s], acc[r], 0, 0, 0);        \
+      if (RMS) sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[s], xf[s], sq, 0, 0, 0);            \
+    }                                                                                              \
+  }
+  int c = 0;
+  if (RT == 1) {
+    for (; c + 256 <= kslice; c += 256) {
+      KLM_SKINNY_CHUNK(c)
+      KLM_SKINNY_CHUNK(c + 128)
+    }
+  }
+  for (; c < kslice; c += 128) KLM_SKINNY_CHUNK(c)
+#undef KLM_SKINNY_CHUNK
+
+#pragma unroll
+  for (int r = 0; r < RT; ++r) part[w][r][lane] = acc[r];
+  if (RMS) {
+    // sq = x . x^T: D[row fq*4+i][col fr]; the diagonal element of row fr sits in lane (fr, fr/4), i = fr%4
+    const int i = fr & 3;
+    const float d = i == 0 ? sq[0] : (i == 1 ? sq[1] : (i == 2 ? sq[2] : sq[3]));
+    if (fq == (fr >> 2)) ssq[w][fr] = d;
+  }
+  __syncthreads();
+  // wave r of the block finishes row tile r (RT <= number of waves is checked by the launcher)
+  if (w < RT) {
+    f32x4 t = part[0][w][lane];
+    for (int ww = 1; ww < nw; ++ww) t += part[ww][w][lane];
+    if (RMS) {
+      float tot = 0.f;
+      for (int ww = 0; ww < nw; ++ww) tot += ssq[ww][fr];
+      t *= rsqrtf(tot / (float)K + eps);
+    }
+    const int nt = n0 + w * 16;
+    if (EPI == EPI_SWIGLU) {
+      // lanes fq 0,1 hold gate columns fq*4+i, lanes fq 2,3 the matching up columns
+      f32x4 u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[i] = __shfl_xor(t[i], 32);
+      if (valid && fq < 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(t[i] / (1.f + __expf(-t[i])) * u[i]);
+        *reinterpret_cast<bf16x4*>(out + (size_t)fr * (N >> 1) + (nt >> 1) + fq * 4) = o;
+      }
+    } else if (valid) {
+      const size_t idx = (size_t)fr * N + nt + fq * 4;
+      if (EPI == EPI_RES) {
+        const uint2 ra = *reinterpret_cast<const uint2*>(res + idx);
+        t[0] += __uint_as_float(ra.x << 16);
+        t[1] += __uint_as_float(ra.x & 0xffff0000u);
+        t[2] += __uint_as_float(ra.y << 16);
+        t[3] += __uint_as_float(ra.y & 0xffff0000u);
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (__bf16)t[i];
+      *reinterpret_cast<bf16x4*>(out + idx) = o;
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int group_shift(int G) {
   switch (G) {
@@ -495,7 +646,7 @@ int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream) {
   size_t blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     (const uint16_t*)gate_up, (uint16_t*)out, F / 8, total);
+                     (const uint16_t*)gate_up, (uint16_t*)out, total);
   return launch_status();
 }
 
@@ -535,8 +686,8 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
                      tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2);
   if (hipGetLastError() != hipSuccess) return KLM_ERR_HIP;
   if (num_splits > 1)
-    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)B * n_q), dim3(128), 0, s, tmp_o, tmp_ml,
-                       (uint16_t*)out, num_splits);
+    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)B * n_q), dim3(128), 0, s, tmp_o, tmp_ml, ctx_lens,
+                       (uint16_t*)out, n_q, max_blocks, num_splits);
   return launch_status();
 }
 
@@ -557,6 +708,53 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
                      static_cast<hipStream_t>(stream), (const uint16_t*)q, (const uint16_t*)k_cache,
                      (const uint16_t*)v_cache, block_tables, seq_info, tiles, (uint16_t*)out, n_seqs, q_stride, n_q, n_kv, G,
                      gs, max_blocks, num_blocks_total, scale_log2);
+  return launch_status();
+}
+
+int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, const void* residual, int M, int N,
+                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, void* stream) {
+  if (M <= 0 || M > 16 || N <= 0 || N % 16 != 0 || K <= 0 || K % 128 != 0) return KLM_ERR_SHAPE;
+  if (epilogue < 0 || epilogue > 2) return KLM_ERR_VARIANT;
+  if (!x || !W || !out || ((epilogue == EPI_RES) != (residual != nullptr))) return KLM_ERR_ARG;
+  if (x_stride % 8 != 0 || x_stride < K) return KLM_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(W) || !aligned16(out) || !aligned16(residual)) return KLM_ERR_ALIGN;
+  // rows of W per block: 64 when the x traffic would otherwise rival the weight traffic (M > 4)
+  // and N is large enough to still give every CU several blocks
+  int rt = row_tiles;
+  if (rt != 1 && rt != 4) rt = (M > 4 && N % 64 == 0 && N / 64 >= 384) ? 4 : 1;
+  if (rt == 4 && N % 64 != 0) rt = 1;
+  // measured on MI355X (scripts/gpu_skinny_bench.py): 8 waves split K up to 8192, 16 beyond; 4 with 64-row blocks
+  int nw = (waves == 1 || waves == 2 || waves == 4 || waves == 8 || waves == 16) ? waves
+                                                                                 : (rt == 4 ? 4 : (K > 8192 ? 16 : 8));
+  if (rt == 4 && nw > 8) nw = 8;
+  while (nw > 1 && K % (128 * nw) != 0) nw >>= 1;
+  if (nw < rt) rt = 1;
+  const int kslice = K / nw;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(N / (16 * rt)), block(64 * nw);
+  const uint16_t* xx = (const uint16_t*)x;
+  const uint16_t* ww = (const uint16_t*)W;
+  uint16_t* oo = (uint16_t*)out;
+  const uint16_t* rr = (const uint16_t*)residual;
+#define KLM_SKINNY(R, E)                                                                                        \
+  do {                                                                                                          \
+    if (rt == 4)                                                                                                \
+      hipLaunchKernelGGL((skinny_linear_kernel<R, E, 4>), grid, block, 0, s, xx, x_stride, ww, oo, rr, M, N, K, \
+                         kslice, eps);                                                                          \
+    else                                                                                                        \
+      hipLaunchKernelGGL((skinny_linear_kernel<R, E, 1>), grid, block, 0, s, xx, x_stride, ww, oo, rr, M, N, K, \
+                         kslice, eps);                                                                          \
+  } while (0)
+  if (rms) {
+    if (epilogue == EPI_NONE) KLM_SKINNY(true, EPI_NONE);
+    else if (epilogue == EPI_RES) KLM_SKINNY(true, EPI_RES);
+    else KLM_SKINNY(true, EPI_SWIGLU);
+  } else {
+    if (epilogue == EPI_NONE) KLM_SKINNY(false, EPI_NONE);
+    else if (epilogue == EPI_RES) KLM_SKINNY(false, EPI_RES);
+    else KLM_SKINNY(false, EPI_SWIGLU);
+  }
+#undef KLM_SKINNY
   return launch_status();
 }
 

@@ -36,7 +36,9 @@ def _lib():
         lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, vp]
         lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
         lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
-        for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill"):
+        lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, vp]
+        for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
+                  "klm_skinny_linear"):
             getattr(lib, n).restype = i
         _bound = True
     return lib
@@ -83,7 +85,8 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5,
 
 
 def silu_mul(gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``silu(gate_up[:, :F]) * gate_up[:, F:]``."""
+    """SwiGLU on the fused gate_up activation (gate/up columns interleaved by 8, see
+    interleave_gate_up): ``out[:, 8j+c] = silu(gate_up[:, 16j+c]) * gate_up[:, 16j+8+c]``."""
     if not gate_up.is_cuda:
         return ref.silu_mul(gate_up)
     _bf16(gate_up)
@@ -93,6 +96,66 @@ def silu_mul(gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
     if out is None:
         out = torch.empty((T, F2 // 2), dtype=gate_up.dtype, device=gate_up.device)
     _check(_lib().klm_silu_mul(gate_up.data_ptr(), out.data_ptr(), T, F2 // 2, _stream(gate_up)), "klm_silu_mul")
+    return out
+
+
+SKINNY_MAX_ROWS = 16
+_EPILOGUES = {"none": 0, "residual": 1, "swiglu": 2}
+
+
+def skinny_ok(M: int, N: int, K: int) -> bool:
+    """Shapes the skinny kernel takes (decode at small batch)."""
+    return 0 < M <= SKINNY_MAX_ROWS and N % 16 == 0 and K % 128 == 0
+
+
+def interleave_gate_up(w_gate: torch.Tensor, w_up: torch.Tensor) -> torch.Tensor:
+    """[F,K] gate and up weights -> the fused [2F,K] layout of this package: rows 16j..16j+7 are gate
+    rows 8j..8j+7, rows 16j+8..16j+15 the matching up rows (see silu_mul / skinny_linear)."""
+    F, K = w_gate.shape
+    return torch.stack((w_gate.view(F // 8, 8, K), w_up.view(F // 8, 8, K)), dim=1).reshape(2 * F, K).contiguous()
+
+
+def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epilogue: str = "none",
+                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  eps: float = 1e-5, waves: int = 0, row_tiles: int = 0) -> torch.Tensor:
+    """``out = x[M,K] @ weight[N,K].T`` for M <= 16, the weight streamed from HBM once.
+
+    rms: rows scaled by ``rsqrt(mean(x^2) + eps)`` (an RMSNorm whose gain is folded into `weight`);
+    epilogue "residual": ``out = residual + product`` (`out` may be `residual`); "swiglu": `weight`
+    rows are gate/up interleaved by 8 and ``out[M, N/2] = silu(gate) * up``."""
+    epi = _EPILOGUES[epilogue]
+    N, K = weight.shape
+    M = x.shape[0]
+    if (epi == 1) != (residual is not None):
+        raise KlmOpsError("skinny_linear: `residual` goes with epilogue='residual'")
+    if not x.is_cuda:
+        xf = x[:, :K].float()
+        if rms:
+            xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+        o = xf @ weight.float().t()
+        if epi == 1:
+            o = o + residual.float()
+        elif epi == 2:
+            o = ref.silu_mul(o)
+        o = o.to(x.dtype)
+        if out is not None:
+            out.copy_(o)
+            return out
+        return o
+    _bf16(x, weight)
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or not weight.is_contiguous() or not skinny_ok(M, N, K):
+        raise KlmOpsError(f"skinny_linear: x {tuple(x.shape)} weight {tuple(weight.shape)}")
+    n_out = N // 2 if epi == 2 else N
+    if residual is not None and (tuple(residual.shape) != (M, N) or not residual.is_contiguous() or residual.dtype != x.dtype):
+        raise KlmOpsError("skinny_linear: residual must be contiguous [M,N]")
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
+        raise KlmOpsError("skinny_linear: bad out")
+    rc = _lib().klm_skinny_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), out.data_ptr(),
+                                  residual.data_ptr() if residual is not None else None, M, N, K, int(bool(rms)), epi,
+                                  float(eps), int(waves), int(row_tiles), _stream(x))
+    _check(rc, f"klm_skinny_linear(M={M},N={N},K={K},rms={rms},{epilogue})")
     return out
 
 

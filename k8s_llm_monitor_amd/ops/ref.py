@@ -37,9 +37,10 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float,
 
 
 def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
+    """gate/up columns interleaved by 8: [.., 16j+c] gate, [.., 16j+8+c] up -> [.., 8j+c]."""
     f = gate_up.shape[-1] // 2
-    g, u = gate_up[..., :f].float(), gate_up[..., f:].float()
-    return (torch.nn.functional.silu(g) * u).to(gate_up.dtype)
+    v = gate_up.float().reshape(*gate_up.shape[:-1], f // 8, 2, 8)
+    return (torch.nn.functional.silu(v[..., 0, :]) * v[..., 1, :]).reshape(*gate_up.shape[:-1], f).to(gate_up.dtype)
 
 
 def rope(qkv: torch.Tensor, cos_sin: torch.Tensor, positions: torch.Tensor, n_q: int, n_kv: int) -> torch.Tensor:

@@ -109,6 +109,8 @@ class Engine:
         self.clock = clock
         mcfg: LlamaConfig = model.cfg if model is not None else PRESETS[self.cfg.model]
         self.device = torch.device(self.cfg.device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.on_gpu = self.device.type == "cuda"
         self.max_len = min(self.cfg.max_model_len, mcfg.max_pos)
         self.model = model or LlamaModel(mcfg, self.device, seed=self.cfg.seed)

@@ -149,3 +149,55 @@ def test_decode_attention_can_be_captured_in_a_hip_graph():
     g.replay()
     torch.cuda.synchronize()
     _close(out, ref.paged_attn_decode(q, kc, vc, bt, cl, scale), 2e-2)
+
+
+def _lin_ref(x, w, rms, epilogue, residual, eps=1e-5):
+    xf = x.float()
+    if rms:
+        xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    o = xf @ w.float().t()
+    if epilogue == "residual":
+        o = o + residual.float()
+    elif epilogue == "swiglu":
+        o = ref.silu_mul(o)
+    return o
+
+
+@pytest.mark.parametrize("M", [1, 5, 16])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (256, 128), (128256, 4096)])
+@pytest.mark.parametrize("rms,epilogue", [(False, "none"), (False, "residual"), (True, "none"), (True, "swiglu"),
+                                          (True, "residual")])
+@pytest.mark.parametrize("waves,row_tiles", [(0, 0), (16, 1), (4, 4)])
+def test_skinny_linear_matches_reference(M, N, K, rms, epilogue, waves, row_tiles):
+    if N == 128256 and (M != 5 or epilogue != "none" or not rms):
+        pytest.skip("the lm_head shape is checked once")
+    torch.manual_seed(7)
+    w = _rand(N, K, scale=0.05)
+    x = _rand(M, K)
+    residual = _rand(M, N) if epilogue == "residual" else None
+    want = _lin_ref(x, w, rms, epilogue, residual)
+    got = llm.skinny_linear(x, w, rms=rms, epilogue=epilogue, residual=residual, waves=waves, row_tiles=row_tiles)
+    _close(got, want, 5e-3 * float(want.abs().max()) + 1e-3, 2e-2)
+    if residual is not None:                            # in place on the residual stream
+        r2 = residual.clone()
+        llm.skinny_linear(x, w, rms=rms, epilogue=epilogue, residual=r2, out=r2, waves=waves, row_tiles=row_tiles)
+        assert torch.equal(r2, got)
+
+
+def test_skinny_linear_reads_a_strided_input():
+    torch.manual_seed(8)
+    big = _rand(4, 3 * 4096)
+    x = big[:, 4096:8192]                                # row stride 12288
+    w = _rand(4096, 4096, scale=0.05)
+    _close(llm.skinny_linear(x, w), _lin_ref(x, w, False, "none", None), 5e-2, 2e-2)
+
+
+def test_interleaved_gate_up_is_the_plain_swiglu():
+    torch.manual_seed(9)
+    F, K, T = 512, 256, 7
+    wg, wu, x = _rand(F, K, scale=0.1), _rand(F, K, scale=0.1), _rand(T, K)
+    w = llm.interleave_gate_up(wg, wu)
+    want = torch.nn.functional.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t())
+    got = llm.silu_mul((x.float() @ w.float().t()).to(torch.bfloat16))
+    _close(got, want, 3e-2, 2e-2)
+    _close(llm.skinny_linear(x, w, epilogue="swiglu"), want, 3e-2, 2e-2)

@@ -31,7 +31,7 @@ def dense_next(model, seq):
     h = model.embed[torch.tensor(seq)]
     pos = torch.arange(T)
     for L in model.layers:
-        x = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + cfg.eps) * L["norm1"]
+        x = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + cfg.eps)    # gains are folded into the weights
         qkv = ref.rope(x @ L["wqkv"].t(), model.cos_sin, pos, cfg.n_q, cfg.n_kv).view(T, -1, 128)
         q, k, v = qkv[:, :cfg.n_q], qkv[:, cfg.n_q:cfg.n_q + cfg.n_kv], qkv[:, cfg.n_q + cfg.n_kv:]
         g = cfg.n_q // cfg.n_kv
@@ -40,10 +40,10 @@ def dense_next(model, seq):
         s = s.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1)[None], float("-inf"))
         a = torch.einsum("htc,chd->thd", torch.softmax(s, -1), v).reshape(T, -1)
         h = h + a @ L["wo"].t()
-        x = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + cfg.eps) * L["norm2"]
-        gu = x @ L["w_gate_up"].t()
-        h = h + (torch.nn.functional.silu(gu[:, :cfg.ffn]) * gu[:, cfg.ffn:]) @ L["w_down"].t()
-    x = h[-1] * torch.rsqrt(h[-1].pow(2).mean(-1, keepdim=True) + cfg.eps) * model.final_norm
+        x = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + cfg.eps)
+        gu = (x @ L["w_gate_up"].t()).view(T, cfg.ffn // 8, 2, 8)       # gate/up interleaved by 8
+        h = h + (torch.nn.functional.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(T, cfg.ffn) @ L["w_down"].t()
+    x = h[-1] * torch.rsqrt(h[-1].pow(2).mean(-1, keepdim=True) + cfg.eps)
     return int((x @ model.lm_head.t()).argmax())
 
 

@@ -186,8 +186,9 @@ class LlamaModel:
         c = self.cfg
         return batch <= llm.SKINNY_MAX_ROWS and c.hidden % 128 == 0 and c.ffn % 128 == 0 and c.vocab % 16 == 0
 
-    def decode(self, tokens, positions, slots, cache: KVCache, meta: DecodeMeta) -> torch.Tensor:
-        """One token per sequence -> greedy next token ids [B] (int64). Capture-safe."""
+    def decode(self, tokens, positions, slots, cache: KVCache, meta: DecodeMeta, logits: bool = False) -> torch.Tensor:
+        """One token per sequence -> greedy next token ids [B] (int64), or the logits [B, vocab].
+        Capture-safe."""
         cfg = self.cfg
 
         def attend(qkv, kc, vc):
@@ -196,12 +197,14 @@ class LlamaModel:
 
         if self.skinny(tokens.shape[0]):
             h = self._stack_skinny(tokens, positions, slots, cache, attend)
-            return llm.skinny_linear(h, self.lm_head, rms=True, eps=cfg.eps).argmax(dim=-1)
-        x = self._stack(tokens, positions, slots, cache, attend)
-        return torch.matmul(x, self.lm_head.t()).argmax(dim=-1)
+            out = llm.skinny_linear(h, self.lm_head, rms=True, eps=cfg.eps)
+        else:
+            out = torch.matmul(self._stack(tokens, positions, slots, cache, attend), self.lm_head.t())
+        return out if logits else out.argmax(dim=-1)
 
-    def prefill(self, tokens, positions, slots, cache: KVCache, meta: PrefillMeta) -> torch.Tensor:
-        """Variable-length batch of prompts (or prompt chunks) -> next token id of each sequence [S]."""
+    def prefill(self, tokens, positions, slots, cache: KVCache, meta: PrefillMeta, logits: bool = False) -> torch.Tensor:
+        """Variable-length batch of prompts (or prompt chunks) -> next token id of each sequence [S]
+        (or the logits [S, vocab])."""
         cfg = self.cfg
 
         def attend(qkv, kc, vc):
@@ -209,4 +212,14 @@ class LlamaModel:
                                           cfg.n_q)
 
         x = self._stack(tokens, positions, slots, cache, attend)
-        return torch.matmul(x[meta.last_rows], self.lm_head.t()).argmax(dim=-1)
+        out = torch.matmul(x[meta.last_rows], self.lm_head.t())
+        return out if logits else out.argmax(dim=-1)
+
+    def load_from(self, other: "LlamaModel") -> "LlamaModel":
+        """Copy another instance's weights (any device / dtype) into this one."""
+        self.embed.copy_(other.embed)
+        self.lm_head.copy_(other.lm_head)
+        for mine, theirs in zip(self.layers, other.layers):
+            for k in mine:
+                mine[k].copy_(theirs[k])
+        return self

@@ -1,0 +1,143 @@
+"""The Llama decoder and the serving engine on a real MI355X: the whole GPU stack (HIP kernels +
+hipBLASLt GEMMs + hipGraph replay) against the fp32 CPU path of the same model, and the engine's
+vLLM metrics scraped over HTTP by the monitor's own collector."""
+import json
+import time
+import urllib.request
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from k8s_llm_monitor_amd.collectors.vllm import VllmDirectSource  # noqa: E402
+from k8s_llm_monitor_amd.models.llama import PRESETS, DecodeMeta, LlamaModel, PrefillMeta  # noqa: E402
+from k8s_llm_monitor_amd.ops import llm  # noqa: E402
+from k8s_llm_monitor_amd.serving import Engine, EngineConfig  # noqa: E402
+from k8s_llm_monitor_amd.serving import bench as sb  # noqa: E402
+from k8s_llm_monitor_amd.serving.loadclient import OpenLoopLoad  # noqa: E402
+from k8s_llm_monitor_amd.serving.server import LlmServer  # noqa: E402
+
+SMALL = PRESETS["small"]
+
+
+@pytest.fixture(scope="module")
+def gpu_model():
+    return LlamaModel(SMALL, "cuda", seed=3)
+
+
+@pytest.fixture(scope="module")
+def cpu_model(gpu_model):
+    return LlamaModel(SMALL, "cpu", seed=0, dtype=torch.float32).load_from(gpu_model)
+
+
+def _prefill_inputs(prompts, dev, max_blocks, first_block=0):
+    toks, pos, slots, info, last = [], [], [], [], []
+    bt = torch.zeros((len(prompts), max_blocks), dtype=torch.int32)
+    blk = first_block
+    for i, p in enumerate(prompts):
+        n = len(p)
+        nb = -(-(n + 1) // 16)
+        ids = list(range(blk, blk + nb))
+        blk += nb
+        bt[i, :nb] = torch.tensor(ids, dtype=torch.int32)
+        info.append((len(toks), n, n))
+        toks += p
+        pos += list(range(n))
+        slots += [ids[j // 16] * 16 + j % 16 for j in range(n)]
+        last.append(len(toks) - 1)
+    meta = PrefillMeta(bt.to(dev), torch.tensor(info, dtype=torch.int32, device=dev),
+                       llm.prefill_tiles([len(p) for p in prompts], SMALL.n_q // SMALL.n_kv).to(dev),
+                       torch.tensor(last, dtype=torch.int64, device=dev))
+    return (torch.tensor(toks, dtype=torch.int64, device=dev), torch.tensor(pos, dtype=torch.int32, device=dev),
+            torch.tensor(slots, dtype=torch.int32, device=dev), meta)
+
+
+def _rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize("n_seqs", [3, 20])          # 3: skinny decode path; 20: library GEMM decode path
+def test_gpu_logits_match_the_fp32_cpu_model(gpu_model, cpu_model, n_seqs):
+    g = torch.Generator().manual_seed(n_seqs)
+    lens = [int(x) for x in torch.randint(5, 90, (n_seqs,), generator=g)]
+    prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in lens]
+    mb, nblocks = 8, 200
+    out = {}
+    for name, model in (("cpu", cpu_model), ("gpu", gpu_model)):
+        dev = model.device
+        cache = model.new_cache(nblocks)
+        t, p, s, meta = _prefill_inputs(prompts, dev, mb)
+        pre = model.prefill(t, p, s, cache, meta, logits=True)
+        # one decode step on top of the prefilled cache, fed with the same (CPU-chosen) tokens
+        nxt = out["cpu_next"] if name == "gpu" else pre.argmax(-1)
+        out.setdefault("cpu_next", nxt.cpu())
+        ctx = torch.tensor([n + 1 for n in lens], dtype=torch.int32, device=dev)
+        posd = torch.tensor(lens, dtype=torch.int32, device=dev)
+        slotd = torch.stack([meta.block_tables[i, n // 16] * 16 + n % 16 for i, n in enumerate(lens)]).to(torch.int32)
+        dmeta = DecodeMeta(meta.block_tables, ctx, num_splits=2 if dev.type == "cuda" else 1)
+        dec = model.decode(out["cpu_next"].to(dev), posd, slotd, cache, dmeta, logits=True)
+        out[name] = (pre, dec)
+    assert _rel_err(out["gpu"][0], out["cpu"][0]) < 0.03, "prefill logits"
+    assert _rel_err(out["gpu"][1], out["cpu"][1]) < 0.03, "decode logits"
+
+
+def _run(engine, prompts, max_tokens):
+    reqs = [engine.submit(p, max_tokens) for p in prompts]
+    n = 0
+    while not engine.idle():
+        engine.step()
+        n += 1
+        assert n < 5000
+    return [r.out for r in reqs]
+
+
+def test_graph_replay_and_eager_decode_generate_the_same_tokens(gpu_model):
+    g = torch.Generator().manual_seed(11)
+    prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in (7, 33, 64, 100, 16)]
+    outs = []
+    for graphs in (True, False):
+        eng = Engine(EngineConfig(model="small", max_num_seqs=32, max_model_len=512, kv_blocks=256, use_graphs=graphs),
+                     model=gpu_model)
+        outs.append(_run(eng, prompts, 24))
+        assert eng.alloc.free == eng.alloc.total
+        if graphs:
+            assert eng._graphs, "decode did not run from a hipGraph"
+    assert outs[0] == outs[1]
+    assert all(len(o) == 24 for o in outs[0])
+
+
+def test_engine_under_load_is_scraped_by_the_monitor_collector(gpu_model):
+    eng = Engine(EngineConfig(model="small", max_num_seqs=64, max_model_len=1024, kv_blocks=2048), model=gpu_model)
+    eng.warmup([1, 2, 4, 8, 16, 32, 64])
+    eng.start()
+    try:
+        with LlmServer(eng) as srv:
+            src = VllmDirectSource([srv.url])
+            assert src.sample()["available"]
+            load = OpenLoopLoad(eng, rate_rps=200, prompt_len=128, output_len=48, seed=2).start(3.0)
+            time.sleep(1.5)
+            mid = src.sample()
+            load.join(10)
+            assert load.wait_all(60)
+            end = src.sample()
+            truth = json.load(urllib.request.urlopen(srv.url + "/stats", timeout=5))["truth"]
+    finally:
+        eng.stop()
+    assert mid["running"] > 0 and mid["tokensPerSec"] > 0 and mid["kvCachePercent"] > 0
+    assert end["running"] == 0 and end["waiting"] == 0 and end["kvCachePercent"] == 0
+    assert truth["totals"]["finished"] == len(load.requests) and truth["totals"]["generation_tokens"] > 0
+    assert 0 < truth["ttft_p50"] < 1.0
+    # the scraped median sits in the same histogram bucket as the exact one
+    from k8s_llm_monitor_amd.serving.metrics import TTFT_BUCKETS
+    import bisect
+    b = bisect.bisect_left(TTFT_BUCKETS, truth["ttft_p50"])
+    lo, hi = (TTFT_BUCKETS[b - 1] if b else 0.0), TTFT_BUCKETS[min(b, len(TTFT_BUCKETS) - 1)]
+    assert end["ttftP50"] is None or lo * 0.5 <= end["ttftP50"] <= hi * 2
+
+
+def test_decode_step_timing_helper_reports_the_roofline_terms(gpu_model):
+    eng = Engine(EngineConfig(model="small", max_num_seqs=16, max_model_len=512, kv_blocks=512), model=gpu_model)
+    r = sb.decode_step_ms(eng, 4, 256, iters=5)
+    assert r["ms"] > 0 and r["tokens_per_s"] > 0 and r["bytes"] > eng.model.weight_bytes() // 2

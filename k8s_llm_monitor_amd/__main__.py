@@ -11,6 +11,7 @@ MI355X validation toolkit.
     burner     run the MFMA GEMM / HBM load generator
     probe      run the RCCL all-reduce probe and store its curve for the dashboard
     validate   run the fidelity / overhead / alert-latency phases on this GPU
+    serve-llm  run the vLLM-compatible serving load generator (Llama-3 architecture, random weights)
 """
 from __future__ import annotations
 
@@ -95,6 +96,37 @@ def _cmd_validate(a) -> int:
     return phases.main_from_args(a)
 
 
+def _cmd_serve_llm(a) -> int:
+    from .serving import Engine, EngineConfig
+    from .serving.loadclient import OpenLoopLoad
+    from .serving.server import LlmServer
+    eng = Engine(EngineConfig(model=a.model, device=a.device, max_num_seqs=a.max_num_seqs, max_model_len=a.max_model_len,
+                              kv_blocks=a.kv_blocks, kv_fraction=a.kv_fraction, use_graphs=not a.no_graphs))
+    eng.warmup()
+    eng.start()
+    srv = LlmServer(eng, host=a.host, port=a.port).start()
+    print(f"llm engine: {json.dumps(eng.describe())}", flush=True)
+    print(f"serving {eng.mcfg.name} on {srv.url}  (/metrics, /v1/completions, /stats)", flush=True)
+    load = None
+    if a.load_rps > 0:
+        load = OpenLoopLoad(eng, a.load_rps, a.prompt_len, a.output_len).start(a.duration or 1e9)
+    stop = threading.Event()
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        signal.signal(sig, lambda *_: stop.set())
+    t0 = time.time()
+    try:
+        while not stop.wait(1.0):
+            if a.duration and time.time() - t0 > a.duration:
+                break
+    finally:
+        if load is not None:
+            load.stop()
+        srv.stop()
+        eng.stop()
+        print(json.dumps(eng.metrics.truth()), flush=True)
+    return 0
+
+
 def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(prog="k8s_llm_monitor_amd", description=__doc__.split("\n")[0])
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -130,15 +162,30 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p = sub.add_parser("validate")
     p.add_argument("--out", default="")
     p.add_argument("--quick", action="store_true")
-    p.add_argument("--phases", default="all")
+    p.add_argument("--phases", default="all", help="all or a comma list of hbm,activity,mem,overhead,latency,vllm")
     p.add_argument("--device", type=int, default=0)
+    p = sub.add_parser("serve-llm")
+    p.add_argument("--model", default="llama3-8b", help="llama3-8b, llama3-70b, small, tiny")
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--host", default="0.0.0.0")
+    p.add_argument("--port", type=int, default=8000)
+    p.add_argument("--max-num-seqs", type=int, default=256)
+    p.add_argument("--max-model-len", type=int, default=4096)
+    p.add_argument("--kv-blocks", type=int, default=0, help="KV blocks of 16 tokens (0: from --kv-fraction)")
+    p.add_argument("--kv-fraction", type=float, default=0.5, help="share of the free HBM given to the KV cache")
+    p.add_argument("--no-graphs", action="store_true")
+    p.add_argument("--load-rps", type=float, default=0.0, help="built-in open-loop load (requests per second)")
+    p.add_argument("--prompt-len", type=int, default=512)
+    p.add_argument("--output-len", type=int, default=128)
+    p.add_argument("--duration", type=float, default=0.0)
     a = ap.parse_args(argv)
     if a.cmd == "serve":
         return _cmd_serve(a)
     if a.cmd == "demo":
         return _cmd_serve(a, demo=True)
     return {"sample": _cmd_sample, "build": _cmd_build, "burner": _cmd_burner, "probe": _cmd_probe,
-            "validate": _cmd_validate}[a.cmd](a)
+            "validate": _cmd_validate,
+            "serve-llm": _cmd_serve_llm}[a.cmd](a)
 
 
 if __name__ == "__main__":

@@ -133,6 +133,27 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             extras["other_kernels"] = dict(k, units={"gemm_*": "TFLOP/s", "hbm_*": "TB/s"})
         except Exception as e:
             extras["other_kernels"] = {"error": f"{type(e).__name__}: {e}"}
+        # the serving load generator (Llama-3-8B architecture, random weights): decode and prefill rates
+        try:
+            from ..serving import Engine, EngineConfig
+            from ..serving import bench as sb
+            eng = Engine(EngineConfig(model="llama3-8b", device=str(dev), max_num_seqs=256, max_model_len=4096,
+                                      kv_blocks=20000))
+            eng.warmup([1, 16, 64, 256])
+            dec = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64, 256)]
+            pre = sb.prefill_ms(eng, 4, 1024, iters=2)
+            extras["llm_serving"] = {
+                "model": "llama3-8b (random weights, bf16)", "ctx": 1024,
+                "decode": [{"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3),
+                            "tokens_per_s": round(r["tokens_per_s"], 1), "TBps": round(r["TBps"], 2)} for r in dec],
+                "prefill": {"n_seqs": 4, "prompt_len": 1024, "tokens_per_s": round(pre["tokens_per_s"], 1),
+                            "TFLOPs": round(pre["TFLOPs"], 1)}}
+            del eng, dec, pre
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+        except Exception as e:
+            extras["llm_serving"] = {"error": f"{type(e).__name__}: {e}"}
 
     if not a.no_validation:
         try:

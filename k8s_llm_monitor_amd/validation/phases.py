@@ -67,17 +67,16 @@ def hbm_fidelity(torch, dev, src, smi_idx: int, steps_gib=(16, 64, 128), settle_
     gc.collect()
     torch.cuda.synchronize(dev)
     torch.cuda.empty_cache()
-    # amdsmi's VRAM figure follows a free with a lag of ~2 s (the driver releases asynchronously):
-    # take the baseline only once two readings 0.5 s apart agree
+    # amdsmi's VRAM figure follows a free with a lag of ~2 s (the driver releases asynchronously, and
+    # the reading stays flat until it does): take the baseline only once it has not moved for 2.5 s
     base = _gpu_sample(src, smi_idx)
-    t_wait = time.perf_counter()
-    while time.perf_counter() - t_wait < 8.0:
-        time.sleep(0.5)
+    t_wait = t_stable = time.perf_counter()
+    while time.perf_counter() - t_wait < 15.0 and time.perf_counter() - t_stable < 2.5:
+        time.sleep(0.25)
         again = _gpu_sample(src, smi_idx)
-        settled = abs(again["memoryUsed"] - base["memoryUsed"]) <= 2
+        if abs(again["memoryUsed"] - base["memoryUsed"]) > 2:
+            t_stable = time.perf_counter()
         base = again
-        if settled:
-            break
     free0, total = torch.cuda.mem_get_info(dev)
     with HbmHold(dev.index or 0) as hold:
         for gib in steps_gib:
@@ -302,6 +301,88 @@ def xgmi_fidelity(torch, dist, dev, rank: int, world: int, nbytes: int = 1 << 28
     return out
 
 
+def vllm_fidelity(torch, dev, model: str = "llama3-8b", seconds: float = 20.0, period_s: float = 5.0,
+                  rate_rps: float = 16.0, prompt_len: int = 512, output_len: int = 128,
+                  kv_blocks: int = 8192) -> Dict[str, Any]:
+    """BASELINE.json config 4 on one GPU: the serving engine (serving/, Llama-3-8B architecture, random
+    weights, vLLM's metric names) runs an open-loop load while the monitor scrapes it exactly as it
+    scrapes a vLLM pod (collectors/vllm.py over HTTP, read back through /api/vllm/metrics). Every
+    scrape window is compared with the engine's exact ground truth for the same window."""
+    import bisect
+    from ..config import load_config
+    from ..server.http import MonitorServer
+    from ..server.sampler import Monitor
+    from ..serving import Engine, EngineConfig
+    from ..serving.loadclient import OpenLoopLoad
+    from ..serving.metrics import TTFT_BUCKETS, exact_quantile
+    from ..serving.server import LlmServer
+    eng = Engine(EngineConfig(model=model, device=str(dev), max_num_seqs=256, max_model_len=4096, kv_blocks=kv_blocks))
+    eng.warmup()
+    eng.start()
+    srv = LlmServer(eng).start()
+    cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"},
+                                         "sources": {"gpu": "none", "kube": "none", "vllm": "direct", "history": "local",
+                                                     "vllm_endpoints": [srv.url]},
+                                         "periods": {"vllm": 3600.0}})
+    mon = Monitor(cfg)
+    msrv = MonitorServer(mon, cfg).start()
+    rows = []
+    try:
+        load = OpenLoopLoad(eng, rate_rps=rate_rps, prompt_len=prompt_len, output_len=output_len, seed=0).start(seconds)
+        mon.tick_vllm()
+        t_prev = time.monotonic()
+        n = max(2, int(seconds / period_s))
+        for _ in range(n):
+            time.sleep(max(0.0, t_prev + period_s - time.monotonic()))
+            mon.tick_vllm()
+            t_now = time.monotonic()
+            kv_true, run_true = eng.alloc.usage * 100.0, len(eng.running)
+            shown = json.loads(urllib.request.urlopen(msrv.url + "/api/vllm/metrics", timeout=3).read())
+            m = eng.metrics
+            with m._lock:
+                gen = sum(g for (t, g, _) in m.token_log if t_prev < t <= t_now)
+                ttft = [v for (t, v) in m.ttft_log if t_prev < t <= t_now]
+            true_tps = gen / (t_now - t_prev)
+            true_p50 = exact_quantile(ttft, 0.5)
+            row = {"window_s": t_now - t_prev, "tokens_per_s_shown": shown.get("tokensPerSec"), "tokens_per_s_true": true_tps,
+                   "kv_percent_shown": shown.get("kvCachePercent"), "kv_percent_true": kv_true,
+                   "running_shown": shown.get("running"), "running_true": run_true, "waiting_shown": shown.get("waiting"),
+                   "ttft_p50_shown": shown.get("ttftP50"), "ttft_p50_true": true_p50, "ttft_p99_shown": shown.get("ttftP99"),
+                   "requests_in_window": len(ttft)}
+            if true_tps > 0 and shown.get("tokensPerSec") is not None:
+                row["tokens_per_s_error_pct"] = abs(shown["tokensPerSec"] - true_tps) / true_tps * 100.0
+            if shown.get("kvCachePercent") is not None:
+                row["kv_error_points"] = abs(shown["kvCachePercent"] - kv_true)
+            if true_p50 is not None and shown.get("ttftP50") is not None:
+                b = bisect.bisect_left(TTFT_BUCKETS, true_p50)
+                lo, hi = (TTFT_BUCKETS[b - 1] if b else 0.0), TTFT_BUCKETS[min(b, len(TTFT_BUCKETS) - 1)]
+                row["ttft_bucket"] = [lo, hi]
+                row["ttft_p50_in_true_bucket"] = bool(lo <= shown["ttftP50"] <= hi)
+            rows.append(row)
+            t_prev = t_now
+        load.stop()
+        drained = load.wait_all(60.0)
+    finally:
+        msrv.stop()
+        mon.stop()
+        srv.stop()
+        eng.stop()
+    truth = eng.metrics.truth()
+    errs = [r["tokens_per_s_error_pct"] for r in rows if "tokens_per_s_error_pct" in r]
+    kv = [r["kv_error_points"] for r in rows if "kv_error_points" in r]
+    inb = [r["ttft_p50_in_true_bucket"] for r in rows if "ttft_p50_in_true_bucket" in r]
+    out = {"model": model, "rows": rows, "drained": drained, "requests": len(load.requests), "period_s": period_s,
+           "offered": {"rate_rps": rate_rps, "prompt_len": prompt_len, "output_len": output_len},
+           "max_tokens_per_s_error_pct": max(errs) if errs else None, "max_kv_error_points": max(kv) if kv else None,
+           "ttft_p50_in_true_bucket": (all(inb) if inb else None),
+           "engine": {"tokens_per_s": truth["tokens_per_s"], "ttft_p50_s": truth["ttft_p50"], "ttft_p99_s": truth["ttft_p99"],
+                      "itl_p50_s": truth["itl_p50"], "kv_usage_max": truth["kv_usage_max"],
+                      "preemptions": truth["totals"]["preemptions"], "describe": eng.describe()}}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=None, a=None,
             quick: bool = True, which: str = "all") -> Dict[str, Any]:
@@ -311,7 +392,7 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
         return {}
     from ..collectors.gpu import open_gpu_source
     out: Dict[str, Any] = {}
-    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "mem", "overhead", "latency"}
+    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "mem", "overhead", "latency", "vllm"}
     src = open_gpu_source("amdsmi")
     try:
         idx = _smi_index_for(torch, dev, src)
@@ -337,6 +418,9 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
             guard("overhead", lambda: overhead(torch, dev, seconds=3.0 if quick else 8.0, repeats=2 if quick else 3))
         if "latency" in want:
             guard("alert_latency", lambda: alert_latency(torch, dev))
+        if "vllm" in want:
+            guard("vllm_fidelity", lambda: vllm_fidelity(torch, dev, seconds=12.0 if quick else 30.0,
+                                                         period_s=3.0 if quick else 5.0))
     finally:
         src.close()
     out["summary"] = summarize(out)
@@ -350,12 +434,18 @@ def summarize(out: Dict[str, Any]) -> Dict[str, Any]:
          "gfx_activity_error_points": g("activity_fidelity", "max_error_points"),
          "sampling_overhead_pct": g("overhead", "overhead_pct"),
          "sampling_overhead_20hz_pct": g("overhead", "overhead_stress_pct"),
-         "alert_latency_max_s": g("alert_latency", "max_latency_s")}
+         "alert_latency_max_s": g("alert_latency", "max_latency_s"),
+         "vllm_tokens_per_s_error_pct": g("vllm_fidelity", "max_tokens_per_s_error_pct"),
+         "vllm_kv_cache_error_points": g("vllm_fidelity", "max_kv_error_points"),
+         "vllm_ttft_p50_in_true_bucket": g("vllm_fidelity", "ttft_p50_in_true_bucket")}
     s["targets"] = {"error_pct": 2.0, "overhead_pct": 1.0, "alert_latency_s": 10.0}
     s["pass"] = {"hbm": s["hbm_error_pct"] is not None and s["hbm_error_pct"] <= 2.0,
                  "activity": s["gfx_activity_error_points"] is not None and s["gfx_activity_error_points"] <= 2.0,
                  "overhead": s["sampling_overhead_pct"] is not None and s["sampling_overhead_pct"] < 1.0,
                  "latency": s["alert_latency_max_s"] is not None and s["alert_latency_max_s"] < 10.0}
+    if "vllm_fidelity" in out:
+        s["pass"]["vllm"] = (s["vllm_tokens_per_s_error_pct"] is not None and s["vllm_tokens_per_s_error_pct"] <= 2.0
+                             and s["vllm_kv_cache_error_points"] is not None and s["vllm_kv_cache_error_points"] <= 2.0)
     return s
 
 

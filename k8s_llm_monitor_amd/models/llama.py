@@ -109,8 +109,16 @@ class DecodeMeta:
 class PrefillMeta:
     block_tables: torch.Tensor          # int32 [S, max_blocks]
     seq_info: torch.Tensor              # int32 [S, 3] = (q_start, q_len, ctx_len)
-    tiles: torch.Tensor                 # int32 [n_tiles, 2]
+    tiles: torch.Tensor                 # int32 [n_tiles, 2], built for `q_tiles`
     last_rows: torch.Tensor             # int64 [S]: row of each sequence's last token
+    q_tiles: int = llm.PREFILL_Q_TILES
+
+    @staticmethod
+    def build(cfg: "LlamaConfig", q_lens, block_tables, seq_info, last_rows, device) -> "PrefillMeta":
+        """Chooses the attention tiling for these prompt lengths and builds the tile table."""
+        g = cfg.n_q // cfg.n_kv
+        qt = llm.pick_q_tiles(q_lens, g, cfg.n_kv)
+        return PrefillMeta(block_tables, seq_info, llm.prefill_tiles(q_lens, g, qt).to(device), last_rows, qt)
 
 
 class LlamaModel:
@@ -209,7 +217,7 @@ class LlamaModel:
 
         def attend(qkv, kc, vc):
             return llm.paged_attn_prefill(qkv, kc, vc, meta.block_tables, meta.seq_info, meta.tiles, self.scale,
-                                          cfg.n_q)
+                                          cfg.n_q, q_tiles=meta.q_tiles)
 
         x = self._stack(tokens, positions, slots, cache, attend)
         out = torch.matmul(x[meta.last_rows], self.lm_head.t())

@@ -88,11 +88,13 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
                           void* stream);
 // Causal prefill over the paged cache (the keys of the queries are already in it).
 // seq_info[n_seqs][3] = {q_start, q_len, ctx_len}; tiles[n_tiles][2] = {sequence, first query
-// token of the tile}; a tile covers 64 / (n_q / n_kv) query tokens.
+// token of the tile}; a tile covers q_tiles * 64 / (n_q / n_kv) query tokens (q_tiles = 16-row
+// query tiles per wave: 1, 2 or 4). variant 0: every wave loads K/V fragments from global memory
+// itself (short prompts); 1: the block stages K/V once through a 4-stage LDS ring (long prompts).
 int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                            const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
                            int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,
-                           void* stream);
+                           int q_tiles, int variant, void* stream);
 
 // Skinny linear layer for decode (M <= 16): out[M][N] = x[M][K] . W[N][K]^T, W streamed once.
 // rms != 0: rows are scaled by rsqrt(mean(x^2) + eps) (RMSNorm whose gain is folded into W).

@@ -260,11 +260,14 @@ __device__ __forceinline__ void attend_step(const Frags& f, const bf16x8 (&qf)[4
   rs += __shfl_xor(rs, 32);
   a.l = a.l * alpha + rs;
   a.m = m_new;
+  // the running maximum settles after the first few steps: skip the 32 rescaling multiplies
+  // whenever no row of the wave moved its maximum (wave-uniform branch)
+  if (__ballot(alpha != 1.f) != 0) {
 #pragma unroll
-  for (int n = 0; n < 8; ++n) {
-    a.o[n] *= alpha;
-    a.o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[n], p, a.o[n], 0, 0, 0);
+    for (int n = 0; n < 8; ++n) a.o[n] *= alpha;
   }
+#pragma unroll
+  for (int n = 0; n < 8; ++n) a.o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[n], p, a.o[n], 0, 0, 0);
 }
 
 __device__ __forceinline__ void load_q(const uint16_t* qrow, bool valid, int fq, bf16x8 (&qf)[4]) {
@@ -429,10 +432,13 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(const float* __r
 
 // Prefill / chunked prefill: the queries are the LAST q_len tokens of a context of ctx_len
 // tokens that is already in the cache (rope_cache runs first). Block = (tile, kv head); a tile
-// is 4 waves x 16/G consecutive query tokens of one sequence; each wave walks the keys up to
-// its own causal limit, so there is no cross-wave exchange.
+// is 4 waves x QT x 16/G consecutive query tokens of one sequence. A wave keeps QT 16-row query
+// tiles in registers and feeds every K / V fragment it loads to all of them (QT x the MFMA work
+// per byte loaded: the kernel is bound by those fragment loads, not by the matrix pipe); each
+// tile stops at its own causal limit, and there is no cross-wave exchange.
 //   seq_info[s] = {q_start (row of the first query in q/out), q_len, ctx_len}
 //   tiles[t]    = {sequence, first query token of the tile (0-based inside the sequence's queries)}
+template <int QT>
 __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int* __restrict__ block_tables, const int* __restrict__ seq_info, const int* __restrict__ tiles,
@@ -448,8 +454,8 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   const int q_start = seq_info[seq * 3], q_len = seq_info[seq * 3 + 1];
   int ctx = seq_info[seq * 3 + 2];
   ctx = ctx < 0 ? 0 : (ctx > max_blocks * BLK ? max_blocks * BLK : ctx);
-  const int tpw = 16 >> g_shift;                    // query tokens per wave
-  const int wtok0 = tok0 + w * tpw;
+  const int tpt = 16 >> g_shift;                    // query tokens per 16-row tile
+  const int wtok0 = tok0 + w * tpt * QT;
   if (tok0 < 0 || wtok0 >= q_len || q_len > ctx) return;   // wave-uniform
 
   KvView kv;
@@ -460,32 +466,201 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   kv.last_blk = ctx > 0 ? (ctx - 1) / BLK : 0;
   kv.nb_total = nb_total;
 
-  const int tq = wtok0 + (fr >> g_shift);
-  const bool valid = tq < q_len;
-  const size_t qrow = (size_t)(q_start + (valid ? tq : wtok0));
   const size_t qhead = (size_t)h * G + (fr & (G - 1));
-  bf16x8 qf[4];
-  load_q(q + qrow * q_stride + qhead * HD, valid, fq, qf);
-  const int qpos = valid ? ctx - q_len + tq : -1;
-  int last_tq = wtok0 + tpw - 1;
-  last_tq = last_tq < q_len ? last_tq : q_len - 1;
-  const int n_steps = ((ctx - q_len + last_tq) >> 5) + 1;
+  bf16x8 qf[QT][4];
+  Acc a[QT];
+  int qpos[QT], nst[QT];
+  size_t qrow[QT];
+  bool valid[QT];
+  int n_steps = 0;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int t0 = wtok0 + t * tpt;
+    const int tq = t0 + (fr >> g_shift);
+    valid[t] = tq < q_len;
+    qrow[t] = (size_t)(q_start + (valid[t] ? tq : wtok0));
+    load_q(q + qrow[t] * q_stride + qhead * HD, valid[t], fq, qf[t]);
+    qpos[t] = valid[t] ? ctx - q_len + tq : -1;
+    int last_tq = t0 + tpt - 1;
+    last_tq = last_tq < q_len ? last_tq : q_len - 1;
+    nst[t] = t0 < q_len ? ((ctx - q_len + last_tq) >> 5) + 1 : 0;     // wave-uniform
+    n_steps = nst[t] > n_steps ? nst[t] : n_steps;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) a[t].o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    a[t].m = -INFINITY;
+    a[t].l = 0.f;
+  }
 
-  Acc a;
+  Frags cur;
+  load_step(kv, 0, fr, fq, cur);
+  for (int st = 0; st < n_steps; ++st) {
+    Frags nxt;
+    load_step(kv, st + 1 < n_steps ? st + 1 : st, fr, fq, nxt);
 #pragma unroll
-  for (int n = 0; n < 8; ++n) a.o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  a.m = -INFINITY;
-  a.l = 0.f;
-  attend_range(kv, qf, 0, n_steps, 1, fr, fq, qpos, scale_log2, a);
+    for (int t = 0; t < QT; ++t)
+      if (st < nst[t]) attend_step(cur, qf[t], st, fq, qpos[t], scale_log2, a[t]);
+    cur = nxt;
+  }
 
-  if (valid) {
-    const float inv = a.l > 0.f ? 1.f / a.l : 0.f;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      bf16x4 o;
+  for (int t = 0; t < QT; ++t) {
+    if (valid[t]) {
+      const float inv = a[t].l > 0.f ? 1.f / a[t].l : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (__bf16)(a.o[n][i] * inv);
-      *reinterpret_cast<bf16x4*>(out + (qrow * n_q + qhead) * HD + n * 16 + fq * 4) = o;
+      for (int n = 0; n < 8; ++n) {
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(a[t].o[n][i] * inv);
+        *reinterpret_cast<bf16x4*>(out + (qrow[t] * n_q + qhead) * HD + n * 16 + fq * 4) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Prefill for long prompts: the same math, K / V staged ONCE per block through an LDS ring.
+// The register kernel above makes each of the 4 waves fetch the whole 16 KiB step itself with one
+// step of lookahead: at long context it waits on L2 latency (about 2 us per step measured). Here
+// the 4 waves of a block split the fetch (4 KiB each, LDS-DMA: no registers, no VALU), 3 steps
+// stay in flight across one raw s_barrier per step (counted s_waitcnt vmcnt(8)), and every wave
+// reads its MFMA fragments from LDS:
+//   stage = K [32 tokens][256 B], 16-byte chunk c of token row r stored at chunk c ^ key(r),
+//           key(r) = (r & 15) ^ ((r >> 4) << 2)  -> the 16 rows of a fragment read hit 16 different
+//           chunk columns (conflict-free ds_read_b128); the swizzle is applied on the DMA source
+//           address, the LDS image itself is lane-linear as the DMA writes it
+//         | V [2 blocks][128 dims][16 tokens], a straight copy of the transposed cache blocks
+// ------------------------------------------------------------------------------------
+constexpr int PF_STAGES = 4;
+constexpr int PF_STAGE_BYTES = 16384;
+
+#define KLM_AS1 __attribute__((address_space(1)))
+#define KLM_AS3 __attribute__((address_space(3)))
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+  __builtin_amdgcn_global_load_lds((const KLM_AS1 void*)g, (KLM_AS3 void*)lds, 16, 0, 0);
+}
+
+__device__ __forceinline__ void pf_issue(const KvView& kv, int st, char* stage, int w, int lane) {
+  int i0 = st * 2, i1 = st * 2 + 1;
+  i0 = i0 > kv.last_blk ? kv.last_blk : i0;
+  i1 = i1 > kv.last_blk ? kv.last_blk : i1;
+  int b0 = kv.bt[i0], b1 = kv.bt[i1];
+  b0 = b0 < 0 ? 0 : (b0 >= kv.nb_total ? kv.nb_total - 1 : b0);
+  b1 = b1 < 0 ? 0 : (b1 >= kv.nb_total ? kv.nb_total - 1 : b1);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = 2 * w + j;                         // piece: K token rows 4p..4p+3, V bytes [1024 p, +1024)
+    const size_t base = (size_t)(p >= 4 ? b1 : b0) * kv.blk_stride;
+    const int row = p * 4 + (lane >> 4);
+    const int key = (row & 15) ^ ((row >> 4) << 2);
+    glds16(kv.kc + base + (row & 15) * HD + (((lane & 15) ^ key) << 3), stage + p * 1024);
+    glds16(kv.vc + base + (p & 3) * 512 + lane * 8, stage + 8192 + p * 1024);
+  }
+}
+
+__device__ __forceinline__ void pf_read(const char* stage, int fr, int fq, Frags& f) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tok = ((fr >> 2) << 3) + t * 4 + (fr & 3);
+    const int key = (tok & 15) ^ ((tok >> 4) << 2);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      f.k[t][s] = *reinterpret_cast<const bf16x8*>(stage + tok * 256 + (((s * 4 + fq) ^ key) << 4));
+  }
+  const char* vp = stage + 8192 + (fq >> 1) * 4096 + fr * 32 + (fq & 1) * 16;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) f.v[n] = *reinterpret_cast<const bf16x8*>(vp + n * 512);
+}
+
+template <int QT>
+__global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+    const int* __restrict__ block_tables, const int* __restrict__ seq_info, const int* __restrict__ tiles,
+    uint16_t* __restrict__ out, int n_seqs, int q_stride, int n_q, int n_kv, int G, int g_shift,
+    int max_blocks, int nb_total, float scale_log2) {
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  const int tile = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  int seq = tiles[tile * 2];
+  seq = seq < 0 ? 0 : (seq >= n_seqs ? n_seqs - 1 : seq);
+  const int tok0 = tiles[tile * 2 + 1];
+  const int q_start = seq_info[seq * 3], q_len = seq_info[seq * 3 + 1];
+  int ctx = seq_info[seq * 3 + 2];
+  ctx = ctx < 0 ? 0 : (ctx > max_blocks * BLK ? max_blocks * BLK : ctx);
+  const int tpt = 16 >> g_shift;
+  if (tok0 < 0 || tok0 >= q_len || q_len > ctx) return;          // block-uniform
+  const int wtok0 = tok0 + w * tpt * QT;
+
+  KvView kv;
+  kv.kc = kc + (size_t)h * BLK_ELEMS;
+  kv.vc = vc + (size_t)h * BLK_ELEMS;
+  kv.bt = block_tables + (size_t)seq * max_blocks;
+  kv.blk_stride = (size_t)n_kv * BLK_ELEMS;
+  kv.last_blk = ctx > 0 ? (ctx - 1) / BLK : 0;
+  kv.nb_total = nb_total;
+
+  int blk_last = tok0 + 4 * QT * tpt - 1;
+  blk_last = blk_last < q_len ? blk_last : q_len - 1;
+  const int n_steps = ((ctx - q_len + blk_last) >> 5) + 1;        // block-uniform: every wave loads and syncs
+
+  const size_t qhead = (size_t)h * G + (fr & (G - 1));
+  bf16x8 qf[QT][4];
+  Acc a[QT];
+  int qpos[QT], nst[QT];
+  size_t qrow[QT];
+  bool valid[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int t0 = wtok0 + t * tpt;
+    const int tq = t0 + (fr >> g_shift);
+    valid[t] = tq < q_len;
+    qrow[t] = (size_t)(q_start + (valid[t] ? tq : tok0));
+    load_q(q + qrow[t] * q_stride + qhead * HD, valid[t], fq, qf[t]);
+    qpos[t] = valid[t] ? ctx - q_len + tq : -1;
+    int last_tq = t0 + tpt - 1;
+    last_tq = last_tq < q_len ? last_tq : q_len - 1;
+    nst[t] = t0 < q_len ? ((ctx - q_len + last_tq) >> 5) + 1 : 0;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) a[t].o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    a[t].m = -INFINITY;
+    a[t].l = 0.f;
+  }
+
+#pragma unroll
+  for (int sidx = 0; sidx < PF_STAGES - 1; ++sidx)
+    pf_issue(kv, sidx < n_steps ? sidx : n_steps - 1, ring + sidx * PF_STAGE_BYTES, w, lane);
+  for (int st = 0; st < n_steps; ++st) {
+    // 4 DMA instructions per wave and step, issued in order: at most the 2 newer steps may be pending
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int nx = st + PF_STAGES - 1;
+    pf_issue(kv, nx < n_steps ? nx : n_steps - 1, ring + (nx & (PF_STAGES - 1)) * PF_STAGE_BYTES, w, lane);
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) any = any || (st < nst[t]);
+    if (any) {
+      Frags f;
+      pf_read(ring + (st & (PF_STAGES - 1)) * PF_STAGE_BYTES, fr, fq, f);
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+        if (st < nst[t]) attend_step(f, qf[t], st, fq, qpos[t], scale_log2, a[t]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant tail DMAs before the LDS goes away
+
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    if (valid[t]) {
+      const float inv = a[t].l > 0.f ? 1.f / a[t].l : 0.f;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(a[t].o[n][i] * inv);
+        *reinterpret_cast<bf16x4*>(out + (qrow[t] * n_q + qhead) * HD + n * 16 + fq * 4) = o;
+      }
     }
   }
 }
@@ -694,7 +869,8 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
 int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                            const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
                            int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,
-                           void* stream) {
+                           int q_tiles, int variant, void* stream) {
+  if ((q_tiles != 1 && q_tiles != 2 && q_tiles != 4) || variant < 0 || variant > 1) return KLM_ERR_VARIANT;
   if (q_stride < n_q * HD || q_stride % 8 != 0) return KLM_ERR_SHAPE;
   if (n_tiles <= 0 || n_seqs <= 0 || n_q <= 0 || n_kv <= 0 || n_kv > 65535 || n_q % n_kv != 0 ||
       max_blocks <= 0 || num_blocks_total <= 0)
@@ -704,10 +880,35 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
   if (!q || !k_cache || !v_cache || !block_tables || !seq_info || !tiles || !out) return KLM_ERR_ARG;
   if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) return KLM_ERR_ALIGN;
   const float scale_log2 = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(paged_attn_prefill_kernel, dim3(n_tiles, n_kv), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), (const uint16_t*)q, (const uint16_t*)k_cache,
-                     (const uint16_t*)v_cache, block_tables, seq_info, tiles, (uint16_t*)out, n_seqs, q_stride, n_q, n_kv, G,
-                     gs, max_blocks, num_blocks_total, scale_log2);
+#define KLM_PREFILL(QT)                                                                                          \
+  hipLaunchKernelGGL((paged_attn_prefill_kernel<QT>), dim3(n_tiles, n_kv), dim3(256), 0,                         \
+                     static_cast<hipStream_t>(stream), (const uint16_t*)q, (const uint16_t*)k_cache,             \
+                     (const uint16_t*)v_cache, block_tables, seq_info, tiles, (uint16_t*)out, n_seqs, q_stride,  \
+                     n_q, n_kv, G, gs, max_blocks, num_blocks_total, scale_log2)
+#define KLM_PREFILL_LDS(QT)                                                                                      \
+  do {                                                                                                           \
+    static bool attr_done = false;                                                                               \
+    if (!attr_done) {                                                                                            \
+      if (hipFuncSetAttribute((const void*)paged_attn_prefill_lds_kernel<QT>,                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PF_STAGES * PF_STAGE_BYTES) != hipSuccess) \
+        return KLM_ERR_HIP;                                                                                      \
+      attr_done = true;                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL((paged_attn_prefill_lds_kernel<QT>), dim3(n_tiles, n_kv), dim3(256),                      \
+                       PF_STAGES * PF_STAGE_BYTES, static_cast<hipStream_t>(stream), (const uint16_t*)q,         \
+                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, seq_info, tiles,        \
+                       (uint16_t*)out, n_seqs, q_stride, n_q, n_kv, G, gs, max_blocks, num_blocks_total,         \
+                       scale_log2);                                                                              \
+  } while (0)
+  if (variant == 1) {
+    if (q_tiles == 1) KLM_PREFILL_LDS(1);
+    else if (q_tiles == 2) KLM_PREFILL_LDS(2);
+    else KLM_PREFILL_LDS(4);
+  } else if (q_tiles == 1) KLM_PREFILL(1);
+  else if (q_tiles == 2) KLM_PREFILL(2);
+  else KLM_PREFILL(4);
+#undef KLM_PREFILL_LDS
+#undef KLM_PREFILL
   return launch_status();
 }
 

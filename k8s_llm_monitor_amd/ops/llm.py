@@ -35,7 +35,7 @@ def _lib():
         lib.klm_silu_mul.argtypes = [vp, vp, i, i, vp]
         lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, vp]
         lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
-        lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
+        lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, i, vp]
         lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, vp]
         for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
                   "klm_skinny_linear"):
@@ -193,8 +193,10 @@ def rope_cache(qkv: torch.Tensor, cos_sin: torch.Tensor, positions: torch.Tensor
     return qkv
 
 
-def pick_splits(batch: int, n_kv: int, max_ctx: int, target_blocks: int = 1024) -> int:
-    """Flash-decoding split count: enough blocks to fill 256 CUs, at least 4 steps of 32 tokens each."""
+def pick_splits(batch: int, n_kv: int, max_ctx: int, target_blocks: int = 256) -> int:
+    """Flash-decoding split count: one block per CU is enough (each holds 4 waves x 16 KiB in flight) and
+    every further split costs a block start and a partial result; at least 4 steps of 32 tokens each.
+    Measured (scripts/gpu_attn_bench.py, ctx 1024): batch 1 -> 16-32 splits, 4 -> 8, 16 -> 2, 64+ -> 1."""
     by_fill = -(-target_blocks // max(1, batch * n_kv))
     by_len = max(1, max_ctx // 128)
     return int(max(1, min(by_fill, by_len, 64)))
@@ -247,10 +249,23 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     return out
 
 
-def prefill_tiles(q_lens: Sequence[int], group: int) -> torch.Tensor:
+PREFILL_Q_TILES = 2      # 16-row query tiles per wave of the prefill kernel (see pick_q_tiles)
+PREFILL_VARIANT = 1      # 1: K/V staged once per block through the LDS ring; 0: per-wave global loads
+
+
+def pick_q_tiles(q_lens: Sequence[int], group: int, n_kv: int) -> int:
+    """2 query tiles per wave (half the LDS reads per MFMA) once that still leaves every CU two
+    blocks; 1 for short prompts, where the grid would not fill the chip (scripts/gpu_attn_bench.py:
+    512 tokens 20 us vs 28 us, 8192 tokens 1194 us vs 1083 us)."""
+    per = 2 * 64 // group
+    blocks = sum(-(-int(n) // per) for n in q_lens) * n_kv
+    return 2 if blocks >= 512 else 1
+
+
+def prefill_tiles(q_lens: Sequence[int], group: int, q_tiles: int = PREFILL_Q_TILES) -> torch.Tensor:
     """Host-side tile table of the prefill kernel: int32 [n_tiles, 2] = (sequence, first query token);
-    one tile = 64 / group query tokens."""
-    per = 64 // group
+    one tile = q_tiles * 64 / group query tokens."""
+    per = q_tiles * 64 // group
     rows: List[Tuple[int, int]] = []
     for s, n in enumerate(q_lens):
         rows.extend((s, t) for t in range(0, int(n), per))
@@ -259,9 +274,10 @@ def prefill_tiles(q_lens: Sequence[int], group: int) -> torch.Tensor:
 
 def paged_attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
                        seq_info: torch.Tensor, tiles: torch.Tensor, scale: float, n_q: int,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, q_tiles: int = PREFILL_Q_TILES,
+                       variant: int = PREFILL_VARIANT) -> torch.Tensor:
     """Causal attention of the last ``q_len`` tokens of each sequence over its paged context.
-    q [T, >= n_q*128]; seq_info int32 [S, 3] = (q_start, q_len, ctx_len); tiles from prefill_tiles()."""
+    q [T, >= n_q*128]; seq_info int32 [S, 3] = (q_start, q_len, ctx_len); tiles from prefill_tiles() built with the same `q_tiles`."""
     n_kv = k_cache.shape[1]
     nb = _check_caches(k_cache, v_cache, n_kv)
     S = seq_info.shape[0]
@@ -281,6 +297,7 @@ def paged_attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Te
         out = torch.zeros((q.shape[0], n_q * HEAD_DIM), dtype=q.dtype, device=q.device)
     rc = _lib().klm_paged_attn_prefill(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
                                        seq_info.data_ptr(), tiles.data_ptr(), out.data_ptr(), tiles.shape[0], S,
-                                       q.stride(0), n_q, n_kv, block_tables.shape[1], nb, float(scale), _stream(q))
+                                       q.stride(0), n_q, n_kv, block_tables.shape[1], nb, float(scale), int(q_tiles),
+                                       int(variant), _stream(q))
     _check(rc, f"klm_paged_attn_prefill(tiles={tiles.shape[0]})")
     return out

@@ -70,9 +70,10 @@ def prefill_ms(eng: Engine, n_seqs: int, prompt_len: int, iters: int = 3, warmup
         idx = np.arange(prompt_len)
         slots[i * prompt_len:(i + 1) * prompt_len] = blocks[idx // BLOCK] * BLOCK + idx % BLOCK
     info = [(i * prompt_len, prompt_len, prompt_len) for i in range(n_seqs)]
-    meta = PrefillMeta(torch.from_numpy(bt).to(dev), torch.tensor(info, dtype=torch.int32, device=dev),
-                       llm.prefill_tiles([prompt_len] * n_seqs, c.n_q // c.n_kv).to(dev),
-                       torch.tensor([(i + 1) * prompt_len - 1 for i in range(n_seqs)], dtype=torch.int64, device=dev))
+    meta = PrefillMeta.build(c, [prompt_len] * n_seqs, torch.from_numpy(bt).to(dev),
+                             torch.tensor(info, dtype=torch.int32, device=dev),
+                             torch.tensor([(i + 1) * prompt_len - 1 for i in range(n_seqs)], dtype=torch.int64, device=dev),
+                             dev)
     toks = torch.randint(0, c.vocab, (T,), device=dev)
     pos = torch.arange(prompt_len, dtype=torch.int32, device=dev).repeat(n_seqs)
     sl = torch.from_numpy(slots).to(dev)

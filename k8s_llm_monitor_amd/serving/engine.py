@@ -240,11 +240,9 @@ class Engine:
             bt[i, :len(r.blocks)] = r.blocks
             last_rows.append(len(toks) - 1)
         dev = self.device
-        meta = PrefillMeta(
-            block_tables=torch.from_numpy(bt).to(dev),
-            seq_info=torch.tensor(info, dtype=torch.int32, device=dev),
-            tiles=llm.prefill_tiles([n for (_, n, _) in info], self.mcfg.n_q // self.mcfg.n_kv).to(dev),
-            last_rows=torch.tensor(last_rows, dtype=torch.int64, device=dev))
+        meta = PrefillMeta.build(self.mcfg, [n for (_, n, _) in info], torch.from_numpy(bt).to(dev),
+                                 torch.tensor(info, dtype=torch.int32, device=dev),
+                                 torch.tensor(last_rows, dtype=torch.int64, device=dev), dev)
         nxt = self.model.prefill(torch.tensor(toks, dtype=torch.int64, device=dev),
                                  torch.tensor(pos, dtype=torch.int32, device=dev),
                                  torch.tensor(slots, dtype=torch.int32, device=dev), self.cache, meta)

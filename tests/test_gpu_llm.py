@@ -104,7 +104,9 @@ def test_paged_decode_attention_matches_reference(n_q, n_kv, splits):
 
 
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (2, 2), (8, 1)])
-def test_paged_prefill_attention_matches_reference(n_q, n_kv):
+@pytest.mark.parametrize("q_tiles", [1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_paged_prefill_attention_matches_reference(n_q, n_kv, q_tiles, variant):
     torch.manual_seed(5)
     # (q_len, ctx_len): fresh prompts, and chunks whose earlier context is already cached
     seqs = [(5, 5), (64, 64), (100, 100), (17, 300), (1, 40), (33, 64)]
@@ -117,11 +119,11 @@ def test_paged_prefill_attention_matches_reference(n_q, n_kv):
         info.append((at, ql, c))
         at += ql
     seq_info = torch.tensor(info, dtype=torch.int32, device=DEV)
-    tiles = llm.prefill_tiles([q for q, _ in seqs], n_q // n_kv).to(DEV)
+    tiles = llm.prefill_tiles([q for q, _ in seqs], n_q // n_kv, q_tiles).to(DEV)
     qkv = _rand(T, (n_q + 2 * n_kv) * 128)
     q = qkv[:, : n_q * 128]
     scale = 1.0 / math.sqrt(128)
-    got = llm.paged_attn_prefill(q, kc, vc, bt, seq_info, tiles, scale, n_q)
+    got = llm.paged_attn_prefill(q, kc, vc, bt, seq_info, tiles, scale, n_q, q_tiles=q_tiles, variant=variant)
     want = ref.paged_attn_prefill(q, kc, vc, bt, seq_info, scale)
     _close(got, want, 2e-2)
 

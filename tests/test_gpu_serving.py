@@ -46,9 +46,9 @@ def _prefill_inputs(prompts, dev, max_blocks, first_block=0):
         pos += list(range(n))
         slots += [ids[j // 16] * 16 + j % 16 for j in range(n)]
         last.append(len(toks) - 1)
-    meta = PrefillMeta(bt.to(dev), torch.tensor(info, dtype=torch.int32, device=dev),
-                       llm.prefill_tiles([len(p) for p in prompts], SMALL.n_q // SMALL.n_kv).to(dev),
-                       torch.tensor(last, dtype=torch.int64, device=dev))
+    meta = PrefillMeta.build(SMALL, [len(p) for p in prompts], bt.to(dev),
+                             torch.tensor(info, dtype=torch.int32, device=dev),
+                             torch.tensor(last, dtype=torch.int64, device=dev), dev)
     return (torch.tensor(toks, dtype=torch.int64, device=dev), torch.tensor(pos, dtype=torch.int32, device=dev),
             torch.tensor(slots, dtype=torch.int32, device=dev), meta)
 

@@ -213,5 +213,7 @@ def test_cpu_dispatch_of_the_ops_matches_the_reference():
     o = llm.rmsnorm(x, w, 1e-5, residual=res)
     want, nr = ref.rmsnorm(x, w, 1e-5, residual=r0)
     assert torch.equal(o, want) and torch.equal(res, nr)
-    assert llm.prefill_tiles([5, 40], 4).tolist() == [[0, 0], [1, 0], [1, 16], [1, 32]]
-    assert llm.pick_splits(1, 8, 8192) == 64 and llm.pick_splits(256, 8, 8192) == 1 and llm.pick_splits(1, 8, 256) == 2
+    assert llm.prefill_tiles([5, 40], 4, 1).tolist() == [[0, 0], [1, 0], [1, 16], [1, 32]]
+    assert llm.prefill_tiles([5, 40], 4, 2).tolist() == [[0, 0], [1, 0], [1, 32]]
+    assert llm.pick_splits(1, 8, 8192) == 32 and llm.pick_splits(64, 8, 8192) == 1 and llm.pick_splits(1, 8, 256) == 2
+    assert llm.pick_q_tiles([512], 4, 8) == 1 and llm.pick_q_tiles([4096], 4, 8) == 2

@@ -13,9 +13,10 @@ from k8s_llm_monitor_amd.serving import bench as sb  # noqa: E402
 from k8s_llm_monitor_amd.serving.loadclient import OpenLoopLoad  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "llama3-8b"
+kv_blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 out = {"model": model}
 t0 = time.time()
-eng = Engine(EngineConfig(model=model, max_num_seqs=256, max_model_len=4096, kv_blocks=40000))
+eng = Engine(EngineConfig(model=model, max_num_seqs=256, max_model_len=4096, kv_blocks=kv_blocks))
 torch.cuda.synchronize()
 out["init_s"] = time.time() - t0
 out["engine"] = eng.describe()
@@ -54,4 +55,4 @@ out["serving"] = {"drained": ok, "requests": len(load.requests), "truth": eng.me
                   "engine": eng.describe()}
 print(json.dumps(out["serving"]["truth"]), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/llm_bench.json", "w"), indent=1, default=str)
+json.dump(out, open("gpurun_out/llm_bench%s.json" % ("" if model == "llama3-8b" else "_" + model), "w"), indent=1, default=str)

@@ -225,36 +225,41 @@ struct Acc {
 
 // One 32-token step of online softmax attention for the wave's 16 query rows.
 // qpos: position of this lane's query row (-1 = row not in use); keys at positions <= qpos count.
+// lim (wave-uniform): every row IN USE has qpos >= lim, so a step whose last key is <= lim needs no
+// mask at all (rows not in use carry q = 0: their scores stay finite and their output is dropped).
+// The softmax keeps m in the scaled log2 domain and costs one max, one FMA and one exp2 per score.
 __device__ __forceinline__ void attend_step(const Frags& f, const bf16x8 (&qf)[4], int step, int fq,
-                                            int qpos, float scale_log2, Acc& a) {
+                                            int qpos, int lim, float scale_log2, Acc& a) {
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.k[0][s], qf[s], s0, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.k[1][s], qf[s], s1, 0, 0, 0);
   }
-  const int tk0 = step * 32 + fq * 8;
   float x[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    x[j] = (tk0 + j <= qpos) ? s0[j] * scale_log2 : -INFINITY;
-    x[j + 4] = (tk0 + 4 + j <= qpos) ? s1[j] * scale_log2 : -INFINITY;
+    x[j] = s0[j];
+    x[j + 4] = s1[j];
   }
-  float mx = x[0];
+  if (step * 32 + 31 > lim) {                      // wave-uniform: only the steps on the causal edge
+    const int tk0 = step * 32 + fq * 8;
 #pragma unroll
-  for (int j = 1; j < 8; ++j) mx = fmaxf(mx, x[j]);
+    for (int j = 0; j < 8; ++j) x[j] = (tk0 + j <= qpos) ? x[j] : -INFINITY;
+  }
+  float mx = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
-  const float m_new = fmaxf(a.m, mx);
+  const float m_new = fmaxf(a.m, mx * scale_log2);  // scale > 0; -inf stays -inf
   const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
   const float alpha = fast_exp2(a.m - m_use);
   bf16x8 p;
   float rs = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const __bf16 pb = (__bf16)fast_exp2(x[j] - m_use);
-    p[j] = pb;
-    rs += (float)pb;
+    const float pj = fast_exp2(fmaf(x[j], scale_log2, -m_use));
+    p[j] = (__bf16)pj;
+    rs += pj;
   }
   rs += __shfl_xor(rs, 16);
   rs += __shfl_xor(rs, 32);
@@ -284,7 +289,7 @@ __device__ __forceinline__ void load_q(const uint16_t* qrow, bool valid, int fq,
 
 // Runs steps st0, st0+stride, ... < st_end with the loads of the next step in flight.
 __device__ __forceinline__ void attend_range(const KvView& kv, const bf16x8 (&qf)[4], int st0, int st_end,
-                                             int stride, int fr, int fq, int qpos, float scale_log2,
+                                             int stride, int fr, int fq, int qpos, int lim, float scale_log2,
                                              Acc& a) {
   if (st0 >= st_end) return;
   Frags cur;
@@ -293,7 +298,7 @@ __device__ __forceinline__ void attend_range(const KvView& kv, const bf16x8 (&qf
     Frags nxt;
     const int nx = st + stride;
     load_step(kv, nx < st_end ? nx : st, fr, fq, nxt);   // last iteration re-reads (cached), unused
-    attend_step(cur, qf, st, fq, qpos, scale_log2, a);
+    attend_step(cur, qf, st, fq, qpos, lim, scale_log2, a);
     cur = nxt;
   }
 }
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
   for (int n = 0; n < 8; ++n) a.o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   a.m = -INFINITY;
   a.l = 0.f;
-  attend_range(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, scale_log2, a);
+  attend_range(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, ctx - 1, scale_log2, a);
 
 #pragma unroll
   for (int n = 0; n < 8; ++n) *reinterpret_cast<f32x4*>(&sm_o[w][fr][n * 16 + fq * 4]) = a.o[n];
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   const size_t qhead = (size_t)h * G + (fr & (G - 1));
   bf16x8 qf[QT][4];
   Acc a[QT];
-  int qpos[QT], nst[QT];
+  int qpos[QT], nst[QT], lim[QT];
   size_t qrow[QT];
   bool valid[QT];
   int n_steps = 0;
@@ -481,6 +486,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     qrow[t] = (size_t)(q_start + (valid[t] ? tq : wtok0));
     load_q(q + qrow[t] * q_stride + qhead * HD, valid[t], fq, qf[t]);
     qpos[t] = valid[t] ? ctx - q_len + tq : -1;
+    lim[t] = ctx - q_len + t0;                       // position of the tile's first query
     int last_tq = t0 + tpt - 1;
     last_tq = last_tq < q_len ? last_tq : q_len - 1;
     nst[t] = t0 < q_len ? ((ctx - q_len + last_tq) >> 5) + 1 : 0;     // wave-uniform
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     load_step(kv, st + 1 < n_steps ? st + 1 : st, fr, fq, nxt);
 #pragma unroll
     for (int t = 0; t < QT; ++t)
-      if (st < nst[t]) attend_step(cur, qf[t], st, fq, qpos[t], scale_log2, a[t]);
+      if (st < nst[t]) attend_step(cur, qf[t], st, fq, qpos[t], lim[t], scale_log2, a[t]);
     cur = nxt;
   }
 
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
   const size_t qhead = (size_t)h * G + (fr & (G - 1));
   bf16x8 qf[QT][4];
   Acc a[QT];
-  int qpos[QT], nst[QT];
+  int qpos[QT], nst[QT], lim[QT];
   size_t qrow[QT];
   bool valid[QT];
 #pragma unroll
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
     qrow[t] = (size_t)(q_start + (valid[t] ? tq : tok0));
     load_q(q + qrow[t] * q_stride + qhead * HD, valid[t], fq, qf[t]);
     qpos[t] = valid[t] ? ctx - q_len + tq : -1;
+    lim[t] = ctx - q_len + t0;                       // position of the tile's first query
     int last_tq = t0 + tpt - 1;
     last_tq = last_tq < q_len ? last_tq : q_len - 1;
     nst[t] = t0 < q_len ? ((ctx - q_len + last_tq) >> 5) + 1 : 0;
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
       pf_read(ring + (st & (PF_STAGES - 1)) * PF_STAGE_BYTES, fr, fq, f);
 #pragma unroll
       for (int t = 0; t < QT; ++t)
-        if (st < nst[t]) attend_step(f, qf[t], st, fq, qpos[t], scale_log2, a[t]);
+        if (st < nst[t]) attend_step(f, qf[t], st, fq, qpos[t], lim[t], scale_log2, a[t]);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant tail DMAs before the LDS goes away

@@ -385,12 +385,26 @@ class Engine:
                 self._wake.wait(0.05)
                 self._wake.clear()
 
-    def stop(self) -> None:
+    def stop(self, abort_pending: bool = True) -> None:
+        """Stop the background loop; requests still queued or running are failed (their `done` event
+        fires with `error` set) so that no caller waits for a step that will never run."""
         self._stop.set()
         self._wake.set()
         if self._thread is not None:
             self._thread.join(timeout=30)
             self._thread = None
+        if abort_pending:
+            now = self.clock()
+            with self._lock:
+                for r in list(self.waiting) + list(self.running):
+                    self.alloc.release(r.blocks)
+                    r.blocks = []
+                    r.error = "engine stopped"
+                    r.t_done = now
+                    r.done.set()
+                self.waiting.clear()
+                self.running = []
+                self.metrics.set_queue(0, 0, self.alloc.usage)
 
     def describe(self) -> Dict[str, object]:
         return {"model": self.mcfg.name, "params": self.mcfg.params(), "weight_bytes": self.model.weight_bytes(),

@@ -119,7 +119,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             if rank == 0:
                 extras["xgmi_fidelity"] = {"error": f"{type(e).__name__}: {e}"}
 
-    if not a.no_validation and rank == 0:
+    if not a.no_validation and rank == 0 and dev.type == "cuda":
         # the other validation-load kernels, 1 s each (outside the timed region)
         try:
             from ..loadgen.burner import Burner

@@ -200,6 +200,17 @@ def test_http_server_and_open_loop_load(model):
         eng.stop()
 
 
+def test_stop_fails_the_requests_it_leaves_behind(model):
+    eng = _engine(model)
+    a = eng.submit([1, 2, 3], 50)
+    eng.step()                                    # prefill: `a` is running
+    b = eng.submit([4, 5], 5)                     # still waiting
+    eng.stop()
+    assert a.done.is_set() and b.done.is_set()
+    assert a.error == "engine stopped" and b.error == "engine stopped"
+    assert eng.idle() and eng.alloc.free == eng.alloc.total
+
+
 def test_exact_quantile():
     assert exact_quantile([], 0.5) is None
     assert exact_quantile([1.0, 2.0, 3.0, 4.0], 0.5) == 2.5

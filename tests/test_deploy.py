@@ -57,3 +57,13 @@ def test_llm_loadgen_manifest_runs_the_cli_and_looks_like_a_vllm_pod():
            "spec": dep["spec"]["template"]["spec"], "status": {"phase": "Running"}}
     assert pods_from_list({"items": [pod]})[0]["vllm"] is True
     del argparse
+
+
+def test_cmake_project_lists_every_native_source():
+    """CMakeLists.txt and build.py describe the same four targets and sources."""
+    from k8s_llm_monitor_amd import build
+    text = open(os.path.join(ROOT, "CMakeLists.txt")).read()
+    for t in build.targets():
+        assert t.name in text, t.name
+        for s in t.sources:
+            assert s.name in text, f"{s.name} missing from CMakeLists.txt"

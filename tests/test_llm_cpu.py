@@ -228,3 +228,32 @@ def test_cpu_dispatch_of_the_ops_matches_the_reference():
     assert llm.prefill_tiles([5, 40], 4, 2).tolist() == [[0, 0], [1, 0], [1, 32]]
     assert llm.pick_splits(1, 8, 8192) == 32 and llm.pick_splits(64, 8, 8192) == 1 and llm.pick_splits(1, 8, 256) == 2
     assert llm.pick_q_tiles([512], 4, 8) == 1 and llm.pick_q_tiles([4096], 4, 8) == 2
+
+
+def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model):
+    """Random arrivals and lengths against 10 blocks: whatever the interleaving of prefill, decode
+    and preemption, no block is held twice or leaked, every request finishes with exactly the
+    tokens of the dense forward, and the counters add up."""
+    import random
+    rng = random.Random(7)
+    eng = _engine(model, kv_blocks=10, max_model_len=96, max_num_seqs=5, max_num_batched_tokens=64)
+    reqs, steps = [], 0
+    while len(reqs) < 14 or not eng.idle():
+        if len(reqs) < 14 and rng.random() < 0.4:
+            p = [rng.randrange(TINY.vocab) for _ in range(rng.randint(1, 40))]
+            reqs.append((p, eng.submit(p, rng.randint(1, 30))))
+        eng.step()
+        steps += 1
+        assert steps < 5000
+        held = [b for r in eng.running for b in r.blocks]
+        assert len(held) == len(set(held)), "a block is owned twice"
+        assert len(held) + eng.alloc.free == eng.alloc.total, "blocks leaked"
+        assert all(not r.blocks for r in eng.waiting)
+        assert len(eng.running) <= 5
+    assert eng.metrics.preemptions > 0, "the scenario is meant to preempt"
+    for p, r in reqs:
+        assert r.done.is_set() and r.error is None
+        assert r.out == dense_generate(model, p, r.max_tokens), f"request {r.rid} (preempted {r.preempted}x)"
+    t = eng.metrics.truth()["totals"]
+    assert t["finished"] == 14 and t["generation_tokens"] >= sum(len(r.out) for _, r in reqs)
+    assert eng.alloc.free == eng.alloc.total

@@ -690,13 +690,31 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
 // ------------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SWIGLU = 2 };
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// 8 e4m3 bytes (two dwords, k order = byte order) -> one bf16 MFMA fragment
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
+  const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, false);
+  const bf16x2 p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, true);
+  const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, false);
+  const bf16x2 p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, true);
+  bf16x8 r;
+  r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
+  r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
+  return r;
+}
+
 // RT = 16-row tiles of W per block: the x fragment is loaded once per RT weight fragments, which
 // matters when M is large enough for the x traffic (M*K*2 bytes per block, from L2) to rival the
 // block's weight traffic (16*RT*K*2 bytes).
-template <bool RMS, int EPI, int RT>
+//
+// W8: the weights are OCP e4m3 bytes with one fp32 scale per output row (W8A16). A lane's 16-byte
+// load then carries 16 k-values; v_cvt_scalef32_pk_bf16_fp8 turns them into two bf16 MFMA fragments
+// in registers (8 VALU instructions per KiB-instruction of weights: still far from the memory time),
+// x stays bf16, and the row scale is applied to the fp32 result. Half the bytes per token.
+template <bool RMS, int EPI, int RT, bool W8>
 __global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
-    const uint16_t* __restrict__ x, int x_stride, const uint16_t* __restrict__ W, uint16_t* out,
-    const uint16_t* res, int M, int N, int K, int kslice, float eps) {
+    const uint16_t* __restrict__ x, int x_stride, const void* __restrict__ Wv, const float* __restrict__ wscale,
+    uint16_t* out, const uint16_t* res, int M, int N, int K, int kslice, float eps, int tiled) {
   constexpr int MAXW = RT == 1 ? 16 : 8;
   __shared__ f32x4 part[MAXW][RT][64];
   __shared__ float ssq[MAXW][16];
@@ -705,8 +723,17 @@ __global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
   const int nw = blockDim.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = blockIdx.x * 16 * RT;
-  const int k0 = w * kslice + fq * 8;
-  const uint16_t* wp = W + (size_t)(n0 + fr) * K + k0;
+  const int k0 = w * kslice + fq * (W8 ? 16 : 8);
+  // Weight layout. Row-major [N][K]: a lane's 16 bytes sit at row n0+fr, k offset k0, and the next
+  // MFMA step is 64 bytes further along the row. Tiled (`tiled` != 0): the 1 KiB that one wave
+  // instruction loads (16 rows x 64 bytes) is stored contiguously in lane order, tiles ordered
+  // [row tile][k step], so a wave streams one contiguous run of kslice*16 elements - the access
+  // pattern HBM likes best. Both layouts have the same distance between row tiles (16*K elements).
+  const size_t wlane = tiled ? ((size_t)(n0 >> 4) * K + (size_t)w * kslice) * 16 + lane * (W8 ? 16 : 8)
+                             : (size_t)(n0 + fr) * K + k0;
+  const int wstep = tiled ? (W8 ? 1024 : 512) : (W8 ? 64 : 32);    // elements between consecutive MFMA steps
+  const uint16_t* wp = reinterpret_cast<const uint16_t*>(Wv) + wlane;      // bf16
+  const uint8_t* wp8 = reinterpret_cast<const uint8_t*>(Wv) + wlane;       // fp8
   const size_t tile_stride = (size_t)16 * K;
   const bool valid = fr < M;
   const uint16_t* xp = x + (size_t)(valid ? fr : 0) * x_stride + k0;
@@ -722,7 +749,7 @@ __global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
     bf16x8 wf[RT][4], xf[4];                                                                       \
     _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                 \
       _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                \
-        wf[r][s] = *reinterpret_cast<const bf16x8*>(wp + r * tile_stride + (c) + s * 32);          \
+        wf[r][s] = *reinterpret_cast<const bf16x8*>(wp + r * tile_stride + ((c) / 32 + s) * wstep); \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                  \
         xf[s] = valid ? *reinterpret_cast<const bf16x8*>(xp + (c) + s * 32) : zero;                \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
@@ -731,15 +758,60 @@ __global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
       if (RMS) sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[s], xf[s], sq, 0, 0, 0);            \
     }                                                                                              \
   }
-  int c = 0;
-  if (RT == 1) {
-    for (; c + 256 <= kslice; c += 256) {
-      KLM_SKINNY_CHUNK(c)
-      KLM_SKINNY_CHUNK(c + 128)
-    }
+  // fp8 weights: 64 k-values per step; the lane's 16 bytes become fragments A0 (values 0..7) and A1
+  // (8..15), matched by the two 16-byte x loads at the same k offsets (any k order is fine for a
+  // contraction as long as both operands use it)
+#define KLM_SKINNY_CHUNK8(c)                                                                       \
+  {                                                                                                \
+    uint4 raw[RT];                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                 \
+        raw[r] = *reinterpret_cast<const uint4*>(wp8 + r * tile_stride + ((c) / 64) * wstep);       \
+    const bf16x8 x0 = valid ? *reinterpret_cast<const bf16x8*>(xp + (c)) : zero;                   \
+    const bf16x8 x1 = valid ? *reinterpret_cast<const bf16x8*>(xp + (c) + 8) : zero;               \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                               \
+      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(raw[r].x, raw[r].y), x0, acc[r], 0, 0, 0); \
+      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(raw[r].z, raw[r].w), x1, acc[r], 0, 0, 0); \
+    }                                                                                              \
+    if (RMS) {                                                                                     \
+      sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, x0, sq, 0, 0, 0);                           \
+      sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, x1, sq, 0, 0, 0);                           \
+    }                                                                                              \
   }
-  for (; c < kslice; c += 128) KLM_SKINNY_CHUNK(c)
+  int c = 0;
+  if (W8) {
+    if (RT == 1) {
+      for (; c + 512 <= kslice; c += 512) {          // 8 weight loads in flight per wave, as in the bf16 loop
+        KLM_SKINNY_CHUNK8(c)
+        KLM_SKINNY_CHUNK8(c + 64)
+        KLM_SKINNY_CHUNK8(c + 128)
+        KLM_SKINNY_CHUNK8(c + 192)
+        KLM_SKINNY_CHUNK8(c + 256)
+        KLM_SKINNY_CHUNK8(c + 320)
+        KLM_SKINNY_CHUNK8(c + 384)
+        KLM_SKINNY_CHUNK8(c + 448)
+      }
+      for (; c + 256 <= kslice; c += 256) {
+        KLM_SKINNY_CHUNK8(c)
+        KLM_SKINNY_CHUNK8(c + 64)
+        KLM_SKINNY_CHUNK8(c + 128)
+        KLM_SKINNY_CHUNK8(c + 192)
+      }
+    }
+    for (; c + 128 <= kslice; c += 128) {
+      KLM_SKINNY_CHUNK8(c)
+      KLM_SKINNY_CHUNK8(c + 64)
+    }
+  } else {
+    if (RT == 1) {
+      for (; c + 256 <= kslice; c += 256) {
+        KLM_SKINNY_CHUNK(c)
+        KLM_SKINNY_CHUNK(c + 128)
+      }
+    }
+    for (; c < kslice; c += 128) KLM_SKINNY_CHUNK(c)
+  }
 #undef KLM_SKINNY_CHUNK
+#undef KLM_SKINNY_CHUNK8
 
 #pragma unroll
   for (int r = 0; r < RT; ++r) part[w][r][lane] = acc[r];
@@ -760,6 +832,10 @@ __global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
       t *= rsqrtf(tot / (float)K + eps);
     }
     const int nt = n0 + w * 16;
+    if (W8) {
+      const f32x4 ws = *reinterpret_cast<const f32x4*>(wscale + nt + fq * 4);
+      t *= ws;
+    }
     if (EPI == EPI_SWIGLU) {
       // lanes fq 0,1 hold gate columns fq*4+i, lanes fq 2,3 the matching up columns
       f32x4 u;
@@ -919,13 +995,15 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
   return launch_status();
 }
 
-int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, const void* residual, int M, int N,
-                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, void* stream) {
+static int skinny_launch(const void* x, int x_stride, const void* W, const float* wscale, bool w8, void* out,
+                         const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
+                         int row_tiles, int tiled, void* stream) {
   if (M <= 0 || M > 16 || N <= 0 || N % 16 != 0 || K <= 0 || K % 128 != 0) return KLM_ERR_SHAPE;
   if (epilogue < 0 || epilogue > 2) return KLM_ERR_VARIANT;
-  if (!x || !W || !out || ((epilogue == EPI_RES) != (residual != nullptr))) return KLM_ERR_ARG;
+  if (!x || !W || !out || ((epilogue == EPI_RES) != (residual != nullptr)) || (w8 && !wscale)) return KLM_ERR_ARG;
   if (x_stride % 8 != 0 || x_stride < K) return KLM_ERR_SHAPE;
-  if (!aligned16(x) || !aligned16(W) || !aligned16(out) || !aligned16(residual)) return KLM_ERR_ALIGN;
+  if (!aligned16(x) || !aligned16(W) || !aligned16(out) || !aligned16(residual) || !aligned16(wscale))
+    return KLM_ERR_ALIGN;
   // rows of W per block: 64 when the x traffic would otherwise rival the weight traffic (M > 4)
   // and N is large enough to still give every CU several blocks
   int rt = row_tiles;
@@ -941,17 +1019,20 @@ int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, con
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid(N / (16 * rt)), block(64 * nw);
   const uint16_t* xx = (const uint16_t*)x;
-  const uint16_t* ww = (const uint16_t*)W;
   uint16_t* oo = (uint16_t*)out;
   const uint16_t* rr = (const uint16_t*)residual;
-#define KLM_SKINNY(R, E)                                                                                        \
-  do {                                                                                                          \
-    if (rt == 4)                                                                                                \
-      hipLaunchKernelGGL((skinny_linear_kernel<R, E, 4>), grid, block, 0, s, xx, x_stride, ww, oo, rr, M, N, K, \
-                         kslice, eps);                                                                          \
-    else                                                                                                        \
-      hipLaunchKernelGGL((skinny_linear_kernel<R, E, 1>), grid, block, 0, s, xx, x_stride, ww, oo, rr, M, N, K, \
-                         kslice, eps);                                                                          \
+#define KLM_SKINNY_L(R, E, T, Q)                                                                            \
+  hipLaunchKernelGGL((skinny_linear_kernel<R, E, T, Q>), grid, block, 0, s, xx, x_stride, W, wscale, oo, rr, M, N, \
+                     K, kslice, eps, tiled)
+#define KLM_SKINNY(R, E)                         \
+  do {                                           \
+    if (w8) {                                    \
+      if (rt == 4) KLM_SKINNY_L(R, E, 4, true);  \
+      else KLM_SKINNY_L(R, E, 1, true);          \
+    } else {                                     \
+      if (rt == 4) KLM_SKINNY_L(R, E, 4, false); \
+      else KLM_SKINNY_L(R, E, 1, false);         \
+    }                                            \
   } while (0)
   if (rms) {
     if (epilogue == EPI_NONE) KLM_SKINNY(true, EPI_NONE);
@@ -963,7 +1044,21 @@ int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, con
     else KLM_SKINNY(false, EPI_SWIGLU);
   }
 #undef KLM_SKINNY
+#undef KLM_SKINNY_L
   return launch_status();
+}
+
+int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, const void* residual, int M, int N,
+                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, int tiled, void* stream) {
+  return skinny_launch(x, x_stride, W, nullptr, false, out, residual, M, N, K, rms, epilogue, eps, waves, row_tiles,
+                       tiled, stream);
+}
+
+int klm_skinny_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, void* out,
+                         const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
+                         int row_tiles, int tiled, void* stream) {
+  return skinny_launch(x, x_stride, W8, wscale, true, out, residual, M, N, K, rms, epilogue, eps, waves, row_tiles,
+                       tiled, stream);
 }
 
 }  // extern "C"

@@ -36,7 +36,9 @@ def _lib():
         lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, vp]
         lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
         lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, i, vp]
-        lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, vp]
+        lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, i, vp]
+        lib.klm_skinny_linear_w8.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, f, i, i, i, vp]
+        lib.klm_skinny_linear_w8.restype = i
         for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
                   "klm_skinny_linear"):
             getattr(lib, n).restype = i
@@ -115,11 +117,52 @@ def interleave_gate_up(w_gate: torch.Tensor, w_up: torch.Tensor) -> torch.Tensor
     return torch.stack((w_gate.view(F // 8, 8, K), w_up.view(F // 8, 8, K)), dim=1).reshape(2 * F, K).contiguous()
 
 
+FP8_MAX = 448.0      # largest finite OCP e4m3 value
+
+
+def quantize_fp8_rows(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[N,K] weights -> (e4m3 [N,K], fp32 scale [N]) with ``w ~= w8.float() * scale[:, None]``
+    (one scale per output row, chosen so that the row's largest magnitude maps to 448)."""
+    wf = w.float()
+    scale = (wf.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX)
+    w8 = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    return w8.contiguous(), scale.to(torch.float32).contiguous()
+
+
+def tile_weights(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] row-major (bf16 or e4m3) -> the skinny kernel's streaming order, same shape and dtype:
+    tiles [N/16][K/kt] of 64 lanes x 16 bytes, lane l holding row 16 nt + l%16, k = kt ks + (l/16)*e .. +e
+    (kt, e = 32, 8 for bf16; 64, 16 for fp8). Pass ``tiled=True`` to skinny_linear with the result."""
+    N, K = w.shape
+    e = 16 if w.dtype == torch.float8_e4m3fn else 8
+    kt = 4 * e
+    if N % 16 or K % kt:
+        raise KlmOpsError(f"tile_weights: {tuple(w.shape)} is not a multiple of 16 x {kt}")
+    v = w.view(torch.uint8 if e == 16 else w.dtype).view(N // 16, 16, K // kt, 4, e)     # [nt, fr, ks, fq, e]
+    t = v.permute(0, 2, 3, 1, 4).contiguous().view(N, K)                                  # [nt, ks, fq, fr, e]
+    return t.view(w.dtype)
+
+
+def untile_weights(t: torch.Tensor) -> torch.Tensor:
+    N, K = t.shape
+    e = 16 if t.dtype == torch.float8_e4m3fn else 8
+    kt = 4 * e
+    v = t.view(torch.uint8 if e == 16 else t.dtype).view(N // 16, K // kt, 4, 16, e)
+    return v.permute(0, 3, 1, 2, 4).contiguous().view(N, K).view(t.dtype)
+
+
+def dequantize_fp8_rows(w8: torch.Tensor, scale: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    return (w8.float() * scale[:, None].float()).to(dtype)
+
+
 def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epilogue: str = "none",
                   residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                  eps: float = 1e-5, waves: int = 0, row_tiles: int = 0) -> torch.Tensor:
+                  eps: float = 1e-5, waves: int = 0, row_tiles: int = 0,
+                  weight_scale: Optional[torch.Tensor] = None, tiled: bool = False) -> torch.Tensor:
     """``out = x[M,K] @ weight[N,K].T`` for M <= 16, the weight streamed from HBM once.
 
+    `weight` is bf16, or e4m3 with `weight_scale` [N] (see quantize_fp8_rows): half the bytes, converted
+    to bf16 in registers (W8A16).
     rms: rows scaled by ``rsqrt(mean(x^2) + eps)`` (an RMSNorm whose gain is folded into `weight`);
     epilogue "residual": ``out = residual + product`` (`out` may be `residual`); "swiglu": `weight`
     rows are gate/up interleaved by 8 and ``out[M, N/2] = silu(gate) * up``."""
@@ -128,11 +171,18 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epil
     M = x.shape[0]
     if (epi == 1) != (residual is not None):
         raise KlmOpsError("skinny_linear: `residual` goes with epilogue='residual'")
+    w8 = weight.dtype == torch.float8_e4m3fn
+    if w8 != (weight_scale is not None):
+        raise KlmOpsError("skinny_linear: `weight_scale` goes with float8_e4m3fn weights")
     if not x.is_cuda:
+        if tiled:
+            weight = untile_weights(weight)
         xf = x[:, :K].float()
         if rms:
             xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
         o = xf @ weight.float().t()
+        if w8:
+            o = o * weight_scale.float()[None, :]
         if epi == 1:
             o = o + residual.float()
         elif epi == 2:
@@ -142,7 +192,10 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epil
             out.copy_(o)
             return out
         return o
-    _bf16(x, weight)
+    _bf16(x) if w8 else _bf16(x, weight)
+    if w8 and (tuple(weight_scale.shape) != (N,) or weight_scale.dtype != torch.float32 or not weight_scale.is_contiguous()
+               or not weight_scale.is_cuda):
+        raise KlmOpsError("skinny_linear: weight_scale must be contiguous fp32 [N] on the GPU")
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or not weight.is_contiguous() or not skinny_ok(M, N, K):
         raise KlmOpsError(f"skinny_linear: x {tuple(x.shape)} weight {tuple(weight.shape)}")
     n_out = N // 2 if epi == 2 else N
@@ -152,9 +205,15 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epil
         out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
     elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
         raise KlmOpsError("skinny_linear: bad out")
-    rc = _lib().klm_skinny_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), out.data_ptr(),
-                                  residual.data_ptr() if residual is not None else None, M, N, K, int(bool(rms)), epi,
-                                  float(eps), int(waves), int(row_tiles), _stream(x))
+    rp = residual.data_ptr() if residual is not None else None
+    if w8:
+        rc = _lib().klm_skinny_linear_w8(x.data_ptr(), x.stride(0), weight.data_ptr(), weight_scale.data_ptr(),
+                                         out.data_ptr(), rp, M, N, K, int(bool(rms)), epi, float(eps), int(waves),
+                                         int(row_tiles), int(bool(tiled)), _stream(x))
+    else:
+        rc = _lib().klm_skinny_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), out.data_ptr(), rp, M, N, K,
+                                      int(bool(rms)), epi, float(eps), int(waves), int(row_tiles), int(bool(tiled)),
+                                      _stream(x))
     _check(rc, f"klm_skinny_linear(M={M},N={N},K={K},rms={rms},{epilogue})")
     return out
 

@@ -47,7 +47,10 @@ def decode_step_ms(eng: Engine, batch: int, ctx: int, iters: int = 20, warmup: i
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     c = eng.mcfg
-    weight_bytes = eng.model.weight_bytes() - c.vocab * c.hidden * 2          # the embedding is only gathered
+    if eng.model.skinny(b):
+        weight_bytes = eng.model.decode_stream_bytes()
+    else:
+        weight_bytes = eng.model.weight_bytes() - c.vocab * c.hidden * 2      # the embedding is only gathered
     kv_bytes = batch * ctx * c.kv_bytes_per_token()
     return {"batch": batch, "bucket": b, "ctx": ctx, "ms": ms, "tokens_per_s": batch / ms * 1e3,
             "bytes": weight_bytes + kv_bytes, "TBps": (weight_bytes + kv_bytes) / ms / 1e9,

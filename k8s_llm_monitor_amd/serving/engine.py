@@ -42,6 +42,7 @@ class EngineConfig:
     kv_blocks: int = 0                 # 0: size the cache from kv_fraction of the free HBM
     kv_fraction: float = 0.5
     use_graphs: bool = True
+    decode_weights: str = "bf16"       # "fp8": W8A16 copies for the batch <= 16 decode path (LlamaModel.enable_fp8_decode)
     seed: int = 0
 
 
@@ -114,6 +115,10 @@ class Engine:
         self.on_gpu = self.device.type == "cuda"
         self.max_len = min(self.cfg.max_model_len, mcfg.max_pos)
         self.model = model or LlamaModel(mcfg, self.device, seed=self.cfg.seed)
+        if self.cfg.decode_weights == "fp8" and not self.model.fp8_decode:
+            self.model.enable_fp8_decode()
+        elif self.cfg.decode_weights not in ("bf16", "fp8"):
+            raise ValueError(f"decode_weights must be bf16 or fp8, not {self.cfg.decode_weights!r}")
         self.mcfg = mcfg
         self.max_blocks = -(-self.max_len // BLOCK)
         nblocks = self.cfg.kv_blocks or self._auto_blocks()
@@ -411,4 +416,5 @@ class Engine:
                 "kv_blocks": self.alloc.total, "kv_capacity_tokens": self.kv_capacity_tokens,
                 "kv_bytes": self.cache.nbytes, "max_num_seqs": self.cfg.max_num_seqs, "max_model_len": self.max_len,
                 "graphs": sorted(self._graphs), "device": str(self.device),
+                "decode_weights": "fp8 (W8A16, batch <= 16)" if self.model.fp8_decode else "bf16",
                 "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts)}

@@ -14,9 +14,10 @@ from k8s_llm_monitor_amd.serving.loadclient import OpenLoopLoad  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "llama3-8b"
 kv_blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
+decode_weights = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 out = {"model": model}
 t0 = time.time()
-eng = Engine(EngineConfig(model=model, max_num_seqs=256, max_model_len=4096, kv_blocks=kv_blocks))
+eng = Engine(EngineConfig(model=model, max_num_seqs=256, max_model_len=4096, kv_blocks=kv_blocks, decode_weights=decode_weights))
 torch.cuda.synchronize()
 out["init_s"] = time.time() - t0
 out["engine"] = eng.describe()
@@ -55,4 +56,4 @@ out["serving"] = {"drained": ok, "requests": len(load.requests), "truth": eng.me
                   "engine": eng.describe()}
 print(json.dumps(out["serving"]["truth"]), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/llm_bench%s.json" % ("" if model == "llama3-8b" else "_" + model), "w"), indent=1, default=str)
+json.dump(out, open("gpurun_out/llm_bench%s.json" % (("" if model == "llama3-8b" else "_" + model) + ("" if decode_weights == "bf16" else "_" + decode_weights)), "w"), indent=1, default=str)

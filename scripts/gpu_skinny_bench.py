@@ -24,7 +24,7 @@ def t(fn, iters=50):
 shapes = [("qkv", 6144, 4096, True, "none"), ("wo", 4096, 4096, False, "residual"),
           ("gate_up", 28672, 4096, True, "swiglu"), ("down", 4096, 14336, False, "residual"),
           ("lm_head", 128256, 4096, True, "none")]
-Ms = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 4, 8, 16]
+Ms = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 16]
 for M in Ms:
     for name, N, K, rms, epi in shapes:
         # several weight copies so that the 256 MB of L2 / MALL does not serve the stream
@@ -36,12 +36,32 @@ for M in Ms:
         i = [0]
         gb = N * K * 2 / 1e9
         line = f"M={M:2d} {name:8s} N={N:6d} K={K:5d}"
-        for waves, rt in ((0, 0), (8, 1), (16, 1), (4, 4), (8, 4)):
+        for waves, rt in ((0, 0),):
             def ours():
                 i[0] = (i[0] + 1) % ncopy
                 llm.skinny_linear(x, ws[i[0]], rms=rms, epilogue=epi, residual=res, out=res, waves=waves, row_tiles=rt)
             a = t(ours)
             line += f" | w{waves}r{rt}: {a:6.1f} us {gb / a * 1e3:4.2f}"
+
+        wts = [llm.tile_weights(wt) for wt in ws]
+        for waves, rt in ((0, 0), (16, 1), (4, 1)):
+            def ourst():
+                i[0] = (i[0] + 1) % ncopy
+                llm.skinny_linear(x, wts[i[0]], rms=rms, epilogue=epi, residual=res, out=res, waves=waves,
+                                  row_tiles=rt, tiled=True)
+            a = t(ourst)
+            line += f" | tiled w{waves}r{rt}: {a:6.1f} us {gb / a * 1e3:4.2f}"
+        del wts
+        w8s = [llm.quantize_fp8_rows(wt) for wt in ws]
+        w8t = [(llm.tile_weights(a8), sc) for a8, sc in w8s]
+        for name8, arr, tl in (("fp8", w8s, False), ("fp8t", w8t, True)):
+            for waves, rt in ((0, 0), (4, 1)):
+                def ours8():
+                    i[0] = (i[0] + 1) % ncopy
+                    llm.skinny_linear(x, arr[i[0]][0], rms=rms, epilogue=epi, residual=res, out=res, waves=waves,
+                                      row_tiles=rt, weight_scale=arr[i[0]][1], tiled=tl)
+                a = t(ours8)
+                line += f" | {name8} w{waves}r{rt}: {a:6.1f} us {gb / 2 / a * 1e3:4.2f}"
 
         def lib():
             i[0] = (i[0] + 1) % ncopy

@@ -203,3 +203,49 @@ def test_interleaved_gate_up_is_the_plain_swiglu():
     got = llm.silu_mul((x.float() @ w.float().t()).to(torch.bfloat16))
     _close(got, want, 3e-2, 2e-2)
     _close(llm.skinny_linear(x, w, epilogue="swiglu"), want, 3e-2, 2e-2)
+
+
+@pytest.mark.parametrize("M", [1, 7, 16])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (256, 128), (28672, 4096)])
+@pytest.mark.parametrize("rms,epilogue", [(False, "none"), (True, "swiglu"), (False, "residual")])
+def test_skinny_linear_with_fp8_weights_matches_the_dequantised_reference(M, N, K, rms, epilogue):
+    torch.manual_seed(10)
+    w = _rand(N, K, scale=0.05)
+    w8, ws = llm.quantize_fp8_rows(w)
+    wd = w8.float() * ws[:, None]                       # what the kernel multiplies by, exactly
+    assert float((wd - w.float()).abs().max()) < 0.07 * float(w.float().abs().max())   # e4m3: 3 mantissa bits
+    x = _rand(M, K)
+    residual = _rand(M, N) if epilogue == "residual" else None
+    want = _lin_ref(x, wd, rms, epilogue, residual)
+    got = llm.skinny_linear(x, w8, rms=rms, epilogue=epilogue, residual=residual, weight_scale=ws)
+    _close(got, want, 5e-3 * float(want.abs().max()) + 1e-3, 2e-2)
+
+
+def test_fp8_fragment_conversion_keeps_the_k_order():
+    """One hot weight per row at a different k: any mix-up of the byte order inside the converted
+    fragments would move the product to another column of x."""
+    N, K = 16, 128
+    w = torch.zeros(N, K, device=DEV)
+    for n in range(N):
+        w[n, (n * 37 + 5) % K] = 1.0
+    w8, ws = llm.quantize_fp8_rows(w)
+    x = torch.arange(K, device=DEV, dtype=torch.float32).remainder(97).to(torch.bfloat16)[None, :].contiguous()
+    got = llm.skinny_linear(x, w8, weight_scale=ws).float()[0]
+    want = torch.stack([x[0, (n * 37 + 5) % K].float() for n in range(N)])
+    assert torch.allclose(got, want, rtol=1e-2, atol=1e-2), (got, want)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,N,K,rt", [(1, 6144, 4096, 0), (9, 28672, 4096, 4), (16, 4096, 14336, 1), (3, 256, 128, 0)])
+def test_skinny_linear_with_tiled_weights_equals_the_row_major_run(fp8, M, N, K, rt):
+    torch.manual_seed(11)
+    w = _rand(N, K, scale=0.05)
+    x = _rand(M, K)
+    ws = None
+    if fp8:
+        w, ws = llm.quantize_fp8_rows(w)
+    t = llm.tile_weights(w)
+    assert torch.equal(llm.untile_weights(t).view(torch.uint8), w.view(torch.uint8))
+    a = llm.skinny_linear(x, w, rms=True, epilogue="swiglu", weight_scale=ws, row_tiles=rt)
+    b = llm.skinny_linear(x, t, rms=True, epilogue="swiglu", weight_scale=ws, row_tiles=rt, tiled=True)
+    assert torch.equal(a, b)                      # same products in the same order: bit-identical

@@ -60,6 +60,17 @@ def _rel_err(a, b):
 
 @pytest.mark.parametrize("n_seqs", [3, 20])          # 3: skinny decode path; 20: library GEMM decode path
 def test_gpu_logits_match_the_fp32_cpu_model(gpu_model, cpu_model, n_seqs):
+    _compare_logits(gpu_model, cpu_model, n_seqs)
+
+
+def test_fp8_decode_weights_match_the_fp32_cpu_model_with_the_dequantised_weights():
+    g = LlamaModel(SMALL, "cuda", seed=4).enable_fp8_decode()
+    c = LlamaModel(SMALL, "cpu", seed=0, dtype=torch.float32).load_from(g)     # the dequantised weights, no fp8
+    assert g.layers[0]["w_down8"].dtype == torch.float8_e4m3fn and not c.fp8_decode
+    _compare_logits(g, c, 5)
+
+
+def _compare_logits(gpu_model, cpu_model, n_seqs):
     g = torch.Generator().manual_seed(n_seqs)
     lens = [int(x) for x in torch.randint(5, 90, (n_seqs,), generator=g)]
     prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in lens]

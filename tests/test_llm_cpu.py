@@ -211,6 +211,21 @@ def test_stop_fails_the_requests_it_leaves_behind(model):
     assert eng.idle() and eng.alloc.free == eng.alloc.total
 
 
+def test_fp8_decode_weights_generate_what_the_dequantised_model_generates():
+    m = LlamaModel(TINY, "cpu", seed=5, dtype=torch.float32).enable_fp8_decode()
+    assert m.fp8_decode and m.layers[0]["wqkv8"].dtype == torch.float8_e4m3fn
+    w8 = llm.untile_weights(m.layers[0]["wqkv8"])
+    assert torch.equal(m.layers[0]["wqkv"], w8.float() * m.layers[0]["wqkv_s"][:, None])   # bf16 path = dequantised fp8
+    assert m.decode_stream_bytes() * 2 == m.weight_bytes() - TINY.vocab * TINY.hidden * 2
+    eng = _engine(m)
+    prompts = [[3, 1, 4, 1, 5, 9, 2, 6], [2, 7, 1, 8]]
+    reqs = [eng.submit(p, 10) for p in prompts]
+    _drain(eng)
+    for p, r in zip(prompts, reqs):
+        assert r.out == dense_generate(m, p, 10)      # prefill on the dequantised weights, decode on fp8 + scales
+    assert "fp8" in eng.describe()["decode_weights"]
+
+
 def test_exact_quantile():
     assert exact_quantile([], 0.5) is None
     assert exact_quantile([1.0, 2.0, 3.0, 4.0], 0.5) == 2.5

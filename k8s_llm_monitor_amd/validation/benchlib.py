@@ -64,6 +64,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     import torch
     import torch.distributed as dist
 
+    t_run0 = time.perf_counter()
+    wall: Dict[str, float] = {}
     size = a.size
     gemm = None
     if dev.type != "cuda":                      # --cpu-rehearsal
@@ -78,7 +80,11 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     extras["sampler"] = (sampler.describe() if sampler is not None else "off")
 
     extras["flop_per_step"] = load.flops
+    wall["setup"] = round(time.perf_counter() - t_run0, 2)
+    t_sec = time.perf_counter()
     dt = timed_steps(torch, dist, load, world, a.steps, a.warmup)
+    wall["warmup_and_timed_steps"] = round(time.perf_counter() - t_sec, 3)
+    wall["timed_steps_only"] = round(dt, 4)
     ms = dt / a.steps * 1e3
     tflops = load.flops * world / (dt / a.steps) / 1e12
     if world > 1:
@@ -90,6 +96,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     if sampler is not None:
         extras["sampler_stats"] = sampler.stats()
 
+    t_sec = time.perf_counter()
     if world > 1 and not getattr(a, "no_probe", False):
         # the RCCL all-reduce curve at this GPU count (outside the timed region)
         try:
@@ -119,6 +126,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             if rank == 0:
                 extras["xgmi_fidelity"] = {"error": f"{type(e).__name__}: {e}"}
 
+    wall["rccl_probe_and_xgmi_check"] = round(time.perf_counter() - t_sec, 2)
+    t_sec = time.perf_counter()
     if not a.no_validation and rank == 0 and dev.type == "cuda":
         # the other validation-load kernels, 1 s each (outside the timed region)
         try:
@@ -163,6 +172,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         except Exception as e:
             extras["llm_serving"] = {"error": f"{type(e).__name__}: {e}"}
 
+    wall["other_kernels_and_llm_serving"] = round(time.perf_counter() - t_sec, 2)
+    t_sec = time.perf_counter()
     if not a.no_validation:
         try:
             from . import phases
@@ -177,6 +188,10 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
 
     if sampler is not None:
         sampler.stop()
+    wall["validation_phases"] = round(time.perf_counter() - t_sec, 2)
+    wall["total"] = round(time.perf_counter() - t_run0, 2)
+    # only `timed_steps_only` enters `value`; everything else is reported, untimed work around it
+    extras["wall_seconds"] = wall
 
     return {
         "metric": "monitored validation-load throughput: bf16 MFMA burner training step (fwd+dgrad+wgrad GEMMs, DP all-reduce over RCCL) under telemetry sampling",

@@ -132,6 +132,8 @@ class Engine:
         self._wake = threading.Event()
         self._thread: Optional[threading.Thread] = None
         self._stop = threading.Event()
+        self.errors = 0
+        self.last_error: Optional[str] = None
         self.step_seconds = {"prefill": 0.0, "decode": 0.0}
         self.step_counts = {"prefill": 0, "decode": 0}
         # decode: static device inputs (graph capture needs stable pointers) + pinned host mirrors
@@ -214,7 +216,18 @@ class Engine:
                 batch.append(r)
                 tokens += n
         if batch:
-            return self._prefill(batch)
+            try:
+                return self._prefill(batch)
+            except Exception:
+                # the admitted requests are in neither queue yet: hand them back so that a failure
+                # handler (see _loop) can fail them and their blocks are not lost
+                with self._lock:
+                    for r in reversed(batch):
+                        if not r.done.is_set() and r not in self.running:
+                            self.alloc.release(r.blocks)
+                            r.blocks = []
+                            self.waiting.appendleft(r)
+                raise
         if self.running:
             return self._decode()
         return 0
@@ -386,9 +399,30 @@ class Engine:
         if self.on_gpu:
             torch.cuda.set_device(self.device)
         while not self._stop.is_set():
-            if self.step() == 0:
+            try:
+                n = self.step()
+            except Exception as e:      # a failed launch (out of memory, bad shape) must not strand the callers
+                self.last_error = f"{type(e).__name__}: {e}"
+                self.errors += 1
+                self._fail_all(self.last_error)
+                n = 0
+            if n == 0:
                 self._wake.wait(0.05)
                 self._wake.clear()
+
+    def _fail_all(self, why: str) -> None:
+        now = self.clock()
+        with self._lock:
+            for r in list(self.waiting) + list(self.running):
+                if r.blocks:
+                    self.alloc.release(r.blocks)
+                r.blocks = []
+                r.error = why
+                r.t_done = now
+                r.done.set()
+            self.waiting.clear()
+            self.running = []
+            self.metrics.set_queue(0, 0, self.alloc.usage)
 
     def stop(self, abort_pending: bool = True) -> None:
         """Stop the background loop; requests still queued or running are failed (their `done` event
@@ -399,17 +433,7 @@ class Engine:
             self._thread.join(timeout=30)
             self._thread = None
         if abort_pending:
-            now = self.clock()
-            with self._lock:
-                for r in list(self.waiting) + list(self.running):
-                    self.alloc.release(r.blocks)
-                    r.blocks = []
-                    r.error = "engine stopped"
-                    r.t_done = now
-                    r.done.set()
-                self.waiting.clear()
-                self.running = []
-                self.metrics.set_queue(0, 0, self.alloc.usage)
+            self._fail_all("engine stopped")
 
     def describe(self) -> Dict[str, object]:
         return {"model": self.mcfg.name, "params": self.mcfg.params(), "weight_bytes": self.model.weight_bytes(),
@@ -417,4 +441,5 @@ class Engine:
                 "kv_bytes": self.cache.nbytes, "max_num_seqs": self.cfg.max_num_seqs, "max_model_len": self.max_len,
                 "graphs": sorted(self._graphs), "device": str(self.device),
                 "decode_weights": "fp8 (W8A16, batch <= 16)" if self.model.fp8_decode else "bf16",
-                "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts)}
+                "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts),
+                "errors": self.errors, "last_error": self.last_error}

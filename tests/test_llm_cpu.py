@@ -226,6 +226,30 @@ def test_fp8_decode_weights_generate_what_the_dequantised_model_generates():
     assert "fp8" in eng.describe()["decode_weights"]
 
 
+def test_a_failing_model_launch_fails_the_requests_instead_of_hanging_them(model):
+    eng = _engine(model)
+    boom = {"n": 0}
+    real = eng._prefill
+
+    def broken(batch):
+        boom["n"] += 1
+        if boom["n"] == 1:
+            raise RuntimeError("HIP out of memory (simulated)")
+        return real(batch)
+
+    eng._prefill = broken
+    eng.start()
+    try:
+        a = eng.submit([1, 2, 3], 4)
+        assert a.done.wait(10) and "out of memory" in a.error
+        b = eng.submit([1, 2, 3], 4)                     # the engine keeps serving afterwards
+        assert b.done.wait(30) and b.error is None and len(b.out) == 4
+    finally:
+        eng.stop()
+    d = eng.describe()
+    assert d["errors"] == 1 and "simulated" in d["last_error"] and eng.alloc.free == eng.alloc.total
+
+
 def test_exact_quantile():
     assert exact_quantile([], 0.5) is None
     assert exact_quantile([1.0, 2.0, 3.0, 4.0], 0.5) == 2.5

@@ -88,6 +88,8 @@ def test_full_duty_burner_rates(torch_dev):
     assert out["duty_achieved"] > 97.0 and out["tflops_avg"] > 1000.0
     out = Burner("gemm_fp8", size=8192, duty=100.0).run(1.0)
     assert out["tflops_avg"] > 1500.0
+    out = Burner("gemm_fp4", size=8192, duty=100.0).run(1.0)
+    assert out["tflops_avg"] > 2500.0
     out = Burner("hbm_copy", duty=100.0).run(1.0)
     assert out["TBps_busy"] > 3.0
 
@@ -186,5 +188,7 @@ def test_standalone_cpp_burner(torch_dev):
     assert abs(fin["duty_achieved"] - 50.0) < 5.0 and fin["tflops_busy"] > 900 and any("t" in l for l in out[:-1])
     fin = run("--kind", "gemm_fp8", "--seconds", "1.5")[-1]
     assert fin["duty_achieved"] > 97.0 and fin["tflops_avg"] > 1500
+    fin = run("--kind", "gemm_fp4", "--seconds", "1.5")[-1]
+    assert fin["duty_achieved"] > 97.0 and fin["tflops_avg"] > 2500
     out = run("--kind", "hbm_copy", "--seconds", "1.5", "--hbm-gib", "8")
     assert out[0] == {"hbm_hold_gib": 8.0} and out[-1]["TBps_busy"] > 3.5

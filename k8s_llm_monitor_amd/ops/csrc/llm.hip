@@ -228,14 +228,18 @@ struct Acc {
 // lim (wave-uniform): every row IN USE has qpos >= lim, so a step whose last key is <= lim needs no
 // mask at all (rows not in use carry q = 0: their scores stay finite and their output is dropped).
 // The softmax keeps m in the scaled log2 domain and costs one max, one FMA and one exp2 per score.
-__device__ __forceinline__ void attend_step(const Frags& f, const bf16x8 (&qf)[4], int step, int fq,
-                                            int qpos, int lim, float scale_log2, Acc& a) {
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void qk_scores(const bf16x8 (&k)[2][4], const bf16x8 (&qf)[4], f32x4& s0, f32x4& s1) {
+  s0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  s1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.k[0][s], qf[s], s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.k[1][s], qf[s], s1, 0, 0, 0);
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][s], qf[s], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][s], qf[s], s1, 0, 0, 0);
   }
+}
+
+__device__ __forceinline__ void softmax_pv(const f32x4& s0, const f32x4& s1, const bf16x8 (&v)[8], int step, int fq,
+                                           int qpos, int lim, float scale_log2, Acc& a) {
   float x[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -272,7 +276,14 @@ __device__ __forceinline__ void attend_step(const Frags& f, const bf16x8 (&qf)[4
     for (int n = 0; n < 8; ++n) a.o[n] *= alpha;
   }
 #pragma unroll
-  for (int n = 0; n < 8; ++n) a.o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v[n], p, a.o[n], 0, 0, 0);
+  for (int n = 0; n < 8; ++n) a.o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[n], p, a.o[n], 0, 0, 0);
+}
+
+__device__ __forceinline__ void attend_step(const Frags& f, const bf16x8 (&qf)[4], int step, int fq,
+                                            int qpos, int lim, float scale_log2, Acc& a) {
+  f32x4 s0, s1;
+  qk_scores(f.k, qf, s0, s1);
+  softmax_pv(s0, s1, f.v, step, fq, qpos, lim, scale_log2, a);
 }
 
 __device__ __forceinline__ void load_q(const uint16_t* qrow, bool valid, int fq, bf16x8 (&qf)[4]) {
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const int* __restrict__ block_tables, const int* __restrict__ seq_info, const int* __restrict__ tiles,
     uint16_t* __restrict__ out, int n_seqs, int q_stride, int n_q, int n_kv, int G, int g_shift,
     int max_blocks, int nb_total, float scale_log2) {
-  const int tile = blockIdx.x, h = blockIdx.y;
+  const int h = blockIdx.x, tile = blockIdx.y;   // heads fastest: the tile table is sorted heaviest first
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -563,18 +574,21 @@ __device__ __forceinline__ void pf_issue(const KvView& kv, int st, char* stage, 
   }
 }
 
-__device__ __forceinline__ void pf_read(const char* stage, int fr, int fq, Frags& f) {
+__device__ __forceinline__ void pf_read_k(const char* stage, int fr, int fq, bf16x8 (&k)[2][4]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int tok = ((fr >> 2) << 3) + t * 4 + (fr & 3);
     const int key = (tok & 15) ^ ((tok >> 4) << 2);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      f.k[t][s] = *reinterpret_cast<const bf16x8*>(stage + tok * 256 + (((s * 4 + fq) ^ key) << 4));
+      k[t][s] = *reinterpret_cast<const bf16x8*>(stage + tok * 256 + (((s * 4 + fq) ^ key) << 4));
   }
+}
+
+__device__ __forceinline__ void pf_read_v(const char* stage, int fr, int fq, bf16x8 (&v)[8]) {
   const char* vp = stage + 8192 + (fq >> 1) * 4096 + fr * 32 + (fq & 1) * 16;
 #pragma unroll
-  for (int n = 0; n < 8; ++n) f.v[n] = *reinterpret_cast<const bf16x8*>(vp + n * 512);
+  for (int n = 0; n < 8; ++n) v[n] = *reinterpret_cast<const bf16x8*>(vp + n * 512);
 }
 
 template <int QT>
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
     uint16_t* __restrict__ out, int n_seqs, int q_stride, int n_q, int n_kv, int G, int g_shift,
     int max_blocks, int nb_total, float scale_log2) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
-  const int tile = blockIdx.x, h = blockIdx.y;
+  const int h = blockIdx.x, tile = blockIdx.y;   // heads fastest: the tile table is sorted heaviest first
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -649,7 +663,9 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
     for (int t = 0; t < QT; ++t) any = any || (st < nst[t]);
     if (any) {
       Frags f;
-      pf_read(ring + (st & (PF_STAGES - 1)) * PF_STAGE_BYTES, fr, fq, f);
+      const char* stage = ring + (st & (PF_STAGES - 1)) * PF_STAGE_BYTES;
+      pf_read_k(stage, fr, fq, f.k);
+      pf_read_v(stage, fr, fq, f.v);
 #pragma unroll
       for (int t = 0; t < QT; ++t)
         if (st < nst[t]) attend_step(f, qf[t], st, fq, qpos[t], lim[t], scale_log2, a[t]);
@@ -955,7 +971,7 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
                            int q_tiles, int variant, void* stream) {
   if ((q_tiles != 1 && q_tiles != 2 && q_tiles != 4) || variant < 0 || variant > 1) return KLM_ERR_VARIANT;
   if (q_stride < n_q * HD || q_stride % 8 != 0) return KLM_ERR_SHAPE;
-  if (n_tiles <= 0 || n_seqs <= 0 || n_q <= 0 || n_kv <= 0 || n_kv > 65535 || n_q % n_kv != 0 ||
+  if (n_tiles <= 0 || n_tiles > 65535 || n_seqs <= 0 || n_q <= 0 || n_kv <= 0 || n_q % n_kv != 0 ||
       max_blocks <= 0 || num_blocks_total <= 0)
     return KLM_ERR_SHAPE;
   const int G = n_q / n_kv, gs = group_shift(G);
@@ -964,11 +980,11 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
   if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) return KLM_ERR_ALIGN;
   const float scale_log2 = scale * 1.4426950408889634f;
 #define KLM_PREFILL(QT)                                                                                          \
-  hipLaunchKernelGGL((paged_attn_prefill_kernel<QT>), dim3(n_tiles, n_kv), dim3(256), 0,                         \
+  hipLaunchKernelGGL((paged_attn_prefill_kernel<QT>), dim3(n_kv, n_tiles), dim3(256), 0,                         \
                      static_cast<hipStream_t>(stream), (const uint16_t*)q, (const uint16_t*)k_cache,             \
                      (const uint16_t*)v_cache, block_tables, seq_info, tiles, (uint16_t*)out, n_seqs, q_stride,  \
                      n_q, n_kv, G, gs, max_blocks, num_blocks_total, scale_log2)
-#define KLM_PREFILL_LDS(QT)                                                                                      \
+#define KLM_PREFILL_LDS(QT)                                                                                        \
   do {                                                                                                           \
     static bool attr_done = false;                                                                               \
     if (!attr_done) {                                                                                            \
@@ -977,7 +993,7 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
         return KLM_ERR_HIP;                                                                                      \
       attr_done = true;                                                                                          \
     }                                                                                                            \
-    hipLaunchKernelGGL((paged_attn_prefill_lds_kernel<QT>), dim3(n_tiles, n_kv), dim3(256),                      \
+    hipLaunchKernelGGL((paged_attn_prefill_lds_kernel<QT>), dim3(n_kv, n_tiles), dim3(256),                      \
                        PF_STAGES * PF_STAGE_BYTES, static_cast<hipStream_t>(stream), (const uint16_t*)q,         \
                        (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, seq_info, tiles,        \
                        (uint16_t*)out, n_seqs, q_stride, n_q, n_kv, G, gs, max_blocks, num_blocks_total,         \

@@ -313,22 +313,31 @@ PREFILL_VARIANT = 1      # 1: K/V staged once per block through the LDS ring; 0:
 
 
 def pick_q_tiles(q_lens: Sequence[int], group: int, n_kv: int) -> int:
-    """2 query tiles per wave (half the LDS reads per MFMA) once that still leaves every CU two
-    blocks; 1 for short prompts, where the grid would not fill the chip (scripts/gpu_attn_bench.py:
-    512 tokens 20 us vs 28 us, 8192 tokens 1194 us vs 1083 us)."""
+    """2 query tiles per wave (half the LDS reads per MFMA) once that still leaves every CU four
+    blocks; 1 for shorter prompts, where the grid would not fill the chip (scripts/gpu_attn_bench.py,
+    one sequence: 2048 tokens 80 us vs 93 us, 4096 tokens 257 us vs 211 us, 8192 tokens 927 us vs 743 us)."""
     per = 2 * 64 // group
     blocks = sum(-(-int(n) // per) for n in q_lens) * n_kv
-    return 2 if blocks >= 512 else 1
+    return 2 if blocks >= 1024 else 1
 
 
-def prefill_tiles(q_lens: Sequence[int], group: int, q_tiles: int = PREFILL_Q_TILES) -> torch.Tensor:
+def prefill_tiles(q_lens: Sequence[int], group: int, q_tiles: int = PREFILL_Q_TILES,
+                  ctx_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Host-side tile table of the prefill kernel: int32 [n_tiles, 2] = (sequence, first query token);
-    one tile = q_tiles * 64 / group query tokens."""
+    one tile = q_tiles * 64 / group query tokens. Tiles are ordered by the number of keys they attend
+    to, longest first: causal attention makes the last tile of a 4096-token prompt 128x the work of
+    the first, and in launch order the chip drained to 0.28 waves per SIMD on average (rocprofv3
+    SQ_WAVE_CYCLES) while the late tiles ran alone. `ctx_lens` (default: q_lens) gives the context
+    length of each sequence when the queries are a chunk of a longer context."""
     per = q_tiles * 64 // group
-    rows: List[Tuple[int, int]] = []
+    ctx = list(q_lens) if ctx_lens is None else list(ctx_lens)
+    rows: List[Tuple[int, int, int]] = []
     for s, n in enumerate(q_lens):
-        rows.extend((s, t) for t in range(0, int(n), per))
-    return torch.tensor(rows, dtype=torch.int32).reshape(-1, 2)
+        n = int(n)
+        for t in range(0, n, per):
+            rows.append((int(ctx[s]) - n + min(t + per, n), s, t))       # keys seen by the tile's last query
+    rows.sort(key=lambda r: -r[0])
+    return torch.tensor([(s, t) for (_, s, t) in rows], dtype=torch.int32).reshape(-1, 2)
 
 
 def paged_attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,

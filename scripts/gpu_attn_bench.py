@@ -35,7 +35,7 @@ for n_seqs, L in ((1, 512), (1, 2048), (1, 4096), (1, 8192), (8, 1024)):
     q = torch.randn(n_seqs * L, (n_q + 2 * n_kv) * 128, device=DEV).to(torch.bfloat16)
     flops = 4.0 * n_q * 128 * n_seqs * L * (L + 1) / 2
     line = f"prefill {n_seqs}x{L}:"
-    for var, qt in ((0, 1), (0, 2), (1, 1), (1, 2), (1, 4)):
+    for var, qt in ((0, 1), (0, 2), (1, 1), (1, 2)):
         tiles = llm.prefill_tiles([L] * n_seqs, n_q // n_kv, qt).to(DEV)
         us = t(lambda: llm.paged_attn_prefill(q, kc, vc, bt, info, tiles, scale, n_q, q_tiles=qt, variant=var))
         line += f"  v{var}qt{qt} {us:7.1f}us {flops / us / 1e6:5.0f}TF"

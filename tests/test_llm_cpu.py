@@ -263,10 +263,11 @@ def test_cpu_dispatch_of_the_ops_matches_the_reference():
     o = llm.rmsnorm(x, w, 1e-5, residual=res)
     want, nr = ref.rmsnorm(x, w, 1e-5, residual=r0)
     assert torch.equal(o, want) and torch.equal(res, nr)
-    assert llm.prefill_tiles([5, 40], 4, 1).tolist() == [[0, 0], [1, 0], [1, 16], [1, 32]]
-    assert llm.prefill_tiles([5, 40], 4, 2).tolist() == [[0, 0], [1, 0], [1, 32]]
+    assert llm.prefill_tiles([5, 40], 4, 1).tolist() == [[1, 32], [1, 16], [1, 0], [0, 0]]     # longest context first
+    assert llm.prefill_tiles([5, 40], 4, 2).tolist() == [[1, 32], [1, 0], [0, 0]]
+    assert llm.prefill_tiles([8, 8], 4, 1, ctx_lens=[8, 300]).tolist() == [[1, 0], [0, 0]]
     assert llm.pick_splits(1, 8, 8192) == 32 and llm.pick_splits(64, 8, 8192) == 1 and llm.pick_splits(1, 8, 256) == 2
-    assert llm.pick_q_tiles([512], 4, 8) == 1 and llm.pick_q_tiles([4096], 4, 8) == 2
+    assert llm.pick_q_tiles([2048], 4, 8) == 1 and llm.pick_q_tiles([4096], 4, 8) == 2
 
 
 def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model):

@@ -326,8 +326,8 @@ def prefill_tiles(q_lens: Sequence[int], group: int, q_tiles: int = PREFILL_Q_TI
     """Host-side tile table of the prefill kernel: int32 [n_tiles, 2] = (sequence, first query token);
     one tile = q_tiles * 64 / group query tokens. Tiles are ordered by the number of keys they attend
     to, longest first: causal attention makes the last tile of a 4096-token prompt 128x the work of
-    the first, and in launch order the chip drained to 0.28 waves per SIMD on average (rocprofv3
-    SQ_WAVE_CYCLES) while the late tiles ran alone. `ctx_lens` (default: q_lens) gives the context
+    the first, and in launch order the chip ran about 40 % empty (rocprofv3 SQ_WAVE_CYCLES) while the
+    late tiles of the last head finished alone. `ctx_lens` (default: q_lens) gives the context
     length of each sequence when the queries are a chunk of a longer context."""
     per = q_tiles * 64 // group
     ctx = list(q_lens) if ctx_lens is None else list(ctx_lens)

@@ -9,7 +9,6 @@ import numpy as np
 import torch
 
 from ..models.llama import BLOCK, PrefillMeta
-from ..ops import llm
 from .engine import Engine
 
 

@@ -58,9 +58,6 @@ def wait_up(url, t=10):
 def main():
     clients = int(os.environ.get("CLIENTS", "8")); seconds = float(os.environ.get("SECONDS", "3"))
     from k8s_llm_monitor_amd.fakes.prometheus import FakePrometheus
-    from k8s_llm_monitor_amd.config import demo_config
-    from k8s_llm_monitor_amd.server.http import MonitorServer
-    from k8s_llm_monitor_amd.server.sampler import Monitor
     prom = FakePrometheus(port=9090).start()
     out = {"clients": clients, "seconds": seconds, "endpoints": {}}
     ref = None

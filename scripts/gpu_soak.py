@@ -1,6 +1,6 @@
 """End-to-end soak on one MI355X (BASELINE.json config 2): the real server on amdsmi, a 50 % duty
 MFMA burner and an HBM hold that crosses the 70 % tier, everything observed through HTTP only."""
-import json, os, sys, threading, time, urllib.request
+import json, os, sys, time, urllib.request
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from k8s_llm_monitor_amd.config import load_config

@@ -163,7 +163,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p = sub.add_parser("validate")
     p.add_argument("--out", default="")
     p.add_argument("--quick", action="store_true")
-    p.add_argument("--phases", default="all", help="all or a comma list of hbm,activity,mem,overhead,latency,vllm")
+    p.add_argument("--phases", default="all", help="all or a comma list of hbm,activity,mem,overhead,latency,llm,vllm")
     p.add_argument("--device", type=int, default=0)
     p = sub.add_parser("serve-llm")
     p.add_argument("--model", default="llama3-8b", help="llama3-8b, llama3-70b, small, tiny")

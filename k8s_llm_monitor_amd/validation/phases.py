@@ -383,6 +383,49 @@ def vllm_fidelity(torch, dev, model: str = "llama3-8b", seconds: float = 20.0, p
     return out
 
 
+def llm_activity(torch, dev, src, smi_idx: int, seconds: float = 2.5, model: str = "llama3-8b") -> Dict[str, Any]:
+    """What the GPU cards of the dashboard show while an LLM is served: the same model in three regimes
+    (decode at batch 1 = weight streaming, decode at batch 64 = weights + KV cache, prefill = GEMMs), each
+    held for `seconds` of back-to-back model launches. GFX activity reads ~100 % in all three while the
+    memory-controller activity and the power tell them apart."""
+    from ..serving import Engine, EngineConfig
+    from ..serving import bench as sb
+    eng = Engine(EngineConfig(model=model, device=str(dev), max_num_seqs=64, max_model_len=4096, kv_blocks=8192))
+    eng.warmup([1, 64])
+    rows = []
+
+    def hold(name: str, once, detail: Dict[str, Any]) -> None:
+        once()
+        torch.cuda.synchronize(dev)
+        src.sample()
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            once()
+            n += 1
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        s = _gpu_sample(src, smi_idx)
+        rows.append(dict(detail, regime=name, launches=n, ms_per_launch=dt / n * 1e3,
+                         gfx_activity_avg=s.get("gfxActivityAvg"), mem_activity_avg=s.get("memActivityAvg"),
+                         power_w=s.get("powerW"), clock_gfx_mhz=s.get("clockGfxMHz")))
+
+    try:
+        for b in (1, 64):
+            r = sb.decode_step_ms(eng, b, 1024, iters=3)
+            bucket = int(r["bucket"])
+            hold(f"decode batch {b}", lambda: eng._run_decode(bucket),
+                 {"tokens_per_s": r["tokens_per_s"], "TBps": r["TBps"]})
+        p = sb.prefill_ms(eng, 4, 1024, iters=1)
+        hold("prefill 4 x 1024", lambda: sb.prefill_ms(eng, 4, 1024, iters=1, warmup=0),
+             {"tokens_per_s": p["tokens_per_s"], "TFLOPs": p["TFLOPs"]})
+    finally:
+        del eng
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    return {"model": model, "rows": rows}
+
+
 # ------------------------------------------------------------------------------------------
 def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=None, a=None,
             quick: bool = True, which: str = "all") -> Dict[str, Any]:
@@ -392,7 +435,7 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
         return {}
     from ..collectors.gpu import open_gpu_source
     out: Dict[str, Any] = {}
-    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "mem", "overhead", "latency", "vllm"}
+    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "mem", "overhead", "latency", "llm", "vllm"}
     src = open_gpu_source("amdsmi")
     try:
         idx = _smi_index_for(torch, dev, src)
@@ -418,6 +461,8 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
             guard("overhead", lambda: overhead(torch, dev, seconds=3.0 if quick else 8.0, repeats=2 if quick else 3))
         if "latency" in want:
             guard("alert_latency", lambda: alert_latency(torch, dev))
+        if "llm" in want:
+            guard("llm_activity", lambda: llm_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
         if "vllm" in want:
             guard("vllm_fidelity", lambda: vllm_fidelity(torch, dev, seconds=12.0 if quick else 30.0,
                                                          period_s=3.0 if quick else 5.0))

@@ -41,6 +41,7 @@ class AlertState:
     pods: Dict[str, Dict[str, Any]] = field(default_factory=dict)   # "ns/name" -> {status, restarts, age}
     gpu_count: Optional[int] = None
     ecc_correctable: Dict[int, int] = field(default_factory=dict)
+    vllm_endpoints: int = 0          # most vLLM endpoints ever seen answering (0 = never seen: no "down" alert)
     evaluations: int = 0
 
 
@@ -108,6 +109,7 @@ _MSG = {
         "xgmi": ("GPU{g} xGMI 链路断开", "链路 {l} 状态 down{peer}", "建议：1. amd-smi xgmi 检查链路 2. RCCL 集合通信将绕行或失败，尽快隔离该节点"),
         "throttle_thm": ("GPU{g} 温度降频中", "降频原因: {r}", "建议：检查散热，降低负载；性能数据在降频期间不可信"),
         "throttle_ppt": ("GPU{g} 功耗受限降频", "功耗限制驻留 {p}%", "建议：满载时属正常；若影响吞吐可调整 power cap 或错峰"),
+        "vllm_down": ("vLLM 服务不可达", "{n}/{m} 个 vLLM 端点有响应", "建议：1. kubectl get pods 查看推理 Pod 2. 查看 Pod 日志 (OOM / HIP 错误) 3. 检查 /metrics 端口与网络策略"),
         "gpu_lost": ("GPU 数量减少", "检测到 {n} 张 GPU，之前为 {m} 张", "建议：1. dmesg 查看 amdgpu 错误 2. amd-smi list 3. 必要时重置或下线节点"),
         "pod_failed": ("Pod 异常: {name}", "命名空间: {ns}, 状态: {st}", "建议：kubectl describe pod {name} -n {ns}"),
         "pod_pending": ("Pod 等待调度: {name}", "命名空间: {ns}", "建议：kubectl describe pod {name} -n {ns}"),
@@ -160,6 +162,7 @@ _MSG["en"] = {
     "xgmi": ("GPU{g} xGMI link down", "link {l} is down{peer}", "Check amd-smi xgmi; RCCL collectives will reroute or fail; isolate the node"),
     "throttle_thm": ("GPU{g} thermal throttling", "reasons: {r}", "Check cooling, reduce load; performance numbers are unreliable while throttled"),
     "throttle_ppt": ("GPU{g} power-limited", "power-limit residency {p}%", "Normal at full load; raise the cap or spread load if throughput matters"),
+    "vllm_down": ("vLLM endpoint unreachable", "{n} of {m} vLLM endpoint(s) answering", "kubectl get pods for the serving pods; read their logs (OOM / HIP errors); check the /metrics port and network policy"),
     "gpu_lost": ("GPU count dropped", "{n} GPU(s) visible, {m} before", "Check dmesg for amdgpu errors; amd-smi list; reset or drain the node"),
     "pod_failed": ("Pod failed: {name}", "namespace: {ns}, status: {st}", "kubectl describe pod {name} -n {ns}"),
     "pod_pending": ("Pod pending: {name}", "namespace: {ns}", "kubectl describe pod {name} -n {ns}"),
@@ -318,6 +321,17 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
                  d.format(reason=reason, **fmt), f.format(**fmt), signal="pod")
 
     # ---- vLLM serving metrics (no reference rule)
+    # an endpoint that answered once and no longer does is an outage, not "no data": level-triggered,
+    # critical when nothing answers, serious when some replicas are gone (direct scraping counts them)
+    n_ep = 0
+    if vllm:
+        e = vllm.get("endpoints")
+        n_ep = int(e) if isinstance(e, (int, float)) and e > 0 else 1
+    if state.vllm_endpoints and n_ep < state.vllm_endpoints:
+        t, d, f = msgs["vllm_down"]
+        _add(alerts, "critical" if n_ep == 0 else "serious", "vllm/down", t, d.format(n=n_ep, m=state.vllm_endpoints), f,
+             signal="vllm_down")
+    next_vllm_endpoints = max(n_ep, state.vllm_endpoints)
     if vllm:
         kv = vllm.get("kvCachePercent")
         if isinstance(kv, (int, float)):
@@ -331,7 +345,7 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
             _tiered(alerts, msgs, "ttft", "vllm/ttft", float(ttft), th.vllm_ttft_p99_s, msgs["ttft_desc"].format(v=_fmt(ttft, 2)))
 
     nxt = AlertState(pods=cur_pods, gpu_count=next_gpu_count, ecc_correctable=next_ecc,
-                     evaluations=state.evaluations + 1)
+                     vllm_endpoints=next_vllm_endpoints, evaluations=state.evaluations + 1)
     return alerts, nxt
 
 

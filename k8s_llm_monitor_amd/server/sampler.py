@@ -210,7 +210,8 @@ class Monitor:
         with self._lock:
             st = self._alert_state
             doc = {"saved": self.clock(), "pods": st.pods, "gpu_count": st.gpu_count,
-                   "ecc_correctable": {str(k): v for k, v in st.ecc_correctable.items()}, "evaluations": st.evaluations}
+                   "ecc_correctable": {str(k): v for k, v in st.ecc_correctable.items()},
+                   "vllm_endpoints": st.vllm_endpoints, "evaluations": st.evaluations}
         tmp = self._state_path(f"alert_state.json.tmp.{os.getpid()}")
         with open(tmp, "w", encoding="utf-8") as f:
             json.dump(doc, f)
@@ -225,6 +226,7 @@ class Monitor:
             if self.clock() - float(d.get("saved", 0.0)) <= max_age_s:       # a stale pod table would raise false edges
                 self._alert_state = AlertState(pods={str(k): dict(v) for k, v in d["pods"].items()}, gpu_count=d.get("gpu_count"),
                                                ecc_correctable={int(k): int(v) for k, v in (d.get("ecc_correctable") or {}).items()},
+                                               vllm_endpoints=int(d.get("vllm_endpoints", 0)),
                                                evaluations=int(d.get("evaluations", 0)))
                 self.restored["alert_state"] = True
         except (OSError, ValueError, KeyError, TypeError, AttributeError):

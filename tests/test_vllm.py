@@ -82,3 +82,26 @@ def test_open_source_selection():
     s = open_vllm_source("auto", cfg)
     assert s.kind == "direct" and s.endpoints == ["http://a:8000/metrics", "http://b:8000/metrics"]
     assert open_vllm_source("auto", Config(), PrometheusClient("http://127.0.0.1:9", timeout=0.2)).kind == "none"
+
+
+def test_a_vllm_endpoint_that_stops_answering_raises_an_outage_alert():
+    """Never seen -> silence; seen and gone -> critical; one of two replicas gone -> serious; back -> clear."""
+    from k8s_llm_monitor_amd.config import load_config
+    from k8s_llm_monitor_amd.server.alerts import AlertState, check_alerts
+    cfg = load_config(env={})
+    host = {"cpu": {"percent": "1.0"}, "memory": {"percent": "1.0"}, "disk": {"percent": "1"}}
+    up2 = {"available": True, "endpoints": 2, "kvCachePercent": 10.0, "waiting": 0, "running": 1}
+    up1 = dict(up2, endpoints=1)
+    keys = lambda a: {x["key"]: x["tier"] for t in a.values() for x in t}
+    a, st = check_alerts(host, [], [], AlertState(), cfg, None)
+    assert "vllm/down" not in keys(a) and st.vllm_endpoints == 0          # nothing configured / never up
+    a, st = check_alerts(host, [], [], st, cfg, up2)
+    assert "vllm/down" not in keys(a) and st.vllm_endpoints == 2
+    a, st = check_alerts(host, [], [], st, cfg, up1)
+    assert keys(a)["vllm/down"] == "serious" and "1 of 2" in a["serious"][0]["desc"] or "1/2" in a["serious"][0]["desc"]
+    a, st = check_alerts(host, [], [], st, cfg, None)
+    assert keys(a)["vllm/down"] == "critical"
+    a, st = check_alerts(host, [], [], st, cfg, None)
+    assert keys(a)["vllm/down"] == "critical"                             # level-triggered while it lasts
+    a, st = check_alerts(host, [], [], st, cfg, up2)
+    assert "vllm/down" not in keys(a)

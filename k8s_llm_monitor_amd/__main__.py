@@ -102,7 +102,7 @@ def _cmd_serve_llm(a) -> int:
     from .serving.server import LlmServer
     eng = Engine(EngineConfig(model=a.model, device=a.device, max_num_seqs=a.max_num_seqs, max_model_len=a.max_model_len,
                               kv_blocks=a.kv_blocks, kv_fraction=a.kv_fraction, use_graphs=not a.no_graphs,
-                              decode_weights=a.decode_weights))
+                              decode_weights=a.decode_weights, kv_cache_dtype=a.kv_cache_dtype))
     eng.warmup()
     eng.start()
     srv = LlmServer(eng, host=a.host, port=a.port).start()
@@ -177,6 +177,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--no-graphs", action="store_true")
     p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                    help="fp8: W8A16 weight copies for decode at batch <= 16 (half the bytes per token)")
+    p.add_argument("--kv-cache-dtype", default="bf16", choices=["bf16", "fp8"],
+                   help="fp8: e4m3 KV cache, twice the tokens per GB and half the attention bytes")
     p.add_argument("--load-rps", type=float, default=0.0, help="built-in open-loop load (requests per second)")
     p.add_argument("--prompt-len", type=int, default=512)
     p.add_argument("--output-len", type=int, default=128)

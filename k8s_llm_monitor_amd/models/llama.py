@@ -81,16 +81,19 @@ PRESETS: Dict[str, LlamaConfig] = {
 
 class KVCache:
     """Paged cache of every layer: K [L, blocks, n_kv, 16, 128], V [L, blocks, n_kv, 128, 16]; zero
-    initialised (the attention kernels read stale slots and multiply them by zero)."""
+    initialised (the attention kernels read stale slots and multiply them by zero). dtype bf16 (or the
+    model's dtype on CPU), or ``torch.float8_e4m3fn``: e4m3 bytes with unit scale, converted back to bf16
+    fragments inside the attention kernels; half the bytes per token, twice the tokens per GB."""
 
     def __init__(self, cfg: LlamaConfig, num_blocks: int, device, dtype=torch.bfloat16):
         self.num_blocks = int(num_blocks)
+        self.dtype = dtype
         self.k = torch.zeros((cfg.layers, num_blocks, cfg.n_kv, BLOCK, HEAD_DIM), dtype=dtype, device=device)
         self.v = torch.zeros((cfg.layers, num_blocks, cfg.n_kv, HEAD_DIM, BLOCK), dtype=dtype, device=device)
 
     @staticmethod
-    def bytes_per_block(cfg: LlamaConfig) -> int:
-        return cfg.kv_bytes_per_token() * BLOCK
+    def bytes_per_block(cfg: LlamaConfig, dtype=torch.bfloat16) -> int:
+        return cfg.kv_bytes_per_token() * BLOCK * (1 if dtype == torch.float8_e4m3fn else 2) // 2
 
     @property
     def nbytes(self) -> int:
@@ -184,8 +187,8 @@ class LlamaModel:
             n += sum(L[k].numel() for k in self._PROJ)
         return n * per
 
-    def new_cache(self, num_blocks: int) -> KVCache:
-        return KVCache(self.cfg, num_blocks, self.device, self.dtype)
+    def new_cache(self, num_blocks: int, dtype=None) -> KVCache:
+        return KVCache(self.cfg, num_blocks, self.device, dtype or self.dtype)
 
     # ------------------------------------------------------------------ the decoder stack
     def _stack(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:

@@ -65,6 +65,8 @@ int klm_spin(uint64_t cycles, int blocks, void* stream);
 // ---- LLM serving kernels (llm.hip): bf16, head_dim 128, KV blocks of 16 tokens --------------
 // K cache [num_blocks][n_kv][16][128], V cache [num_blocks][n_kv][128][16] (transposed), both
 // bf16 and zero-initialised by the caller (stale slots are read and multiplied by zero).
+// kv_fp8 != 0 in the three calls below: the caches hold OCP e4m3 bytes (unit scale) in the same
+// layouts; q, the in-place k and every output stay bf16. Prefill then always runs variant 0.
 //
 // out = rmsnorm(x) * weight; with `residual` != NULL: residual <- x + residual first, and the
 // norm is taken of the new residual. H % 8 == 0, H <= 8192.
@@ -77,7 +79,7 @@ int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream);
 // (= block * 16 + offset; a negative slot skips the write).
 int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
                    void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
-                   void* stream);
+                   int kv_fp8, void* stream);
 // Decode attention: q (row b at q + b*q_stride elements, n_q heads of 128), block_tables[B][max_blocks],
 // ctx_lens[B] -> out[B][n_q][128]. q_stride lets q be a view of the fused qkv activation.
 // num_splits > 1 splits each context over that many blocks (flash decoding); then
@@ -85,7 +87,7 @@ int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, co
 int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                           const int32_t* ctx_lens, void* out, float* tmp_o, float* tmp_ml, int B, int q_stride,
                           int n_q, int n_kv, int max_blocks, int num_blocks_total, int num_splits, float scale,
-                          void* stream);
+                          int kv_fp8, void* stream);
 // Causal prefill over the paged cache (the keys of the queries are already in it).
 // seq_info[n_seqs][3] = {q_start, q_len, ctx_len}; tiles[n_tiles][2] = {sequence, first query
 // token of the tile}; a tile covers q_tiles * 64 / (n_q / n_kv) query tokens (q_tiles = 16-row
@@ -94,7 +96,7 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
 int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                            const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
                            int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,
-                           int q_tiles, int variant, void* stream);
+                           int q_tiles, int variant, int kv_fp8, void* stream);
 
 // Skinny linear layer for decode (M <= 16): out[M][N] = x[M][K] . W[N][K]^T, W streamed once.
 // rms != 0: rows are scaled by rsqrt(mean(x^2) + eps) (RMSNorm whose gain is folded into W).

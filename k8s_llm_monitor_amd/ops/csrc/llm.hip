@@ -66,6 +66,24 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
   return r;
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// 8 e4m3 bytes (two dwords, k order = byte order) -> one bf16 MFMA fragment
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
+  const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, false);
+  const bf16x2 p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, true);
+  const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, false);
+  const bf16x2 p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, true);
+  bf16x8 r;
+  r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
+  r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
+  return r;
+}
+// one float -> one e4m3 byte (round to nearest even, saturating at +-448)
+__device__ __forceinline__ uint8_t f2fp8(float x) {
+  x = fminf(fmaxf(x, -448.f), 448.f);
+  return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff);
+}
+
 // ------------------------------------------------------------------------------------
 // RMSNorm (optionally fused with the residual add): one 256-thread block per token, the
 // row stays in registers between the sum of squares and the scaled write (H <= 8192).
@@ -146,13 +164,19 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
 // qkv activation, in place, and the write of k / v into the paged cache. One wave per
 // (token, head).
 // ------------------------------------------------------------------------------------
+// KV8: the cache holds OCP e4m3 bytes (unit scale) instead of bf16; q and the in-place k stay bf16.
+template <bool KV8>
 __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv,
                                                          const float* __restrict__ cos_sin,
                                                          const int* __restrict__ positions,
                                                          const int* __restrict__ slots,
-                                                         uint16_t* __restrict__ kc,
-                                                         uint16_t* __restrict__ vc, int T, int n_q,
+                                                         void* __restrict__ kcv,
+                                                         void* __restrict__ vcv, int T, int n_q,
                                                          int n_kv, int max_pos, int num_slots) {
+  uint16_t* kc = reinterpret_cast<uint16_t*>(kcv);
+  uint16_t* vc = reinterpret_cast<uint16_t*>(vcv);
+  uint8_t* kc8 = reinterpret_cast<uint8_t*>(kcv);
+  uint8_t* vc8 = reinterpret_cast<uint8_t*>(vcv);
   const int lane = threadIdx.x & 63;
   const int heads = n_q + 2 * n_kv;
   const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -171,14 +195,24 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
     row[lane] = b1;
     row[lane + 64] = b2;
     if (hs >= n_q && cache_ok) {
-      uint16_t* dst = kc + ((size_t)(slot / BLK) * n_kv + (hs - n_q)) * BLK_ELEMS + (slot % BLK) * HD;
-      dst[lane] = b1;
-      dst[lane + 64] = b2;
+      const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q)) * BLK_ELEMS + (slot % BLK) * HD;
+      if (KV8) {
+        kc8[off + lane] = f2fp8(bf2f(b1));
+        kc8[off + lane + 64] = f2fp8(bf2f(b2));
+      } else {
+        kc[off + lane] = b1;
+        kc[off + lane + 64] = b2;
+      }
     }
   } else if (cache_ok) {
-    uint16_t* dst = vc + ((size_t)(slot / BLK) * n_kv + (hs - n_q - n_kv)) * BLK_ELEMS + (slot % BLK);
-    dst[lane * BLK] = r1;
-    dst[(lane + 64) * BLK] = r2;
+    const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q - n_kv)) * BLK_ELEMS + (slot % BLK);
+    if (KV8) {
+      vc8[off + lane * BLK] = f2fp8(bf2f(r1));
+      vc8[off + (lane + 64) * BLK] = f2fp8(bf2f(r2));
+    } else {
+      vc[off + lane * BLK] = r1;
+      vc[off + (lane + 64) * BLK] = r2;
+    }
   }
 }
 
@@ -186,10 +220,12 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
 // Attention over the paged cache.
 // ------------------------------------------------------------------------------------
 struct KvView {
-  const uint16_t* kc;   // K cache + kv head offset
+  const uint16_t* kc;   // K cache + kv head offset (bf16 cache; an fp8 cache is addressed through kc8 / vc8)
   const uint16_t* vc;   // V cache + kv head offset
+  const uint8_t* kc8;
+  const uint8_t* vc8;
   const int* bt;        // block table row of this sequence
-  size_t blk_stride;    // n_kv * BLK_ELEMS
+  size_t blk_stride;    // n_kv * BLK_ELEMS, in elements
   int last_blk;         // index (in the table) of the last block that holds a token
   int nb_total;         // blocks in the cache (ids are clamped to it)
 };
@@ -199,6 +235,11 @@ struct Frags {
   bf16x8 v[8];
 };
 
+// KV8 (e4m3 cache): a lane's 16-byte K load carries 16 dims = two MFMA k-steps, so the k order of the
+// contraction is dims (h2*4+fq)*16 + half*8 .. +8 for k-step 2*h2+half (load_q<true> orders q alike);
+// V^T rows are 16 bytes per block, a lane takes its 8 tokens with one 8-byte load. Both are turned
+// into bf16 fragments in registers: half the cache bytes per token, the same MFMAs.
+template <bool KV8>
 __device__ __forceinline__ void load_step(const KvView& kv, int step, int fr, int fq, Frags& f) {
   int i0 = step * 2, i1 = step * 2 + 1;
   i0 = i0 > kv.last_blk ? kv.last_blk : i0;
@@ -206,6 +247,25 @@ __device__ __forceinline__ void load_step(const KvView& kv, int step, int fr, in
   int b0 = kv.bt[i0], b1 = kv.bt[i1];
   b0 = b0 < 0 ? 0 : (b0 >= kv.nb_total ? kv.nb_total - 1 : b0);
   b1 = b1 < 0 ? 0 : (b1 >= kv.nb_total ? kv.nb_total - 1 : b1);
+  if (KV8) {
+    const uint8_t* kp8 = kv.kc8 + (size_t)((fr >> 3) ? b1 : b0) * kv.blk_stride +
+                         ((((fr >> 2) & 1) << 3) + (fr & 3)) * HD + fq * 16;
+    const uint8_t* vp8 = kv.vc8 + (size_t)((fq >> 1) ? b1 : b0) * kv.blk_stride + fr * BLK + (fq & 1) * 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(kp8 + t * 4 * HD + h2 * 64);
+        f.k[t][2 * h2] = fp8x8_to_bf16(raw.x, raw.y);
+        f.k[t][2 * h2 + 1] = fp8x8_to_bf16(raw.z, raw.w);
+      }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(vp8 + n * 16 * BLK);
+      f.v[n] = fp8x8_to_bf16(raw.x, raw.y);
+    }
+    return;
+  }
   const uint16_t* kp = kv.kc + (size_t)((fr >> 3) ? b1 : b0) * kv.blk_stride +
                        ((((fr >> 2) & 1) << 3) + (fr & 3)) * HD + fq * 8;
   const uint16_t* vp = kv.vc + (size_t)((fq >> 1) ? b1 : b0) * kv.blk_stride + fr * BLK + (fq & 1) * 8;
@@ -286,11 +346,13 @@ __device__ __forceinline__ void attend_step(const Frags& f, const bf16x8 (&qf)[4
   softmax_pv(s0, s1, f.v, step, fq, qpos, lim, scale_log2, a);
 }
 
+template <bool KV8 = false>
 __device__ __forceinline__ void load_q(const uint16_t* qrow, bool valid, int fq, bf16x8 (&qf)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     if (valid) {
-      qf[s] = *reinterpret_cast<const bf16x8*>(qrow + s * 32 + fq * 8);
+      // the dims of k-step s must be the ones load_step puts there (see load_step<true>)
+      qf[s] = *reinterpret_cast<const bf16x8*>(qrow + (KV8 ? (s >> 1) * 64 + fq * 16 + (s & 1) * 8 : s * 32 + fq * 8));
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)0.f;
@@ -299,16 +361,17 @@ __device__ __forceinline__ void load_q(const uint16_t* qrow, bool valid, int fq,
 }
 
 // Runs steps st0, st0+stride, ... < st_end with the loads of the next step in flight.
+template <bool KV8>
 __device__ __forceinline__ void attend_range(const KvView& kv, const bf16x8 (&qf)[4], int st0, int st_end,
                                              int stride, int fr, int fq, int qpos, int lim, float scale_log2,
                                              Acc& a) {
   if (st0 >= st_end) return;
   Frags cur;
-  load_step(kv, st0, fr, fq, cur);
+  load_step<KV8>(kv, st0, fr, fq, cur);
   for (int st = st0; st < st_end; st += stride) {
     Frags nxt;
     const int nx = st + stride;
-    load_step(kv, nx < st_end ? nx : st, fr, fq, nxt);   // last iteration re-reads (cached), unused
+    load_step<KV8>(kv, nx < st_end ? nx : st, fr, fq, nxt);   // last iteration re-reads (cached), unused
     attend_step(cur, qf, st, fq, qpos, lim, scale_log2, a);
     cur = nxt;
   }
@@ -318,6 +381,7 @@ constexpr int OPAD = HD + 4;
 
 // Decode: one token per sequence. Block = (kv head, sequence, split); its 4 waves take the
 // 32-token steps of the split round-robin and are combined through LDS.
+template <bool KV8>
 __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int* __restrict__ block_tables, const int* __restrict__ ctx_lens, uint16_t* __restrict__ out,
@@ -339,6 +403,8 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
   KvView kv;
   kv.kc = kc + (size_t)h * BLK_ELEMS;
   kv.vc = vc + (size_t)h * BLK_ELEMS;
+  kv.kc8 = reinterpret_cast<const uint8_t*>(kc) + (size_t)h * BLK_ELEMS;
+  kv.vc8 = reinterpret_cast<const uint8_t*>(vc) + (size_t)h * BLK_ELEMS;
   kv.bt = block_tables + (size_t)b * max_blocks;
   kv.blk_stride = (size_t)n_kv * BLK_ELEMS;
   kv.last_blk = ctx > 0 ? (ctx - 1) / BLK : 0;
@@ -346,7 +412,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
 
   const bool valid = fr < G;
   bf16x8 qf[4];
-  load_q(q + (size_t)b * q_stride + ((size_t)h * G + (valid ? fr : 0)) * HD, valid, fq, qf);
+  load_q<KV8>(q + (size_t)b * q_stride + ((size_t)h * G + (valid ? fr : 0)) * HD, valid, fq, qf);
   const int qpos = valid ? ctx - 1 : -1;
 
   Acc a;
@@ -354,7 +420,7 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
   for (int n = 0; n < 8; ++n) a.o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   a.m = -INFINITY;
   a.l = 0.f;
-  attend_range(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, ctx - 1, scale_log2, a);
+  attend_range<KV8>(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, ctx - 1, scale_log2, a);
 
 #pragma unroll
   for (int n = 0; n < 8; ++n) *reinterpret_cast<f32x4*>(&sm_o[w][fr][n * 16 + fq * 4]) = a.o[n];
@@ -454,7 +520,7 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(const float* __r
 // tile stops at its own causal limit, and there is no cross-wave exchange.
 //   seq_info[s] = {q_start (row of the first query in q/out), q_len, ctx_len}
 //   tiles[t]    = {sequence, first query token of the tile (0-based inside the sequence's queries)}
-template <int QT>
+template <int QT, bool KV8>
 __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int* __restrict__ block_tables, const int* __restrict__ seq_info, const int* __restrict__ tiles,
@@ -477,6 +543,8 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   KvView kv;
   kv.kc = kc + (size_t)h * BLK_ELEMS;
   kv.vc = vc + (size_t)h * BLK_ELEMS;
+  kv.kc8 = reinterpret_cast<const uint8_t*>(kc) + (size_t)h * BLK_ELEMS;
+  kv.vc8 = reinterpret_cast<const uint8_t*>(vc) + (size_t)h * BLK_ELEMS;
   kv.bt = block_tables + (size_t)seq * max_blocks;
   kv.blk_stride = (size_t)n_kv * BLK_ELEMS;
   kv.last_blk = ctx > 0 ? (ctx - 1) / BLK : 0;
@@ -495,7 +563,7 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
     const int tq = t0 + (fr >> g_shift);
     valid[t] = tq < q_len;
     qrow[t] = (size_t)(q_start + (valid[t] ? tq : wtok0));
-    load_q(q + qrow[t] * q_stride + qhead * HD, valid[t], fq, qf[t]);
+    load_q<KV8>(q + qrow[t] * q_stride + qhead * HD, valid[t], fq, qf[t]);
     qpos[t] = valid[t] ? ctx - q_len + tq : -1;
     lim[t] = ctx - q_len + t0;                       // position of the tile's first query
     int last_tq = t0 + tpt - 1;
@@ -509,10 +577,10 @@ __global__ __launch_bounds__(256) void paged_attn_prefill_kernel(
   }
 
   Frags cur;
-  load_step(kv, 0, fr, fq, cur);
+  load_step<KV8>(kv, 0, fr, fq, cur);
   for (int st = 0; st < n_steps; ++st) {
     Frags nxt;
-    load_step(kv, st + 1 < n_steps ? st + 1 : st, fr, fq, nxt);
+    load_step<KV8>(kv, st + 1 < n_steps ? st + 1 : st, fr, fq, nxt);
 #pragma unroll
     for (int t = 0; t < QT; ++t)
       if (st < nst[t]) attend_step(cur, qf[t], st, fq, qpos[t], lim[t], scale_log2, a[t]);
@@ -615,6 +683,8 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
   KvView kv;
   kv.kc = kc + (size_t)h * BLK_ELEMS;
   kv.vc = vc + (size_t)h * BLK_ELEMS;
+  kv.kc8 = reinterpret_cast<const uint8_t*>(kc) + (size_t)h * BLK_ELEMS;
+  kv.vc8 = reinterpret_cast<const uint8_t*>(vc) + (size_t)h * BLK_ELEMS;
   kv.bt = block_tables + (size_t)seq * max_blocks;
   kv.blk_stride = (size_t)n_kv * BLK_ELEMS;
   kv.last_blk = ctx > 0 ? (ctx - 1) / BLK : 0;
@@ -706,18 +776,7 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
 // ------------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_SWIGLU = 2 };
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-// 8 e4m3 bytes (two dwords, k order = byte order) -> one bf16 MFMA fragment
-__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
-  const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, false);
-  const bf16x2 p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, true);
-  const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, false);
-  const bf16x2 p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, true);
-  bf16x8 r;
-  r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
-  r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
-  return r;
-}
+
 
 // RT = 16-row tiles of W per block: the x fragment is loaded once per RT weight fragments, which
 // matters when M is large enough for the x traffic (M*K*2 bytes per block, from L2) to rival the
@@ -926,23 +985,28 @@ int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream) {
 
 int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
                    void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
-                   void* stream) {
+                   int kv_fp8, void* stream) {
   if (T <= 0 || n_q <= 0 || n_kv <= 0 || max_pos <= 0 || num_slots <= 0 || num_slots > INT32_MAX)
     return KLM_ERR_SHAPE;
   if (!qkv || !cos_sin || !positions || !slots || !k_cache || !v_cache) return KLM_ERR_ARG;
   const long waves = (long)T * (n_q + 2 * n_kv);
   const long blocks = (waves + 3) / 4;
   if (blocks > INT32_MAX) return KLM_ERR_SHAPE;
-  hipLaunchKernelGGL(rope_cache_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     (uint16_t*)qkv, cos_sin, positions, slots, (uint16_t*)k_cache, (uint16_t*)v_cache, T, n_q,
-                     n_kv, max_pos, (int)num_slots);
+  if (kv_fp8)
+    hipLaunchKernelGGL(rope_cache_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (uint16_t*)qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos,
+                       (int)num_slots);
+  else
+    hipLaunchKernelGGL(rope_cache_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (uint16_t*)qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos,
+                       (int)num_slots);
   return launch_status();
 }
 
 int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                           const int32_t* ctx_lens, void* out, float* tmp_o, float* tmp_ml, int B, int q_stride,
                           int n_q, int n_kv, int max_blocks, int num_blocks_total, int num_splits, float scale,
-                          void* stream) {
+                          int kv_fp8, void* stream) {
   if (q_stride < n_q * HD || q_stride % 8 != 0) return KLM_ERR_SHAPE;
   if (B <= 0 || B > 65535 || n_q <= 0 || n_kv <= 0 || n_q % n_kv != 0 || max_blocks <= 0 || num_blocks_total <= 0)
     return KLM_ERR_SHAPE;
@@ -955,9 +1019,14 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
     return KLM_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float scale_log2 = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(paged_attn_decode_kernel, dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
-                     (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, ctx_lens, (uint16_t*)out,
-                     tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2);
+  if (kv_fp8)
+    hipLaunchKernelGGL(paged_attn_decode_kernel<true>, dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
+                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, ctx_lens, (uint16_t*)out,
+                       tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2);
+  else
+    hipLaunchKernelGGL(paged_attn_decode_kernel<false>, dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
+                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, ctx_lens, (uint16_t*)out,
+                       tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2);
   if (hipGetLastError() != hipSuccess) return KLM_ERR_HIP;
   if (num_splits > 1)
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)B * n_q), dim3(128), 0, s, tmp_o, tmp_ml, ctx_lens,
@@ -968,8 +1037,9 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
 int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                            const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
                            int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,
-                           int q_tiles, int variant, void* stream) {
+                           int q_tiles, int variant, int kv_fp8, void* stream) {
   if ((q_tiles != 1 && q_tiles != 2 && q_tiles != 4) || variant < 0 || variant > 1) return KLM_ERR_VARIANT;
+  if (kv_fp8) variant = 0;        // the LDS-ring kernel reads a bf16 cache only
   if (q_stride < n_q * HD || q_stride % 8 != 0) return KLM_ERR_SHAPE;
   if (n_tiles <= 0 || n_tiles > 65535 || n_seqs <= 0 || n_q <= 0 || n_kv <= 0 || n_q % n_kv != 0 ||
       max_blocks <= 0 || num_blocks_total <= 0)
@@ -979,11 +1049,16 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
   if (!q || !k_cache || !v_cache || !block_tables || !seq_info || !tiles || !out) return KLM_ERR_ARG;
   if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) return KLM_ERR_ALIGN;
   const float scale_log2 = scale * 1.4426950408889634f;
-#define KLM_PREFILL(QT)                                                                                          \
-  hipLaunchKernelGGL((paged_attn_prefill_kernel<QT>), dim3(n_kv, n_tiles), dim3(256), 0,                         \
+#define KLM_PREFILL_K(QT, F8)                                                                                    \
+  hipLaunchKernelGGL((paged_attn_prefill_kernel<QT, F8>), dim3(n_kv, n_tiles), dim3(256), 0,                     \
                      static_cast<hipStream_t>(stream), (const uint16_t*)q, (const uint16_t*)k_cache,             \
                      (const uint16_t*)v_cache, block_tables, seq_info, tiles, (uint16_t*)out, n_seqs, q_stride,  \
                      n_q, n_kv, G, gs, max_blocks, num_blocks_total, scale_log2)
+#define KLM_PREFILL(QT)             \
+  do {                              \
+    if (kv_fp8) KLM_PREFILL_K(QT, true); \
+    else KLM_PREFILL_K(QT, false);  \
+  } while (0)
 #define KLM_PREFILL_LDS(QT)                                                                                        \
   do {                                                                                                           \
     static bool attr_done = false;                                                                               \
@@ -1008,6 +1083,7 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
   else KLM_PREFILL(4);
 #undef KLM_PREFILL_LDS
 #undef KLM_PREFILL
+#undef KLM_PREFILL_K
   return launch_status();
 }
 

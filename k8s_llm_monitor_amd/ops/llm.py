@@ -33,9 +33,9 @@ def _lib():
             raise KlmOpsError("libklm_ops.so was built without llm.hip: run `python -m k8s_llm_monitor_amd.build --force`")
         lib.klm_rmsnorm.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         lib.klm_silu_mul.argtypes = [vp, vp, i, i, vp]
-        lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, vp]
-        lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, vp]
-        lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, i, vp]
+        lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, i, vp]
+        lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, vp]
+        lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, i, i, vp]
         lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, i, vp]
         lib.klm_skinny_linear_w8.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, f, i, i, i, vp]
         lib.klm_skinny_linear_w8.restype = i
@@ -224,7 +224,18 @@ def _check_caches(k_cache: torch.Tensor, v_cache: torch.Tensor, n_kv: int) -> in
         raise KlmOpsError(f"cache shapes: K {tuple(k_cache.shape)} V {tuple(v_cache.shape)} for n_kv={n_kv}")
     if not (k_cache.is_contiguous() and v_cache.is_contiguous()):
         raise KlmOpsError("caches must be contiguous")
+    if k_cache.dtype != v_cache.dtype:
+        raise KlmOpsError("K and V caches must have the same dtype")
     return nb
+
+
+def _kv8(k_cache: torch.Tensor) -> int:
+    """1 when the cache holds e4m3 bytes (fp8 KV cache, unit scale), 0 for bf16."""
+    if k_cache.dtype == torch.float8_e4m3fn:
+        return 1
+    if k_cache.dtype != torch.bfloat16:
+        raise KlmOpsError("the KV cache is bfloat16 or float8_e4m3fn")
+    return 0
 
 
 def rope_cache(qkv: torch.Tensor, cos_sin: torch.Tensor, positions: torch.Tensor, slots: torch.Tensor,
@@ -243,11 +254,11 @@ def rope_cache(qkv: torch.Tensor, cos_sin: torch.Tensor, positions: torch.Tensor
         qkv.copy_(r)
         ref.cache_write(qkv, slots, k_cache, v_cache, n_q, n_kv)
         return qkv
-    _bf16(qkv, k_cache, v_cache)
+    _bf16(qkv)
     _i32(positions, slots)
     rc = _lib().klm_rope_cache(qkv.data_ptr(), cos_sin.data_ptr(), positions.data_ptr(), slots.data_ptr(),
                                k_cache.data_ptr(), v_cache.data_ptr(), T, n_q, n_kv, cos_sin.shape[0],
-                               nb * BLOCK, _stream(qkv))
+                               nb * BLOCK, _kv8(k_cache), _stream(qkv))
     _check(rc, f"klm_rope_cache(T={T})")
     return qkv
 
@@ -288,7 +299,7 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
             out.copy_(o)
             return out
         return o
-    _bf16(q, k_cache, v_cache)
+    _bf16(q)
     _i32(block_tables, ctx_lens)
     if out is None:
         out = torch.empty((B, n_q * HEAD_DIM), dtype=q.dtype, device=q.device)
@@ -303,7 +314,8 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
         tmp_o, tmp_ml = workspace.tmp_o.data_ptr(), workspace.tmp_ml.data_ptr()
     rc = _lib().klm_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
                                       ctx_lens.data_ptr(), out.data_ptr(), tmp_o, tmp_ml, B, q.stride(0), n_q, n_kv,
-                                      block_tables.shape[1], nb, int(num_splits), float(scale), _stream(q))
+                                      block_tables.shape[1], nb, int(num_splits), float(scale), _kv8(k_cache),
+                                      _stream(q))
     _check(rc, f"klm_paged_attn_decode(B={B},splits={num_splits})")
     return out
 
@@ -359,13 +371,13 @@ def paged_attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Te
             out.copy_(o)
             return out
         return o
-    _bf16(q, k_cache, v_cache)
+    _bf16(q)
     _i32(block_tables, seq_info, tiles)
     if out is None:
         out = torch.zeros((q.shape[0], n_q * HEAD_DIM), dtype=q.dtype, device=q.device)
     rc = _lib().klm_paged_attn_prefill(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
                                        seq_info.data_ptr(), tiles.data_ptr(), out.data_ptr(), tiles.shape[0], S,
                                        q.stride(0), n_q, n_kv, block_tables.shape[1], nb, float(scale), int(q_tiles),
-                                       int(variant), _stream(q))
+                                       int(variant), _kv8(k_cache), _stream(q))
     _check(rc, f"klm_paged_attn_prefill(tiles={tiles.shape[0]})")
     return out

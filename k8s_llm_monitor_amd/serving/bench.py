@@ -50,7 +50,7 @@ def decode_step_ms(eng: Engine, batch: int, ctx: int, iters: int = 20, warmup: i
         weight_bytes = eng.model.decode_stream_bytes()
     else:
         weight_bytes = eng.model.weight_bytes() - c.vocab * c.hidden * 2      # the embedding is only gathered
-    kv_bytes = batch * ctx * c.kv_bytes_per_token()
+    kv_bytes = batch * ctx * c.kv_bytes_per_token() // (2 if eng.cfg.kv_cache_dtype == "fp8" else 1)
     return {"batch": batch, "bucket": b, "ctx": ctx, "ms": ms, "tokens_per_s": batch / ms * 1e3,
             "bytes": weight_bytes + kv_bytes, "TBps": (weight_bytes + kv_bytes) / ms / 1e9,
             "TFLOPs": batch * c.flops_per_token(ctx) / ms / 1e9}

@@ -42,6 +42,7 @@ class EngineConfig:
     kv_blocks: int = 0                 # 0: size the cache from kv_fraction of the free HBM
     kv_fraction: float = 0.5
     use_graphs: bool = True
+    kv_cache_dtype: str = "bf16"       # "fp8": e4m3 KV cache (half the bytes per token; prefill then uses the register kernel)
     decode_weights: str = "bf16"       # "fp8": W8A16 copies for the batch <= 16 decode path (LlamaModel.enable_fp8_decode)
     seed: int = 0
 
@@ -121,8 +122,11 @@ class Engine:
             raise ValueError(f"decode_weights must be bf16 or fp8, not {self.cfg.decode_weights!r}")
         self.mcfg = mcfg
         self.max_blocks = -(-self.max_len // BLOCK)
+        if self.cfg.kv_cache_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"kv_cache_dtype must be bf16 or fp8, not {self.cfg.kv_cache_dtype!r}")
+        self.kv_dtype = torch.float8_e4m3fn if self.cfg.kv_cache_dtype == "fp8" else None
         nblocks = self.cfg.kv_blocks or self._auto_blocks()
-        self.cache: KVCache = self.model.new_cache(nblocks)
+        self.cache: KVCache = self.model.new_cache(nblocks, self.kv_dtype)
         self.alloc = BlockAllocator(nblocks)
         self.metrics = EngineMetrics(mcfg.name, clock=clock)
         self.waiting: Deque[Request] = deque()
@@ -161,7 +165,7 @@ class Engine:
 
     # ------------------------------------------------------------------ sizing
     def _auto_blocks(self) -> int:
-        per_block = KVCache.bytes_per_block(self.mcfg)
+        per_block = KVCache.bytes_per_block(self.mcfg, self.kv_dtype or torch.bfloat16)
         if self.on_gpu:
             free, _total = torch.cuda.mem_get_info(self.device)
             n = int(free * self.cfg.kv_fraction) // per_block
@@ -441,5 +445,6 @@ class Engine:
                 "kv_bytes": self.cache.nbytes, "max_num_seqs": self.cfg.max_num_seqs, "max_model_len": self.max_len,
                 "graphs": sorted(self._graphs), "device": str(self.device),
                 "decode_weights": "fp8 (W8A16, batch <= 16)" if self.model.fp8_decode else "bf16",
+                "kv_cache_dtype": self.cfg.kv_cache_dtype,
                 "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts),
                 "errors": self.errors, "last_error": self.last_error}

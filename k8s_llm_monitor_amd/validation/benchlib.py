@@ -165,8 +165,19 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             extras["llm_serving"]["decode_fp8_weights"] = [
                 {"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3), "tokens_per_s": round(r["tokens_per_s"], 1),
                  "TBps": round(r["TBps"], 2)} for r in d8]
-            del eng, dec, pre, d8
+            del eng
             import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            # and with an e4m3 KV cache on top (large batches, where attention bytes dominate)
+            eng = Engine(EngineConfig(model="llama3-8b", device=str(dev), max_num_seqs=256, max_model_len=4096,
+                                      kv_blocks=20000, kv_cache_dtype="fp8"))
+            eng.warmup([64, 256])
+            dk = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (64, 256)]
+            extras["llm_serving"]["decode_fp8_kv_cache"] = [
+                {"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3), "tokens_per_s": round(r["tokens_per_s"], 1),
+                 "TBps": round(r["TBps"], 2)} for r in dk]
+            del eng, dec, pre, d8, dk
             gc.collect()
             torch.cuda.empty_cache()
         except Exception as e:

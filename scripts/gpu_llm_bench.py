@@ -15,9 +15,10 @@ from k8s_llm_monitor_amd.serving.loadclient import OpenLoopLoad  # noqa: E402
 model = sys.argv[1] if len(sys.argv) > 1 else "llama3-8b"
 kv_blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 decode_weights = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+kv_dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 out = {"model": model}
 t0 = time.time()
-eng = Engine(EngineConfig(model=model, max_num_seqs=256, max_model_len=4096, kv_blocks=kv_blocks, decode_weights=decode_weights))
+eng = Engine(EngineConfig(model=model, max_num_seqs=256, max_model_len=4096, kv_blocks=kv_blocks, decode_weights=decode_weights, kv_cache_dtype=kv_dtype))
 torch.cuda.synchronize()
 out["init_s"] = time.time() - t0
 out["engine"] = eng.describe()
@@ -56,4 +57,4 @@ out["serving"] = {"drained": ok, "requests": len(load.requests), "truth": eng.me
                   "engine": eng.describe()}
 print(json.dumps(out["serving"]["truth"]), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/llm_bench%s.json" % (("" if model == "llama3-8b" else "_" + model) + ("" if decode_weights == "bf16" else "_" + decode_weights)), "w"), indent=1, default=str)
+json.dump(out, open("gpurun_out/llm_bench%s.json" % (("" if model == "llama3-8b" else "_" + model) + ("" if decode_weights == "bf16" else "_" + decode_weights) + ("" if kv_dtype == "bf16" else "_kv" + kv_dtype)), "w"), indent=1, default=str)

@@ -249,3 +249,69 @@ def test_skinny_linear_with_tiled_weights_equals_the_row_major_run(fp8, M, N, K,
     a = llm.skinny_linear(x, w, rms=True, epilogue="swiglu", weight_scale=ws, row_tiles=rt)
     b = llm.skinny_linear(x, t, rms=True, epilogue="swiglu", weight_scale=ws, row_tiles=rt, tiled=True)
     assert torch.equal(a, b)                      # same products in the same order: bit-identical
+
+
+# ---------------------------------------------------------------- fp8 (e4m3) KV cache
+FP8 = torch.float8_e4m3fn
+
+
+def test_rope_cache_writes_an_fp8_cache_like_torch_converts_it():
+    torch.manual_seed(12)
+    T, n_q, n_kv, nb = 40, 32, 8, 12
+    qkv = _rand(T, (n_q + 2 * n_kv) * 128, scale=3.0)
+    cs = llm.rope_table(2048, 500000.0, DEV)
+    pos = torch.randint(0, 2048, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(nb * 16, device=DEV)[:T].to(torch.int32)
+    kr, vr = _caches(nb, n_kv, fill=False)
+    want = ref.rope(qkv, cs, pos, n_q, n_kv)
+    ref.cache_write(want, slots, kr, vr, n_q, n_kv)
+    k8 = torch.zeros(nb, n_kv, 16, 128, device=DEV, dtype=FP8)
+    v8 = torch.zeros(nb, n_kv, 128, 16, device=DEV, dtype=FP8)
+    got = qkv.clone()
+    llm.rope_cache(got, cs, pos, slots, k8, v8, n_q, n_kv)
+    _close(got, want, 1e-2, 1e-2)                                   # q and the in-place k stay bf16
+    assert torch.equal(v8.view(torch.uint8), vr.to(FP8).view(torch.uint8))
+    # k goes through the kernel's own fp32 rotation before the two roundings: allow the last fp8 bit
+    dk = (k8.float() - kr.to(FP8).float()).abs()
+    assert float((dk > 0).float().mean()) < 0.02 and bool((dk <= 0.13 * kr.float().abs() + 1e-3).all())
+
+
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (4, 4), (16, 1)])
+@pytest.mark.parametrize("splits", [1, 4])
+def test_decode_attention_over_an_fp8_cache_matches_the_reference_on_the_same_values(n_q, n_kv, splits):
+    torch.manual_seed(13)
+    ctx = [1, 16, 17, 33, 700, 129, 0]
+    nb, mb = 80, 48
+    kc, vc = _caches(nb, n_kv)
+    k8, v8 = kc.to(FP8), vc.to(FP8)
+    bt = _tables(ctx, nb, mb)
+    cl = torch.tensor(ctx, dtype=torch.int32, device=DEV)
+    qkv = _rand(len(ctx), (n_q + 2 * n_kv) * 128)
+    q = qkv[:, : n_q * 128]
+    scale = 1.0 / math.sqrt(128)
+    got = llm.paged_attn_decode(q, k8, v8, bt, cl, scale, n_q, num_splits=splits)
+    want = ref.paged_attn_decode(q, k8.to(torch.bfloat16), v8.to(torch.bfloat16), bt, cl, scale)
+    _close(got, want, 2e-2)
+
+
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (2, 2), (8, 1)])
+@pytest.mark.parametrize("q_tiles", [1, 2])
+def test_prefill_attention_over_an_fp8_cache_matches_the_reference_on_the_same_values(n_q, n_kv, q_tiles):
+    torch.manual_seed(14)
+    seqs = [(5, 5), (64, 64), (100, 100), (17, 300), (33, 64)]
+    nb, mb = 60, 24
+    kc, vc = _caches(nb, n_kv)
+    k8, v8 = kc.to(FP8), vc.to(FP8)
+    bt = _tables([c for _, c in seqs], nb, mb)
+    info, at = [], 0
+    for ql, c in seqs:
+        info.append((at, ql, c))
+        at += ql
+    seq_info = torch.tensor(info, dtype=torch.int32, device=DEV)
+    tiles = llm.prefill_tiles([q for q, _ in seqs], n_q // n_kv, q_tiles, ctx_lens=[c for _, c in seqs]).to(DEV)
+    qkv = _rand(at, (n_q + 2 * n_kv) * 128)
+    q = qkv[:, : n_q * 128]
+    scale = 1.0 / math.sqrt(128)
+    got = llm.paged_attn_prefill(q, k8, v8, bt, seq_info, tiles, scale, n_q, q_tiles=q_tiles)   # variant 0 is forced
+    want = ref.paged_attn_prefill(q, k8.to(torch.bfloat16), v8.to(torch.bfloat16), bt, seq_info, scale)
+    _close(got, want, 2e-2)

@@ -70,7 +70,12 @@ def test_fp8_decode_weights_match_the_fp32_cpu_model_with_the_dequantised_weight
     _compare_logits(g, c, 5)
 
 
-def _compare_logits(gpu_model, cpu_model, n_seqs):
+def test_fp8_kv_cache_stays_close_to_the_bf16_cache_model(gpu_model, cpu_model):
+    _compare_logits(gpu_model, cpu_model, 4, kv_dtype=torch.float8_e4m3fn, tol=0.08)
+    _compare_logits(gpu_model, cpu_model, 20, kv_dtype=torch.float8_e4m3fn, tol=0.08)
+
+
+def _compare_logits(gpu_model, cpu_model, n_seqs, kv_dtype=None, tol=0.03):
     g = torch.Generator().manual_seed(n_seqs)
     lens = [int(x) for x in torch.randint(5, 90, (n_seqs,), generator=g)]
     prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in lens]
@@ -78,7 +83,7 @@ def _compare_logits(gpu_model, cpu_model, n_seqs):
     out = {}
     for name, model in (("cpu", cpu_model), ("gpu", gpu_model)):
         dev = model.device
-        cache = model.new_cache(nblocks)
+        cache = model.new_cache(nblocks, kv_dtype if dev.type == "cuda" else None)
         t, p, s, meta = _prefill_inputs(prompts, dev, mb)
         pre = model.prefill(t, p, s, cache, meta, logits=True)
         # one decode step on top of the prefilled cache, fed with the same (CPU-chosen) tokens
@@ -90,8 +95,8 @@ def _compare_logits(gpu_model, cpu_model, n_seqs):
         dmeta = DecodeMeta(meta.block_tables, ctx, num_splits=2 if dev.type == "cuda" else 1)
         dec = model.decode(out["cpu_next"].to(dev), posd, slotd, cache, dmeta, logits=True)
         out[name] = (pre, dec)
-    assert _rel_err(out["gpu"][0], out["cpu"][0]) < 0.03, "prefill logits"
-    assert _rel_err(out["gpu"][1], out["cpu"][1]) < 0.03, "decode logits"
+    assert _rel_err(out["gpu"][0], out["cpu"][0]) < tol, "prefill logits"
+    assert _rel_err(out["gpu"][1], out["cpu"][1]) < tol, "decode logits"
 
 
 def _run(engine, prompts, max_tokens):

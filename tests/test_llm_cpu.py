@@ -250,6 +250,25 @@ def test_a_failing_model_launch_fails_the_requests_instead_of_hanging_them(model
     assert d["errors"] == 1 and "simulated" in d["last_error"] and eng.alloc.free == eng.alloc.total
 
 
+def test_fp8_kv_cache_serves_and_halves_the_cache_bytes(model):
+    a = Engine(EngineConfig(model="tiny", device="cpu", max_num_seqs=4, max_model_len=128, kv_blocks=32, use_graphs=False),
+               model=model)
+    b = Engine(EngineConfig(model="tiny", device="cpu", max_num_seqs=4, max_model_len=128, kv_blocks=32, use_graphs=False,
+                            kv_cache_dtype="fp8"), model=model)
+    assert b.cache.k.dtype == torch.float8_e4m3fn and b.cache.nbytes * (4 if model.dtype == torch.float32 else 2) == a.cache.nbytes
+    prompts = [[5, 6, 7, 8, 9], [11] * 20]
+    ra = [a.submit(p, 8) for p in prompts]
+    rb = [b.submit(p, 8) for p in prompts]
+    _drain(a)
+    _drain(b)
+    assert all(len(r.out) == 8 and r.error is None for r in rb) and b.alloc.free == b.alloc.total
+    # the first token comes from the prefill of the same prompt: identical up to the quantised context
+    same = sum(x.out[0] == y.out[0] for x, y in zip(ra, rb))
+    assert same >= 1
+    with pytest.raises(ValueError):
+        Engine(EngineConfig(model="tiny", device="cpu", kv_cache_dtype="int4", kv_blocks=8), model=model)
+
+
 def test_exact_quantile():
     assert exact_quantile([], 0.5) is None
     assert exact_quantile([1.0, 2.0, 3.0, 4.0], 0.5) == 2.5

@@ -8,11 +8,16 @@ can be validated on hardware without vLLM, a checkpoint or a network. No referen
 (the reference only mentions vLLM, README.md:73).
 
 Scheduling (one `step()` = one model launch):
-  1. while requests wait and blocks / sequence slots / the token budget allow: admit them and
-     run ONE variable-length prefill batch; each admitted request gets its first token (TTFT);
-  2. otherwise decode one token for every running sequence. A sequence that needs a new block
-     when none is free preempts the most recently admitted sequence (its blocks are freed, it
-     re-enters the queue at the front and is recomputed from prompt + generated tokens).
+  1. prefill: the requests already in prefill continue, then waiting requests are admitted while
+     blocks and sequence slots allow, up to `max_num_batched_tokens` tokens per launch. A prompt
+     longer than what is left of the budget is CHUNKED: its next chunk attends to the chunks already
+     in the paged cache (the prefill kernel takes q_len < ctx_len). A request gets its first token
+     (TTFT) from the launch that finishes its prompt;
+  2. decode one token for every running sequence. After a prefill launch the running sequences get
+     a decode step before the next prefill chunk, so a stream of long prompts delays them by one
+     chunk at a time, not by whole prompts. A sequence that needs a new block when none is free
+     preempts the most recently admitted one (prefilling before running): its blocks are freed, it
+     re-enters the queue at the front and is recomputed from prompt + generated tokens.
 Decode runs from a hipGraph captured per batch-size bucket (launch-bound otherwise: ~10 kernel
 launches per layer); the graph's inputs are static device buffers that each step refills.
 """
@@ -83,6 +88,7 @@ class Request:
     t_last: Optional[float] = None
     t_done: Optional[float] = None
     preempted: int = 0
+    prefilled: int = 0                # tokens of prompt + out whose K/V are in the cache (chunked prefill)
     error: Optional[str] = None
     done: threading.Event = field(default_factory=threading.Event)
 
@@ -131,6 +137,8 @@ class Engine:
         self.metrics = EngineMetrics(mcfg.name, clock=clock)
         self.waiting: Deque[Request] = deque()
         self.running: List[Request] = []
+        self.prefilling: List[Request] = []        # admitted (blocks held), prompt not fully in the cache yet
+        self._last_was_prefill = False
         self._lock = threading.Lock()
         self._next_id = 0
         self._wake = threading.Event()
@@ -199,39 +207,40 @@ class Engine:
 
     def idle(self) -> bool:
         with self._lock:
-            return not self.waiting and not self.running
+            return not self.waiting and not self.running and not self.prefilling
 
     # ------------------------------------------------------------------ one iteration
     def step(self) -> int:
         """Run one model launch; returns the number of tokens it produced (0 = nothing to do)."""
-        batch: List[Request] = []
+        chunks: List[tuple] = []                    # (request, tokens of it in this launch)
         with self._lock:
-            tokens = 0
-            while self.waiting and len(self.running) + len(batch) < self.cfg.max_num_seqs:
-                r = self.waiting[0]
-                n = r.n_tokens
-                need = -(-(n + 1) // BLOCK)
-                if batch and tokens + n > self.cfg.max_num_batched_tokens:
-                    break
-                if need > self.alloc.free:
-                    break
-                r.blocks = self.alloc.alloc(need)
-                self.waiting.popleft()
-                batch.append(r)
-                tokens += n
-        if batch:
-            try:
-                return self._prefill(batch)
-            except Exception:
-                # the admitted requests are in neither queue yet: hand them back so that a failure
-                # handler (see _loop) can fail them and their blocks are not lost
-                with self._lock:
-                    for r in reversed(batch):
-                        if not r.done.is_set() and r not in self.running:
-                            self.alloc.release(r.blocks)
-                            r.blocks = []
-                            self.waiting.appendleft(r)
-                raise
+            decode_turn = self._last_was_prefill and bool(self.running)
+            if not decode_turn:
+                budget = self.cfg.max_num_batched_tokens
+                for r in self.prefilling:
+                    take = min(r.n_tokens - r.prefilled, budget)
+                    if take <= 0:
+                        break
+                    chunks.append((r, take))
+                    budget -= take
+                while budget > 0 and self.waiting and \
+                        len(self.running) + len(self.prefilling) < self.cfg.max_num_seqs:
+                    r = self.waiting[0]
+                    n = r.n_tokens
+                    need = -(-(n + 1) // BLOCK)
+                    if need > self.alloc.free:
+                        break
+                    r.blocks = self.alloc.alloc(need)
+                    r.prefilled = 0
+                    self.waiting.popleft()
+                    self.prefilling.append(r)
+                    take = min(n, budget)
+                    chunks.append((r, take))
+                    budget -= take
+        if chunks:
+            self._last_was_prefill = True
+            return self._prefill(chunks)
+        self._last_was_prefill = False
         if self.running:
             return self._decode()
         return 0
@@ -243,40 +252,49 @@ class Engine:
         self.metrics.on_finish(now - r.arrival)
         r.done.set()
 
-    def _prefill(self, batch: List[Request]) -> int:
+    def _prefill(self, chunks: List[tuple]) -> int:
         t0 = self.clock()
         toks: List[int] = []
         pos: List[int] = []
         slots: List[int] = []
         info, last_rows = [], []
-        bt = np.zeros((len(batch), self.max_blocks), dtype=np.int32)
-        for i, r in enumerate(batch):
+        bt = np.zeros((len(chunks), self.max_blocks), dtype=np.int32)
+        for i, (r, take) in enumerate(chunks):
             seq = r.prompt + r.out
-            n = len(seq)
-            info.append((len(toks), n, n))
-            toks.extend(seq)
-            pos.extend(range(n))
+            lo, hi = r.prefilled, r.prefilled + take
+            info.append((len(toks), take, hi))                    # the chunk's queries see the hi tokens cached so far
+            toks.extend(seq[lo:hi])
+            pos.extend(range(lo, hi))
             blk = np.asarray(r.blocks, dtype=np.int64)
-            idx = np.arange(n)
+            idx = np.arange(lo, hi)
             slots.extend((blk[idx // BLOCK] * BLOCK + idx % BLOCK).tolist())
             bt[i, :len(r.blocks)] = r.blocks
             last_rows.append(len(toks) - 1)
         dev = self.device
-        meta = PrefillMeta.build(self.mcfg, [n for (_, n, _) in info], torch.from_numpy(bt).to(dev),
-                                 torch.tensor(info, dtype=torch.int32, device=dev),
-                                 torch.tensor(last_rows, dtype=torch.int64, device=dev), dev)
+        g = self.mcfg.n_q // self.mcfg.n_kv
+        q_lens = [n for (_, n, _) in info]
+        qt = llm.pick_q_tiles(q_lens, g, self.mcfg.n_kv)
+        meta = PrefillMeta(torch.from_numpy(bt).to(dev), torch.tensor(info, dtype=torch.int32, device=dev),
+                           llm.prefill_tiles(q_lens, g, qt, ctx_lens=[c for (_, _, c) in info]).to(dev),
+                           torch.tensor(last_rows, dtype=torch.int64, device=dev), qt)
         nxt = self.model.prefill(torch.tensor(toks, dtype=torch.int64, device=dev),
                                  torch.tensor(pos, dtype=torch.int32, device=dev),
                                  torch.tensor(slots, dtype=torch.int32, device=dev), self.cache, meta)
         nxt = nxt.tolist()                      # synchronises
         now = self.clock()
-        new_prompt = 0
+        new_prompt = produced = 0
         with self._lock:
-            for r, t in zip(batch, nxt):
+            for (r, take), t in zip(chunks, nxt):
+                if r.t_first is None:
+                    new_prompt += take
+                r.prefilled += take
+                if r.prefilled < r.n_tokens:
+                    continue                    # more chunks to go: the sampled token of a partial prompt is dropped
+                self.prefilling.remove(r)
+                produced += 1
                 if r.t_first is None:
                     r.t_first = now
                     self.metrics.on_first_token(now - r.arrival)
-                    new_prompt += len(r.prompt)
                 else:
                     self.metrics.on_token_gap(now - (r.t_last or now))
                 r.out.append(int(t))
@@ -285,10 +303,11 @@ class Engine:
                     self._finish(r, now)
                 else:
                     self.running.append(r)
-            self.metrics.on_step(len(batch), new_prompt, len(self.running), len(self.waiting), self.alloc.usage)
+            self.metrics.on_step(produced, new_prompt, len(self.running) + len(self.prefilling), len(self.waiting),
+                                 self.alloc.usage)
         self.step_seconds["prefill"] += now - t0
         self.step_counts["prefill"] += 1
-        return len(batch)
+        return max(produced, 1)
 
     def _make_room(self) -> None:
         """Give every running sequence the block its next token needs, preempting from the back."""
@@ -300,9 +319,11 @@ class Engine:
                 i += 1
                 continue
             if self.alloc.free == 0:
-                victim = self.running.pop()          # most recently admitted
+                # most recently admitted first: a request still in prefill loses the least work
+                victim = self.prefilling.pop() if self.prefilling else self.running.pop()
                 self.alloc.release(victim.blocks)
                 victim.blocks = []
+                victim.prefilled = 0
                 victim.preempted += 1
                 self.waiting.appendleft(victim)
                 self.metrics.on_preempt()
@@ -350,7 +371,7 @@ class Engine:
                 else:
                     still.append(r)
             self.running = still
-            self.metrics.on_step(n, 0, len(self.running), len(self.waiting), self.alloc.usage)
+            self.metrics.on_step(n, 0, len(self.running) + len(self.prefilling), len(self.waiting), self.alloc.usage)
         self.step_seconds["decode"] += now - t0
         self.step_counts["decode"] += 1
         return n
@@ -417,7 +438,7 @@ class Engine:
     def _fail_all(self, why: str) -> None:
         now = self.clock()
         with self._lock:
-            for r in list(self.waiting) + list(self.running):
+            for r in list(self.waiting) + list(self.prefilling) + list(self.running):
                 if r.blocks:
                     self.alloc.release(r.blocks)
                 r.blocks = []
@@ -426,6 +447,7 @@ class Engine:
                 r.done.set()
             self.waiting.clear()
             self.running = []
+            self.prefilling = []
             self.metrics.set_queue(0, 0, self.alloc.usage)
 
     def stop(self, abort_pending: bool = True) -> None:

@@ -157,3 +157,21 @@ def test_decode_step_timing_helper_reports_the_roofline_terms(gpu_model):
     eng = Engine(EngineConfig(model="small", max_num_seqs=16, max_model_len=512, kv_blocks=512), model=gpu_model)
     r = sb.decode_step_ms(eng, 4, 256, iters=5)
     assert r["ms"] > 0 and r["tokens_per_s"] > 0 and r["bytes"] > eng.model.weight_bytes() // 2
+
+
+def test_chunked_prefill_on_the_gpu_gives_the_first_token_of_the_unchunked_run(gpu_model):
+    """The same prompts through one big prefill launch and through 64-token chunks: the chunks attend to
+    their predecessors through the paged cache (prefill kernel with q_len < ctx_len). bf16 GEMMs of
+    different shapes may flip a near-tie, so most (not all) first tokens must agree."""
+    g = torch.Generator().manual_seed(21)
+    prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in (150, 200, 97, 310, 64, 180)]
+    firsts = []
+    for budget in (4096, 64):
+        eng = Engine(EngineConfig(model="small", max_num_seqs=16, max_model_len=512, kv_blocks=512,
+                                  max_num_batched_tokens=budget), model=gpu_model)
+        firsts.append([o[0] for o in _run(eng, prompts, 2)])
+        if budget == 64:
+            assert eng.step_counts["prefill"] >= sum(-(-len(p) // 64) for p in prompts) // 2
+        assert eng.alloc.free == eng.alloc.total
+    agree = sum(a == b for a, b in zip(*firsts))
+    assert agree >= len(prompts) - 1, firsts

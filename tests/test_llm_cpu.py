@@ -123,6 +123,32 @@ def test_late_arrivals_join_the_running_batch(model):
     assert b.out == dense_generate(model, [9, 8, 7], 6)
 
 
+def test_long_prompts_are_prefilled_in_chunks_between_decode_steps(model):
+    """A 16-token budget turns 45- and 70-token prompts into 3 and 5 launches whose later chunks attend to
+    the earlier ones through the paged cache; a request already decoding gets a token between chunks."""
+    eng = _engine(model, max_num_batched_tokens=16, max_model_len=128)
+    g = torch.Generator().manual_seed(9)
+    short = [4, 8, 15, 16, 23, 42]
+    a = eng.submit(short, 12)
+    eng.step()                                                        # `a` is decoding from here on
+    longs = [torch.randint(0, TINY.vocab, (n,), generator=g).tolist() for n in (45, 70)]
+    rs = [eng.submit(p, 5) for p in longs]
+    kinds, gaps, last = [], [], len(a.out)
+    while not eng.idle():
+        before = dict(eng.step_counts)
+        eng.step()
+        kinds.append("P" if eng.step_counts["prefill"] > before["prefill"] else "D")
+        if not a.done.is_set() or len(a.out) != last:
+            gaps.append(len(a.out) - last)
+            last = len(a.out)
+    assert eng.step_counts["prefill"] >= 1 + 3 + 5 - 1                 # chunks of different requests share launches
+    assert "PP" not in "".join(kinds[:12])                             # while `a` runs, every chunk is followed by a decode
+    assert a.out == dense_generate(model, short, 12)
+    for p, r in zip(longs, rs):
+        assert r.out == dense_generate(model, p, 5)
+    assert eng.alloc.free == eng.alloc.total
+
+
 def test_preemption_recomputes_and_still_matches(model):
     # 6 blocks = 96 token slots for three requests that grow to 3 x 40 tokens: someone must be preempted
     eng = _engine(model, kv_blocks=6, max_model_len=64)
@@ -295,7 +321,7 @@ def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model):
     tokens of the dense forward, and the counters add up."""
     import random
     rng = random.Random(7)
-    eng = _engine(model, kv_blocks=10, max_model_len=96, max_num_seqs=5, max_num_batched_tokens=64)
+    eng = _engine(model, kv_blocks=10, max_model_len=96, max_num_seqs=5, max_num_batched_tokens=24)   # prompts get chunked
     reqs, steps = [], 0
     while len(reqs) < 14 or not eng.idle():
         if len(reqs) < 14 and rng.random() < 0.4:
@@ -304,11 +330,11 @@ def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model):
         eng.step()
         steps += 1
         assert steps < 5000
-        held = [b for r in eng.running for b in r.blocks]
+        held = [b for r in eng.running + eng.prefilling for b in r.blocks]
         assert len(held) == len(set(held)), "a block is owned twice"
         assert len(held) + eng.alloc.free == eng.alloc.total, "blocks leaked"
-        assert all(not r.blocks for r in eng.waiting)
-        assert len(eng.running) <= 5
+        assert all(not r.blocks and r.prefilled == 0 for r in eng.waiting)
+        assert len(eng.running) + len(eng.prefilling) <= 5
     assert eng.metrics.preemptions > 0, "the scenario is meant to preempt"
     for p, r in reqs:
         assert r.done.is_set() and r.error is None

@@ -58,15 +58,16 @@ def hipcc() -> Optional[str]:
 def targets() -> List[Target]:
     ops = PKG / "ops" / "csrc"
     hdr = ops / "klm_ops.h"
-    ops_src = [ops / "gemm_bf16.hip", ops / "gemm_mx.hip", ops / "hbm.hip", ops / "llm.hip"]
+    ops_src = [ops / "gemm_bf16.hip", ops / "gemm_mx.hip", ops / "hbm.hip", ops / "llm_elementwise.hip", ops / "llm_attention.hip",
+               ops / "llm_skinny.hip"]
     ops_src = [s for s in ops_src if s.exists()]
     out: List[Target] = [
-        Target("klm_ops", LIB_DIR / "libklm_ops.so", ops_src, "hip-shared", deps=[hdr]),
+        Target("klm_ops", LIB_DIR / "libklm_ops.so", ops_src, "hip-shared", deps=[hdr, ops / "llm_common.h"]),
     ]
     burner = PKG / "loadgen" / "native" / "klm_burner.cpp"
     if burner.exists():
         out.append(Target("klm_burner", BIN_DIR / "klm_burner", [burner, *ops_src], "hip-exe",
-                          extra=[f"-I{ops}"], deps=[hdr]))
+                          extra=[f"-I{ops}"], deps=[hdr, ops / "llm_common.h"]))
     probe = PKG / "parallel" / "csrc" / "rccl_probe.cpp"
     if probe.exists():
         out.append(Target("klm_rccl_probe", BIN_DIR / "klm_rccl_probe", [probe], "hip-exe",

@@ -10,7 +10,7 @@ MI355X-first choices:
   * 288 GB of HBM3E: 8B (16 GB) and 70B (141 GB) both fit ONE GPU in bf16, so replicas scale as
     one process per GPU (data parallel serving) and no tensor-parallel all-reduce sits on the
     token path; the KV cache gets the rest of the HBM.
-  * attention, RMSNorm(+residual), RoPE+cache write and SwiGLU are the kernels of ops/csrc/llm.hip.
+  * attention, RMSNorm(+residual), RoPE+cache write and SwiGLU are the kernels of ops/csrc/llm_*.hip.
     At batch <= 16 (decode is then a pure weight-streaming problem) the projections run on the
     skinny MFMA kernel with the norm, the residual add and SwiGLU fused into it: 4 weight passes
     + rope + attention per layer. Larger batches and prefill use plain library GEMMs (hipBLASLt

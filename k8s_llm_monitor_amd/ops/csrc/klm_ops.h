@@ -62,7 +62,7 @@ int klm_hbm_checksum(const void* src, size_t bytes, void* sum64, void* stream);
 // traffic and ~0 MFMA work, used to tell "GFX activity" apart from useful work.
 int klm_spin(uint64_t cycles, int blocks, void* stream);
 
-// ---- LLM serving kernels (llm.hip): bf16, head_dim 128, KV blocks of 16 tokens --------------
+// ---- LLM serving kernels (llm_*.hip): bf16, head_dim 128, KV blocks of 16 tokens --------------
 // K cache [num_blocks][n_kv][16][128], V cache [num_blocks][n_kv][128][16] (transposed), both
 // bf16 and zero-initialised by the caller (stale slots are read and multiplied by zero).
 // kv_fp8 != 0 in the three calls below: the caches hold OCP e4m3 bytes (unit scale) in the same

@@ -28,193 +28,11 @@
 // query heads, so a 16-row tile is 16/G tokens x G heads and K/V are read once per group.
 // Decode (one token per sequence) uses G of the 16 rows; the kernel is HBM-bound and the
 // MFMA time is noise (16 MFMAs per 16 KiB of cache read).
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdint.h>
+#include "llm_common.h"
 
-#include "klm_ops.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+using namespace klm_llm;
 
 namespace {
-
-constexpr int HD = 128;               // head dim
-constexpr int BLK = 16;               // tokens per KV block
-constexpr int BLK_ELEMS = HD * BLK;   // elements of one (block, kv head) slab
-
-__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  __bf16 b = (__bf16)f;
-  return __builtin_bit_cast(uint16_t, b);
-}
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-__device__ __forceinline__ void unpack8(const uint4& a, float* v) {
-  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
-  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
-  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
-  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
-}
-__device__ __forceinline__ uint4 pack8(const float* v) {
-  uint4 r;
-  r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  r.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  r.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-  return r;
-}
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-// 8 e4m3 bytes (two dwords, k order = byte order) -> one bf16 MFMA fragment
-__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
-  const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, false);
-  const bf16x2 p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, true);
-  const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, false);
-  const bf16x2 p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, true);
-  bf16x8 r;
-  r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
-  r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
-  return r;
-}
-// one float -> one e4m3 byte (round to nearest even, saturating at +-448)
-__device__ __forceinline__ uint8_t f2fp8(float x) {
-  x = fminf(fmaxf(x, -448.f), 448.f);
-  return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xff);
-}
-
-// ------------------------------------------------------------------------------------
-// RMSNorm (optionally fused with the residual add): one 256-thread block per token, the
-// row stays in registers between the sum of squares and the scaled write (H <= 8192).
-//   RES: residual <- bf16(x + residual); out <- rmsnorm(residual) * w
-//  !RES:                                 out <- rmsnorm(x) * w
-// ------------------------------------------------------------------------------------
-template <bool RES>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict__ x,
-                                                      uint16_t* __restrict__ res,
-                                                      const uint16_t* __restrict__ w,
-                                                      uint16_t* __restrict__ out, int H, float eps) {
-  __shared__ float red[4];
-  const size_t base = (size_t)blockIdx.x * H;
-  const int tid = threadIdx.x;
-  float v[4][8];
-  float ss = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int e = (c * 256 + tid) * 8;
-    if (e < H) {
-      const uint4 a = *reinterpret_cast<const uint4*>(x + base + e);
-      unpack8(a, v[c]);
-      if (RES) {
-        const uint4 r = *reinterpret_cast<const uint4*>(res + base + e);
-        float rv[8];
-        unpack8(r, rv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[c][j] = bf2f(f2bf(v[c][j] + rv[j]));
-        *reinterpret_cast<uint4*>(res + base + e) = pack8(v[c]);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss += v[c][j] * v[c][j];
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  if ((tid & 63) == 0) red[tid >> 6] = ss;
-  __syncthreads();
-  ss = red[0] + red[1] + red[2] + red[3];
-  const float inv = rsqrtf(ss / (float)H + eps);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int e = (c * 256 + tid) * 8;
-    if (e < H) {
-      const uint4 wa = *reinterpret_cast<const uint4*>(w + e);
-      float wv[8], o[8];
-      unpack8(wa, wv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = v[c][j] * inv * wv[j];
-      *reinterpret_cast<uint4*>(out + base + e) = pack8(o);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// SwiGLU activation on the fused gate_up projection, whose output columns are interleaved in
-// groups of 8 (columns 16j..16j+7 = gate 8j..8j+7, columns 16j+8..16j+15 = up 8j..8j+7; the
-// weight rows are stored in that order so that the skinny kernel's 16-column tile holds both):
-//   out[t][8j + c] = silu(gu[t][16j + c]) * gu[t][16j + 8 + c]
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gu,
-                                                       uint16_t* __restrict__ out, size_t total) {
-  // `total` = T * F / 8 output vectors of 8; vector i reads the 32 contiguous bytes at gu + 16 i
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const uint4 g = *reinterpret_cast<const uint4*>(gu + i * 16);
-    const uint4 u = *reinterpret_cast<const uint4*>(gu + i * 16 + 8);
-    float gv[8], uv[8], o[8];
-    unpack8(g, gv);
-    unpack8(u, uv);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = gv[j] / (1.f + __expf(-gv[j])) * uv[j];
-    *reinterpret_cast<uint4*>(out + i * 8) = pack8(o);
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// RoPE (rotate-half pairing i <-> i+64, cos/sin from a table) on the q and k heads of a fused
-// qkv activation, in place, and the write of k / v into the paged cache. One wave per
-// (token, head).
-// ------------------------------------------------------------------------------------
-// KV8: the cache holds OCP e4m3 bytes (unit scale) instead of bf16; q and the in-place k stay bf16.
-template <bool KV8>
-__global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv,
-                                                         const float* __restrict__ cos_sin,
-                                                         const int* __restrict__ positions,
-                                                         const int* __restrict__ slots,
-                                                         void* __restrict__ kcv,
-                                                         void* __restrict__ vcv, int T, int n_q,
-                                                         int n_kv, int max_pos, int num_slots) {
-  uint16_t* kc = reinterpret_cast<uint16_t*>(kcv);
-  uint16_t* vc = reinterpret_cast<uint16_t*>(vcv);
-  uint8_t* kc8 = reinterpret_cast<uint8_t*>(kcv);
-  uint8_t* vc8 = reinterpret_cast<uint8_t*>(vcv);
-  const int lane = threadIdx.x & 63;
-  const int heads = n_q + 2 * n_kv;
-  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (gw >= (long)T * heads) return;
-  const int t = (int)(gw / heads), hs = (int)(gw - (long)t * heads);
-  uint16_t* row = qkv + ((size_t)t * heads + hs) * HD;
-  int pos = positions[t];
-  pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
-  const int slot = slots[t];
-  const bool cache_ok = slot >= 0 && slot < num_slots;
-  const uint16_t r1 = row[lane], r2 = row[lane + 64];
-  if (hs < n_q + n_kv) {
-    const float x1 = bf2f(r1), x2 = bf2f(r2);
-    const float c = cos_sin[(size_t)pos * HD + lane], s = cos_sin[(size_t)pos * HD + 64 + lane];
-    const uint16_t b1 = f2bf(x1 * c - x2 * s), b2 = f2bf(x2 * c + x1 * s);
-    row[lane] = b1;
-    row[lane + 64] = b2;
-    if (hs >= n_q && cache_ok) {
-      const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q)) * BLK_ELEMS + (slot % BLK) * HD;
-      if (KV8) {
-        kc8[off + lane] = f2fp8(bf2f(b1));
-        kc8[off + lane + 64] = f2fp8(bf2f(b2));
-      } else {
-        kc[off + lane] = b1;
-        kc[off + lane + 64] = b2;
-      }
-    }
-  } else if (cache_ok) {
-    const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q - n_kv)) * BLK_ELEMS + (slot % BLK);
-    if (KV8) {
-      vc8[off + lane * BLK] = f2fp8(bf2f(r1));
-      vc8[off + (lane + 64) * BLK] = f2fp8(bf2f(r2));
-    } else {
-      vc[off + lane * BLK] = r1;
-      vc[off + (lane + 64) * BLK] = r2;
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------
 // Attention over the paged cache.
@@ -758,250 +576,9 @@ __global__ __launch_bounds__(256, QT <= 2 ? 2 : 1) void paged_attn_prefill_lds_k
   }
 }
 
-// ------------------------------------------------------------------------------------
-// Skinny linear layer for decode at small batch (M <= 16 rows): out[M][N] = x[M][K] . W[N][K]^T.
-// The weight matrix is streamed from HBM exactly once, straight into MFMA operand registers
-// (no LDS staging): a block owns 16 output columns (16 rows of W), its waves split K, every
-// wave issues 16-byte loads of W[n0 + lane&15][k + (lane>>4)*8 ..] and of the matching x
-// fragment (L1/L2 resident, M*K*2 bytes), and one v_mfma_f32_16x16x32_bf16 per 1 KiB of W keeps
-// the math invisible next to the memory time. There is NO per-element VALU work in the loop:
-//   RMS      : the row's sum of squares is a second MFMA, x . x^T, whose diagonal is read at the
-//              end; the product is then scaled by rsqrt(mean(x^2) + eps). The norm's gain is
-//              folded into W's columns when the model is built.
-//   EPI_RES  : out = res + product  (the residual add; out may alias res)
-//   EPI_SWIGLU: W rows are gate/up interleaved by 8 (see silu_mul_kernel), the tile's 8 gate and
-//              8 up columns meet through one cross-lane exchange: out[M][N/2] = silu(g) * u
-// so a decoder layer at small batch is 4 of these + rope + attention. The K split is reduced
-// through LDS (deterministic, no atomics).
-// ------------------------------------------------------------------------------------
-enum { EPI_NONE = 0, EPI_RES = 1, EPI_SWIGLU = 2 };
-
-
-
-// RT = 16-row tiles of W per block: the x fragment is loaded once per RT weight fragments, which
-// matters when M is large enough for the x traffic (M*K*2 bytes per block, from L2) to rival the
-// block's weight traffic (16*RT*K*2 bytes).
-//
-// W8: the weights are OCP e4m3 bytes with one fp32 scale per output row (W8A16). A lane's 16-byte
-// load then carries 16 k-values; v_cvt_scalef32_pk_bf16_fp8 turns them into two bf16 MFMA fragments
-// in registers (8 VALU instructions per KiB-instruction of weights: still far from the memory time),
-// x stays bf16, and the row scale is applied to the fp32 result. Half the bytes per token.
-template <bool RMS, int EPI, int RT, bool W8>
-__global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
-    const uint16_t* __restrict__ x, int x_stride, const void* __restrict__ Wv, const float* __restrict__ wscale,
-    uint16_t* out, const uint16_t* res, int M, int N, int K, int kslice, float eps, int tiled) {
-  constexpr int MAXW = RT == 1 ? 16 : 8;
-  __shared__ f32x4 part[MAXW][RT][64];
-  __shared__ float ssq[MAXW][16];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = blockDim.x >> 6;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int n0 = blockIdx.x * 16 * RT;
-  const int k0 = w * kslice + fq * (W8 ? 16 : 8);
-  // Weight layout. Row-major [N][K]: a lane's 16 bytes sit at row n0+fr, k offset k0, and the next
-  // MFMA step is 64 bytes further along the row. Tiled (`tiled` != 0): the 1 KiB that one wave
-  // instruction loads (16 rows x 64 bytes) is stored contiguously in lane order, tiles ordered
-  // [row tile][k step], so a wave streams one contiguous run of kslice*16 elements - the access
-  // pattern HBM likes best. Both layouts have the same distance between row tiles (16*K elements).
-  const size_t wlane = tiled ? ((size_t)(n0 >> 4) * K + (size_t)w * kslice) * 16 + lane * (W8 ? 16 : 8)
-                             : (size_t)(n0 + fr) * K + k0;
-  const int wstep = tiled ? (W8 ? 1024 : 512) : (W8 ? 64 : 32);    // elements between consecutive MFMA steps
-  const uint16_t* wp = reinterpret_cast<const uint16_t*>(Wv) + wlane;      // bf16
-  const uint8_t* wp8 = reinterpret_cast<const uint8_t*>(Wv) + wlane;       // fp8
-  const size_t tile_stride = (size_t)16 * K;
-  const bool valid = fr < M;
-  const uint16_t* xp = x + (size_t)(valid ? fr : 0) * x_stride + k0;
-  f32x4 acc[RT], sq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 zero;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f;
-
-#define KLM_SKINNY_CHUNK(c)                                                                        \
-  {                                                                                                \
-    bf16x8 wf[RT][4], xf[4];                                                                       \
-    _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                 \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                \
-        wf[r][s] = *reinterpret_cast<const bf16x8*>(wp + r * tile_stride + ((c) / 32 + s) * wstep); \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                  \
-        xf[s] = valid ? *reinterpret_cast<const bf16x8*>(xp + (c) + s * 32) : zero;                \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
-      _Pragma("unroll") for (int r = 0; r < RT; ++r)                                               \
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r][s], xf[s], acc[r], 0, 0, 0);        \
-      if (RMS) sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[s], xf[s], sq, 0, 0, 0);            \
-    }                                                                                              \
-  }
-  // fp8 weights: 64 k-values per step; the lane's 16 bytes become fragments A0 (values 0..7) and A1
-  // (8..15), matched by the two 16-byte x loads at the same k offsets (any k order is fine for a
-  // contraction as long as both operands use it)
-#define KLM_SKINNY_CHUNK8(c)                                                                       \
-  {                                                                                                \
-    uint4 raw[RT];                                                                                 \
-    _Pragma("unroll") for (int r = 0; r < RT; ++r)                                                 \
-        raw[r] = *reinterpret_cast<const uint4*>(wp8 + r * tile_stride + ((c) / 64) * wstep);       \
-    const bf16x8 x0 = valid ? *reinterpret_cast<const bf16x8*>(xp + (c)) : zero;                   \
-    const bf16x8 x1 = valid ? *reinterpret_cast<const bf16x8*>(xp + (c) + 8) : zero;               \
-    _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                               \
-      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(raw[r].x, raw[r].y), x0, acc[r], 0, 0, 0); \
-      acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16(raw[r].z, raw[r].w), x1, acc[r], 0, 0, 0); \
-    }                                                                                              \
-    if (RMS) {                                                                                     \
-      sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, x0, sq, 0, 0, 0);                           \
-      sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, x1, sq, 0, 0, 0);                           \
-    }                                                                                              \
-  }
-  int c = 0;
-  if (W8) {
-    if (RT == 1) {
-      for (; c + 512 <= kslice; c += 512) {          // 8 weight loads in flight per wave, as in the bf16 loop
-        KLM_SKINNY_CHUNK8(c)
-        KLM_SKINNY_CHUNK8(c + 64)
-        KLM_SKINNY_CHUNK8(c + 128)
-        KLM_SKINNY_CHUNK8(c + 192)
-        KLM_SKINNY_CHUNK8(c + 256)
-        KLM_SKINNY_CHUNK8(c + 320)
-        KLM_SKINNY_CHUNK8(c + 384)
-        KLM_SKINNY_CHUNK8(c + 448)
-      }
-      for (; c + 256 <= kslice; c += 256) {
-        KLM_SKINNY_CHUNK8(c)
-        KLM_SKINNY_CHUNK8(c + 64)
-        KLM_SKINNY_CHUNK8(c + 128)
-        KLM_SKINNY_CHUNK8(c + 192)
-      }
-    }
-    for (; c + 128 <= kslice; c += 128) {
-      KLM_SKINNY_CHUNK8(c)
-      KLM_SKINNY_CHUNK8(c + 64)
-    }
-  } else {
-    if (RT == 1) {
-      for (; c + 256 <= kslice; c += 256) {
-        KLM_SKINNY_CHUNK(c)
-        KLM_SKINNY_CHUNK(c + 128)
-      }
-    }
-    for (; c < kslice; c += 128) KLM_SKINNY_CHUNK(c)
-  }
-#undef KLM_SKINNY_CHUNK
-#undef KLM_SKINNY_CHUNK8
-
-#pragma unroll
-  for (int r = 0; r < RT; ++r) part[w][r][lane] = acc[r];
-  if (RMS) {
-    // sq = x . x^T: D[row fq*4+i][col fr]; the diagonal element of row fr sits in lane (fr, fr/4), i = fr%4
-    const int i = fr & 3;
-    const float d = i == 0 ? sq[0] : (i == 1 ? sq[1] : (i == 2 ? sq[2] : sq[3]));
-    if (fq == (fr >> 2)) ssq[w][fr] = d;
-  }
-  __syncthreads();
-  // wave r of the block finishes row tile r (RT <= number of waves is checked by the launcher)
-  if (w < RT) {
-    f32x4 t = part[0][w][lane];
-    for (int ww = 1; ww < nw; ++ww) t += part[ww][w][lane];
-    if (RMS) {
-      float tot = 0.f;
-      for (int ww = 0; ww < nw; ++ww) tot += ssq[ww][fr];
-      t *= rsqrtf(tot / (float)K + eps);
-    }
-    const int nt = n0 + w * 16;
-    if (W8) {
-      const f32x4 ws = *reinterpret_cast<const f32x4*>(wscale + nt + fq * 4);
-      t *= ws;
-    }
-    if (EPI == EPI_SWIGLU) {
-      // lanes fq 0,1 hold gate columns fq*4+i, lanes fq 2,3 the matching up columns
-      f32x4 u;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) u[i] = __shfl_xor(t[i], 32);
-      if (valid && fq < 2) {
-        bf16x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(t[i] / (1.f + __expf(-t[i])) * u[i]);
-        *reinterpret_cast<bf16x4*>(out + (size_t)fr * (N >> 1) + (nt >> 1) + fq * 4) = o;
-      }
-    } else if (valid) {
-      const size_t idx = (size_t)fr * N + nt + fq * 4;
-      if (EPI == EPI_RES) {
-        const uint2 ra = *reinterpret_cast<const uint2*>(res + idx);
-        t[0] += __uint_as_float(ra.x << 16);
-        t[1] += __uint_as_float(ra.x & 0xffff0000u);
-        t[2] += __uint_as_float(ra.y << 16);
-        t[3] += __uint_as_float(ra.y & 0xffff0000u);
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (__bf16)t[i];
-      *reinterpret_cast<bf16x4*>(out + idx) = o;
-    }
-  }
-}
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-inline int group_shift(int G) {
-  switch (G) {
-    case 1: return 0;
-    case 2: return 1;
-    case 4: return 2;
-    case 8: return 3;
-    case 16: return 4;
-    default: return -1;
-  }
-}
-inline int launch_status() { return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP; }
-
 }  // namespace
 
 extern "C" {
-
-int klm_rmsnorm(const void* x, void* residual, const void* weight, void* out, int T, int H, float eps,
-                void* stream) {
-  if (T <= 0 || H <= 0 || H % 8 != 0 || H > 8192) return KLM_ERR_SHAPE;
-  if (!x || !weight || !out) return KLM_ERR_ARG;
-  if (!aligned16(x) || !aligned16(weight) || !aligned16(out) || !aligned16(residual)) return KLM_ERR_ALIGN;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (residual)
-    hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(T), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)residual,
-                       (const uint16_t*)weight, (uint16_t*)out, H, eps);
-  else
-    hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(T), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)nullptr,
-                       (const uint16_t*)weight, (uint16_t*)out, H, eps);
-  return launch_status();
-}
-
-int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream) {
-  if (T <= 0 || F <= 0 || F % 8 != 0) return KLM_ERR_SHAPE;
-  if (!gate_up || !out) return KLM_ERR_ARG;
-  if (!aligned16(gate_up) || !aligned16(out)) return KLM_ERR_ALIGN;
-  const size_t total = (size_t)T * (F / 8);
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     (const uint16_t*)gate_up, (uint16_t*)out, total);
-  return launch_status();
-}
-
-int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
-                   void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
-                   int kv_fp8, void* stream) {
-  if (T <= 0 || n_q <= 0 || n_kv <= 0 || max_pos <= 0 || num_slots <= 0 || num_slots > INT32_MAX)
-    return KLM_ERR_SHAPE;
-  if (!qkv || !cos_sin || !positions || !slots || !k_cache || !v_cache) return KLM_ERR_ARG;
-  const long waves = (long)T * (n_q + 2 * n_kv);
-  const long blocks = (waves + 3) / 4;
-  if (blocks > INT32_MAX) return KLM_ERR_SHAPE;
-  if (kv_fp8)
-    hipLaunchKernelGGL(rope_cache_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (uint16_t*)qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos,
-                       (int)num_slots);
-  else
-    hipLaunchKernelGGL(rope_cache_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (uint16_t*)qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos,
-                       (int)num_slots);
-  return launch_status();
-}
 
 int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                           const int32_t* ctx_lens, void* out, float* tmp_o, float* tmp_ml, int B, int q_stride,
@@ -1085,72 +662,6 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
 #undef KLM_PREFILL
 #undef KLM_PREFILL_K
   return launch_status();
-}
-
-static int skinny_launch(const void* x, int x_stride, const void* W, const float* wscale, bool w8, void* out,
-                         const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
-                         int row_tiles, int tiled, void* stream) {
-  if (M <= 0 || M > 16 || N <= 0 || N % 16 != 0 || K <= 0 || K % 128 != 0) return KLM_ERR_SHAPE;
-  if (epilogue < 0 || epilogue > 2) return KLM_ERR_VARIANT;
-  if (!x || !W || !out || ((epilogue == EPI_RES) != (residual != nullptr)) || (w8 && !wscale)) return KLM_ERR_ARG;
-  if (x_stride % 8 != 0 || x_stride < K) return KLM_ERR_SHAPE;
-  if (!aligned16(x) || !aligned16(W) || !aligned16(out) || !aligned16(residual) || !aligned16(wscale))
-    return KLM_ERR_ALIGN;
-  // rows of W per block: 64 when the x traffic would otherwise rival the weight traffic (M > 4)
-  // and N is large enough to still give every CU several blocks
-  int rt = row_tiles;
-  if (rt != 1 && rt != 4) rt = (M > 4 && N % 64 == 0 && N / 64 >= 384) ? 4 : 1;
-  if (rt == 4 && N % 64 != 0) rt = 1;
-  // measured on MI355X (scripts/gpu_skinny_bench.py): 8 waves split K up to 8192, 16 beyond; 4 with 64-row blocks
-  int nw = (waves == 1 || waves == 2 || waves == 4 || waves == 8 || waves == 16) ? waves
-                                                                                 : (rt == 4 ? 4 : (K > 8192 ? 16 : 8));
-  if (rt == 4 && nw > 8) nw = 8;
-  while (nw > 1 && K % (128 * nw) != 0) nw >>= 1;
-  if (nw < rt) rt = 1;
-  const int kslice = K / nw;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(N / (16 * rt)), block(64 * nw);
-  const uint16_t* xx = (const uint16_t*)x;
-  uint16_t* oo = (uint16_t*)out;
-  const uint16_t* rr = (const uint16_t*)residual;
-#define KLM_SKINNY_L(R, E, T, Q)                                                                            \
-  hipLaunchKernelGGL((skinny_linear_kernel<R, E, T, Q>), grid, block, 0, s, xx, x_stride, W, wscale, oo, rr, M, N, \
-                     K, kslice, eps, tiled)
-#define KLM_SKINNY(R, E)                         \
-  do {                                           \
-    if (w8) {                                    \
-      if (rt == 4) KLM_SKINNY_L(R, E, 4, true);  \
-      else KLM_SKINNY_L(R, E, 1, true);          \
-    } else {                                     \
-      if (rt == 4) KLM_SKINNY_L(R, E, 4, false); \
-      else KLM_SKINNY_L(R, E, 1, false);         \
-    }                                            \
-  } while (0)
-  if (rms) {
-    if (epilogue == EPI_NONE) KLM_SKINNY(true, EPI_NONE);
-    else if (epilogue == EPI_RES) KLM_SKINNY(true, EPI_RES);
-    else KLM_SKINNY(true, EPI_SWIGLU);
-  } else {
-    if (epilogue == EPI_NONE) KLM_SKINNY(false, EPI_NONE);
-    else if (epilogue == EPI_RES) KLM_SKINNY(false, EPI_RES);
-    else KLM_SKINNY(false, EPI_SWIGLU);
-  }
-#undef KLM_SKINNY
-#undef KLM_SKINNY_L
-  return launch_status();
-}
-
-int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, const void* residual, int M, int N,
-                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, int tiled, void* stream) {
-  return skinny_launch(x, x_stride, W, nullptr, false, out, residual, M, N, K, rms, epilogue, eps, waves, row_tiles,
-                       tiled, stream);
-}
-
-int klm_skinny_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, void* out,
-                         const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
-                         int row_tiles, int tiled, void* stream) {
-  return skinny_launch(x, x_stride, W8, wscale, true, out, residual, M, N, K, rms, epilogue, eps, waves, row_tiles,
-                       tiled, stream);
 }
 
 }  // extern "C"

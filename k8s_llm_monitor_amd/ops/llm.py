@@ -1,6 +1,6 @@
 """LLM serving ops: RMSNorm, SwiGLU, RoPE + paged-cache write, paged attention (decode, prefill).
 
-On a GPU every call runs the hand-written gfx950 kernel of ``csrc/llm.hip`` (ctypes, current
+On a GPU every call runs the hand-written gfx950 kernel of ``csrc/llm_*.hip`` (ctypes, current
 torch stream, no allocation inside the launcher, so the calls can be captured into a hipGraph);
 a missing library is an error there. On CPU tensors the fp32 reference of ``ops.ref`` runs, which
 is what lets the serving engine be tested without a GPU.
@@ -30,7 +30,7 @@ def _lib():
     if not _bound:
         vp, i, f, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
         if not hasattr(lib, "klm_paged_attn_decode"):
-            raise KlmOpsError("libklm_ops.so was built without llm.hip: run `python -m k8s_llm_monitor_amd.build --force`")
+            raise KlmOpsError("libklm_ops.so was built without the llm_*.hip kernels: run `python -m k8s_llm_monitor_amd.build --force`")
         lib.klm_rmsnorm.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         lib.klm_silu_mul.argtypes = [vp, vp, i, i, vp]
         lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, i, vp]

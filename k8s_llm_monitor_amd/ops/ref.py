@@ -1,10 +1,10 @@
-"""Plain PyTorch fp32 references of the LLM kernels in ``csrc/llm.hip``.
+"""Plain PyTorch fp32 references of the LLM kernels in ``csrc/llm_*.hip``.
 
 Two users: the numerics tests (``tests/test_gpu_llm.py`` compares every HIP kernel against
 these on the same inputs) and the CPU path of ``ops.llm`` (a tiny model steps through the
 serving engine in the CPU test suite). On a GPU the HIP kernels run, never these.
 
-Cache layouts (see llm.hip): K ``[blocks, n_kv, 16, 128]``, V ``[blocks, n_kv, 128, 16]``.
+Cache layouts (see llm_attention.hip): K ``[blocks, n_kv, 16, 128]``, V ``[blocks, n_kv, 128, 16]``.
 """
 from __future__ import annotations
 

@@ -1,4 +1,4 @@
-"""Numerics of the LLM serving kernels (ops/csrc/llm.hip) against the fp32 PyTorch references of
+"""Numerics of the LLM serving kernels (ops/csrc/llm_*.hip) against the fp32 PyTorch references of
 ops/ref.py on the same inputs. GPU only; the CPU dispatch of the same functions is covered by
 tests/test_llm_cpu.py."""
 import math

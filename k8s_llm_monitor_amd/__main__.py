@@ -96,7 +96,38 @@ def _cmd_validate(a) -> int:
     return phases.main_from_args(a)
 
 
+def _cmd_serve_llm_replicas(a) -> int:
+    """--gpus N: one engine process per GPU (data parallel) behind the router on --port."""
+    from .serving.router import ReplicaSet, Router
+    child = ["--model", a.model, "--max-num-seqs", str(a.max_num_seqs), "--max-model-len", str(a.max_model_len),
+             "--kv-blocks", str(a.kv_blocks), "--kv-fraction", str(a.kv_fraction), "--decode-weights", a.decode_weights,
+             "--kv-cache-dtype", a.kv_cache_dtype, "--load-rps", str(a.load_rps / a.gpus), "--prompt-len", str(a.prompt_len),
+             "--output-len", str(a.output_len)] + (["--no-graphs"] if a.no_graphs else [])
+    kind = "cpu" if a.device == "cpu" else "cuda"
+    base = a.replica_base_port or a.port + 1
+    rs = ReplicaSet(list(range(a.gpus)), base, child, host="127.0.0.1", device_kind=kind).start()
+    stop = threading.Event()
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        signal.signal(sig, lambda *_: stop.set())
+    try:
+        if not rs.wait_ready(a.ready_timeout):
+            print("a replica did not come up", file=sys.stderr, flush=True)
+            return 1
+        with Router(rs.urls, host=a.host, port=a.port) as router:
+            print(f"router on {router.url} -> {a.gpus} replica(s): {rs.urls}", flush=True)
+            t0 = time.time()
+            while not stop.wait(1.0):
+                if a.duration and time.time() - t0 > a.duration:
+                    break
+            print(json.dumps({k: v for k, v in router.stats().items() if k != "replicas"}), flush=True)
+    finally:
+        rs.stop()
+    return 0
+
+
 def _cmd_serve_llm(a) -> int:
+    if a.gpus > 1:
+        return _cmd_serve_llm_replicas(a)
     from .serving import Engine, EngineConfig
     from .serving.loadclient import OpenLoopLoad
     from .serving.server import LlmServer
@@ -175,6 +206,9 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--kv-blocks", type=int, default=0, help="KV blocks of 16 tokens (0: from --kv-fraction)")
     p.add_argument("--kv-fraction", type=float, default=0.5, help="share of the free HBM given to the KV cache")
     p.add_argument("--no-graphs", action="store_true")
+    p.add_argument("--gpus", type=int, default=1, help="N > 1: one engine process per GPU behind a router on --port")
+    p.add_argument("--replica-base-port", type=int, default=0, help="first replica port (default: --port + 1)")
+    p.add_argument("--ready-timeout", type=float, default=300.0)
     p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                    help="fp8: W8A16 weight copies for decode at batch <= 16 (half the bytes per token)")
     p.add_argument("--kv-cache-dtype", default="bf16", choices=["bf16", "fp8"],

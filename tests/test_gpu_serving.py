@@ -175,3 +175,33 @@ def test_chunked_prefill_on_the_gpu_gives_the_first_token_of_the_unchunked_run(g
         assert eng.alloc.free == eng.alloc.total
     agree = sum(a == b for a, b in zip(*firsts))
     assert agree >= len(prompts) - 1, firsts
+
+
+def test_two_replica_processes_on_the_gpu_behind_the_router():
+    """The per-GPU replica launcher with real GPU children. One MI355X is all a test box has, so both
+    children are pinned to device 0 (on a node each gets its own); what is checked is the launch path:
+    HIP_VISIBLE_DEVICES set before the child touches HIP, readiness, routing, merged metrics."""
+    import socket
+    from k8s_llm_monitor_amd.collectors.vllm import parse_exposition
+    from k8s_llm_monitor_amd.serving.router import ReplicaSet, Router
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    base = s.getsockname()[1]
+    s.close()
+    rs = ReplicaSet([0, 0], base, ["--model", "small", "--kv-blocks", "256", "--max-model-len", "512",
+                                   "--max-num-seqs", "8"]).start()
+    try:
+        assert rs.wait_ready(240), "replicas did not come up"
+        with Router(rs.urls) as router:
+            outs = []
+            for i in range(4):
+                req = urllib.request.Request(router.url + "/v1/completions",
+                                             data=json.dumps({"prompt_len": 40, "seed": i, "max_tokens": 6}).encode(),
+                                             headers={"Content-Type": "application/json"})
+                outs.append(json.load(urllib.request.urlopen(req, timeout=120)))
+            assert {o["replica"] for o in outs} == {0, 1} and all(len(o["choices"][0]["token_ids"]) == 6 for o in outs)
+            text = urllib.request.urlopen(router.url + "/metrics", timeout=10).read().decode()
+            gen = {l.get("replica"): v for (n, l, v) in parse_exposition(text) if n == "vllm:generation_tokens_total"}
+            assert gen == {"0": 12.0, "1": 12.0}
+    finally:
+        rs.stop()

@@ -197,7 +197,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--phases", default="all", help="all or a comma list of hbm,activity,mem,overhead,latency,llm,vllm")
     p.add_argument("--device", type=int, default=0)
     p = sub.add_parser("serve-llm")
-    p.add_argument("--model", default="llama3-8b", help="llama3-8b, llama3-70b, small, tiny")
+    p.add_argument("--model", default="llama3-8b", help="llama3-8b, llama3-70b, mistral-7b, small, tiny")
     p.add_argument("--device", default="cuda")
     p.add_argument("--host", default="0.0.0.0")
     p.add_argument("--port", type=int, default=8000)

@@ -73,6 +73,9 @@ class LlamaConfig:
 PRESETS: Dict[str, LlamaConfig] = {
     "llama3-8b": LlamaConfig("llama3-8b", vocab=128256, hidden=4096, layers=32, n_q=32, n_kv=8, ffn=14336),
     "llama3-70b": LlamaConfig("llama3-70b", vocab=128256, hidden=8192, layers=80, n_q=64, n_kv=8, ffn=28672),
+    # the same decoder block with other published shapes (GQA, head_dim 128, SwiGLU, no biases)
+    "mistral-7b": LlamaConfig("mistral-7b", vocab=32768, hidden=4096, layers=32, n_q=32, n_kv=8, ffn=14336,
+                              rope_theta=1000000.0, max_pos=32768),
     # same block structure, sized for CPU tests and smoke runs
     "tiny": LlamaConfig("tiny", vocab=512, hidden=256, layers=2, n_q=4, n_kv=2, ffn=512, max_pos=1024),
     "small": LlamaConfig("small", vocab=32000, hidden=2048, layers=4, n_q=16, n_kv=4, ffn=8192, max_pos=8192),

@@ -76,6 +76,7 @@ def test_presets_have_the_published_shapes():
     assert abs(c.params() / 1e9 - 8.03) < 0.01                      # Llama-3-8B: 8.03 B parameters
     assert c.kv_bytes_per_token() == 131072                          # 128 KiB of KV per token in bf16
     assert abs(PRESETS["llama3-70b"].params() / 1e9 - 70.55) < 0.05
+    assert abs(PRESETS["mistral-7b"].params() / 1e9 - 7.25) < 0.01                 # Mistral-7B-v0.3
 
 
 def test_block_allocator():

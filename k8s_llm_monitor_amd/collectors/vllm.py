@@ -170,22 +170,50 @@ class VllmDirectSource(VllmSource):
         self._rates = RateTracker(bits=63)
         self._prev_buckets: Dict[str, Dict[float, float]] = {}
 
+    def _replica_rows(self, per_ep: List[Tuple[str, Optional[List[Sample]]]], t: float) -> List[Dict[str, Any]]:
+        """One row per serving replica: per endpoint, and per ``replica`` label inside an endpoint
+        (the router of serving/router.py merges its replicas into one exposition). The totals hide a
+        saturated replica next to idle ones; these rows do not."""
+        rows: List[Dict[str, Any]] = []
+        for ep, smp in per_ep:
+            if smp is None:
+                rows.append({"endpoint": ep, "up": False})
+                continue
+            reps = sorted({l["replica"] for (_, l, _) in smp if "replica" in l}) or [None]
+            for rep in reps:
+                mine = [x for x in smp if rep is None or x[1].get("replica") == rep]
+                kv = _max(mine, KV_NAMES)
+                gen = _sum(mine, GEN_TOKENS)
+                key = f"gen|{ep}|{rep}"
+                rows.append({"endpoint": ep, "replica": rep, "up": True,
+                             "running": _sum(mine, (RUNNING,)), "waiting": _sum(mine, (WAITING,)),
+                             "kvCachePercent": None if kv is None else kv * 100.0,
+                             "tokensPerSec": self._rates.update(key, t, None if gen is None else int(gen))})
+        return rows
+
     def _sample(self) -> Dict[str, Any]:
         samples: List[Sample] = []
+        per_ep: List[Tuple[str, Optional[List[Sample]]]] = []
         ok = 0
         errs = []
         for ep in self.endpoints:
             try:
-                samples.extend(parse_exposition(self._fetch(ep)))
+                smp = parse_exposition(self._fetch(ep))
+                samples.extend(smp)
+                per_ep.append((ep, smp))
                 ok += 1
             except Exception as e:
                 errs.append(f"{ep}: {type(e).__name__}")
+                per_ep.append((ep, None))
         if ok == 0:
             if errs:
                 self.last_error = "; ".join(errs)
             return {"available": False, "endpoints": 0}
         t = self._clock()
         out: Dict[str, Any] = {"available": True, "endpoints": ok}
+        rows = self._replica_rows(per_ep, t)
+        if len(rows) > 1:
+            out["replicas"] = rows
         out["models"] = sorted({l["model_name"] for (_, l, _) in samples if "model_name" in l})
         kv = _max(samples, KV_NAMES)
         out["kvCachePercent"] = None if kv is None else kv * 100.0

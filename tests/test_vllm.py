@@ -105,3 +105,37 @@ def test_a_vllm_endpoint_that_stops_answering_raises_an_outage_alert():
     assert keys(a)["vllm/down"] == "critical"                             # level-triggered while it lasts
     a, st = check_alerts(host, [], [], st, cfg, up2)
     assert "vllm/down" not in keys(a)
+
+
+def test_direct_source_reports_one_row_per_replica():
+    """Two endpoints, one of them a router that merges two replicas: three rows, so a saturated
+    replica is visible next to idle ones (the totals and the max alone would hide which one)."""
+    from k8s_llm_monitor_amd.collectors.vllm import VllmDirectSource
+    t = [0.0]
+    gen = {"a": 0, "r0": 0, "r1": 0}
+
+    def fetch(url):
+        if "pod-a" in url:
+            return (f'vllm:num_requests_running{{model_name="m"}} 2\nvllm:num_requests_waiting{{model_name="m"}} 0\n'
+                    f'vllm:kv_cache_usage_perc{{model_name="m"}} 0.10\nvllm:generation_tokens_total{{model_name="m"}} {gen["a"]}\n')
+        if "router" in url:
+            return "".join(f'vllm:num_requests_running{{model_name="m",replica="{i}"}} {run}\n'
+                           f'vllm:num_requests_waiting{{model_name="m",replica="{i}"}} {wait}\n'
+                           f'vllm:kv_cache_usage_perc{{model_name="m",replica="{i}"}} {kv}\n'
+                           f'vllm:generation_tokens_total{{model_name="m",replica="{i}"}} {gen["r%d" % i]}\n'
+                           for i, (run, wait, kv) in enumerate([(30, 200, 0.99), (1, 0, 0.02)]))
+        raise OSError("connection refused")
+
+    src = VllmDirectSource(["http://pod-a:8000", "http://router:8000", "http://pod-dead:8000"], fetch=fetch, clock=lambda: t[0])
+    src.sample()
+    t[0] += 2.0
+    gen.update(a=1000, r0=4000, r1=100)
+    v = src.sample()
+    assert v["endpoints"] == 2 and v["running"] == 33 and v["waiting"] == 200 and v["kvCachePercent"] == pytest.approx(99.0)
+    rows = {(r["endpoint"].split("//")[1].split(":")[0], r.get("replica")): r for r in v["replicas"]}
+    assert set(rows) == {("pod-a", None), ("router", "0"), ("router", "1"), ("pod-dead", None)}
+    assert rows[("pod-dead", None)]["up"] is False
+    hot = rows[("router", "0")]
+    assert hot["waiting"] == 200 and hot["kvCachePercent"] == pytest.approx(99.0) and hot["tokensPerSec"] == pytest.approx(2000.0)
+    assert rows[("router", "1")]["tokensPerSec"] == pytest.approx(50.0) and rows[("pod-a", None)]["tokensPerSec"] == pytest.approx(500.0)
+    assert v["tokensPerSec"] == pytest.approx(2550.0)

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
 // (token, head).
 // ------------------------------------------------------------------------------------
 // KV8: the cache holds OCP e4m3 bytes (unit scale) instead of bf16; q and the in-place k stay bf16.
+// Eight lanes per (token, head): lane j of the group owns dims 8j..8j+7 and their partners 64+8j..,
+// so every global access of the activation is a 16-byte vector (a 2-byte-per-lane version ran the
+// 4096-token prefill's rope at 2.2 TB/s); only the transposed V cache write stays element-wise.
 template <bool KV8>
 __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv,
                                                          const float* __restrict__ cos_sin,
@@ -99,41 +102,62 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
   uint16_t* vc = reinterpret_cast<uint16_t*>(vcv);
   uint8_t* kc8 = reinterpret_cast<uint8_t*>(kcv);
   uint8_t* vc8 = reinterpret_cast<uint8_t*>(vcv);
-  const int lane = threadIdx.x & 63;
   const int heads = n_q + 2 * n_kv;
-  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (gw >= (long)T * heads) return;
-  const int t = (int)(gw / heads), hs = (int)(gw - (long)t * heads);
+  const long pair = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;       // (token, head) index
+  if (pair >= (long)T * heads) return;
+  const int j = threadIdx.x & 7;
+  const int t = (int)(pair / heads), hs = (int)(pair - (long)t * heads);
   uint16_t* row = qkv + ((size_t)t * heads + hs) * HD;
   int pos = positions[t];
   pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
   const int slot = slots[t];
   const bool cache_ok = slot >= 0 && slot < num_slots;
-  const uint16_t r1 = row[lane], r2 = row[lane + 64];
+  const uint4 a1 = *reinterpret_cast<const uint4*>(row + j * 8);
+  const uint4 a2 = *reinterpret_cast<const uint4*>(row + 64 + j * 8);
+  float x1[8], x2[8];
+  unpack8(a1, x1);
+  unpack8(a2, x2);
   if (hs < n_q + n_kv) {
-    const float x1 = bf2f(r1), x2 = bf2f(r2);
-    const float c = cos_sin[(size_t)pos * HD + lane], s = cos_sin[(size_t)pos * HD + 64 + lane];
-    const uint16_t b1 = f2bf(x1 * c - x2 * s), b2 = f2bf(x2 * c + x1 * s);
-    row[lane] = b1;
-    row[lane + 64] = b2;
+    const float* cs = cos_sin + (size_t)pos * HD + j * 8;
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + 64), s1 = *reinterpret_cast<const f32x4*>(cs + 68);
+    float y1[8], y2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float c = i < 4 ? c0[i & 3] : c1[i & 3], sn = i < 4 ? s0[i & 3] : s1[i & 3];
+      y1[i] = bf2f(f2bf(x1[i] * c - x2[i] * sn));
+      y2[i] = bf2f(f2bf(x2[i] * c + x1[i] * sn));
+    }
+    const uint4 o1 = pack8(y1), o2 = pack8(y2);
+    *reinterpret_cast<uint4*>(row + j * 8) = o1;
+    *reinterpret_cast<uint4*>(row + 64 + j * 8) = o2;
     if (hs >= n_q && cache_ok) {
-      const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q)) * BLK_ELEMS + (slot % BLK) * HD;
+      const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q)) * BLK_ELEMS + (slot % BLK) * HD + j * 8;
       if (KV8) {
-        kc8[off + lane] = f2fp8(bf2f(b1));
-        kc8[off + lane + 64] = f2fp8(bf2f(b2));
+        uint2 p1, p2;
+        p1.x = f2fp8(y1[0]) | (f2fp8(y1[1]) << 8) | (f2fp8(y1[2]) << 16) | ((uint32_t)f2fp8(y1[3]) << 24);
+        p1.y = f2fp8(y1[4]) | (f2fp8(y1[5]) << 8) | (f2fp8(y1[6]) << 16) | ((uint32_t)f2fp8(y1[7]) << 24);
+        p2.x = f2fp8(y2[0]) | (f2fp8(y2[1]) << 8) | (f2fp8(y2[2]) << 16) | ((uint32_t)f2fp8(y2[3]) << 24);
+        p2.y = f2fp8(y2[4]) | (f2fp8(y2[5]) << 8) | (f2fp8(y2[6]) << 16) | ((uint32_t)f2fp8(y2[7]) << 24);
+        *reinterpret_cast<uint2*>(kc8 + off) = p1;
+        *reinterpret_cast<uint2*>(kc8 + off + 64) = p2;
       } else {
-        kc[off + lane] = b1;
-        kc[off + lane + 64] = b2;
+        *reinterpret_cast<uint4*>(kc + off) = o1;
+        *reinterpret_cast<uint4*>(kc + off + 64) = o2;
       }
     }
   } else if (cache_ok) {
     const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q - n_kv)) * BLK_ELEMS + (slot % BLK);
-    if (KV8) {
-      vc8[off + lane * BLK] = f2fp8(bf2f(r1));
-      vc8[off + (lane + 64) * BLK] = f2fp8(bf2f(r2));
-    } else {
-      vc[off + lane * BLK] = r1;
-      vc[off + (lane + 64) * BLK] = r2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int d1 = j * 8 + i, d2 = 64 + j * 8 + i;
+      if (KV8) {
+        vc8[off + d1 * BLK] = f2fp8(x1[i]);
+        vc8[off + d2 * BLK] = f2fp8(x2[i]);
+      } else {
+        vc[off + d1 * BLK] = f2bf(x1[i]);
+        vc[off + d2 * BLK] = f2bf(x2[i]);
+      }
     }
   }
 }
@@ -175,8 +199,9 @@ int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, co
   if (T <= 0 || n_q <= 0 || n_kv <= 0 || max_pos <= 0 || num_slots <= 0 || num_slots > INT32_MAX)
     return KLM_ERR_SHAPE;
   if (!qkv || !cos_sin || !positions || !slots || !k_cache || !v_cache) return KLM_ERR_ARG;
-  const long waves = (long)T * (n_q + 2 * n_kv);
-  const long blocks = (waves + 3) / 4;
+  if (!aligned16(qkv) || !aligned16(cos_sin) || !aligned16(k_cache) || !aligned16(v_cache)) return KLM_ERR_ALIGN;
+  const long pairs = (long)T * (n_q + 2 * n_kv);       // 8 lanes per (token, head): 32 pairs per 256-thread block
+  const long blocks = (pairs + 31) / 32;
   if (blocks > INT32_MAX) return KLM_ERR_SHAPE;
   if (kv_fp8)
     hipLaunchKernelGGL(rope_cache_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -146,6 +146,8 @@ class Engine:
         self._stop = threading.Event()
         self.errors = 0
         self.last_error: Optional[str] = None
+        # the last model launches, for /trace: (start, seconds, kind, sequences, tokens)
+        self.step_log: Deque[tuple] = deque(maxlen=4096)
         self.step_seconds = {"prefill": 0.0, "decode": 0.0}
         self.step_counts = {"prefill": 0, "decode": 0}
         # decode: static device inputs (graph capture needs stable pointers) + pinned host mirrors
@@ -307,6 +309,7 @@ class Engine:
                                  self.alloc.usage)
         self.step_seconds["prefill"] += now - t0
         self.step_counts["prefill"] += 1
+        self.step_log.append((t0, now - t0, "prefill", len(chunks), len(toks)))
         return max(produced, 1)
 
     def _make_room(self) -> None:
@@ -374,6 +377,7 @@ class Engine:
             self.metrics.on_step(n, 0, len(self.running) + len(self.prefilling), len(self.waiting), self.alloc.usage)
         self.step_seconds["decode"] += now - t0
         self.step_counts["decode"] += 1
+        self.step_log.append((t0, now - t0, "decode", n, n))
         return n
 
     def _decode_call(self, b: int) -> None:
@@ -460,6 +464,19 @@ class Engine:
             self._thread = None
         if abort_pending:
             self._fail_all("engine stopped")
+
+    def trace(self) -> Dict[str, object]:
+        """The recent model launches as a Chrome trace (chrome://tracing, Perfetto): one track per kind,
+        complete events with the batch shape as arguments."""
+        ev = []
+        for (t0, dt, kind, seqs, toks) in list(self.step_log):
+            ev.append({"name": f"{kind} {seqs}x" if kind == "decode" else f"prefill {toks} tok", "cat": kind, "ph": "X",
+                       "ts": t0 * 1e6, "dur": dt * 1e6, "pid": 1, "tid": 1 if kind == "prefill" else 2,
+                       "args": {"sequences": seqs, "tokens": toks}})
+        meta = [{"name": "thread_name", "ph": "M", "pid": 1, "tid": 1, "args": {"name": "prefill launches"}},
+                {"name": "thread_name", "ph": "M", "pid": 1, "tid": 2, "args": {"name": "decode launches"}},
+                {"name": "process_name", "ph": "M", "pid": 1, "args": {"name": f"klm engine {self.mcfg.name}"}}]
+        return {"traceEvents": meta + ev, "displayTimeUnit": "ms"}
 
     def describe(self) -> Dict[str, object]:
         return {"model": self.mcfg.name, "params": self.mcfg.params(), "weight_bytes": self.model.weight_bytes(),

@@ -5,6 +5,7 @@
     GET  /v1/models          the served model
     POST /v1/completions     {"prompt": [token ids] | "prompt_len": n, "max_tokens": m} -> token ids
     GET  /stats[?window=S]   exact ground truth (quantiles, rates) + engine description
+    GET  /trace              the recent model launches as a Chrome trace (open in Perfetto)
 
 There is no tokenizer (no network to fetch one): prompts are token ids, or a length from which
 random ids are drawn. Standard library only.
@@ -59,6 +60,8 @@ class LlmServer:
                     except ValueError:
                         w = None
                     self._json(200, {"truth": outer.engine.metrics.truth(w), "engine": outer.engine.describe()})
+                elif u.path == "/trace":
+                    self._json(200, outer.engine.trace())
                 else:
                     self._json(404, {"error": "not found"})
 

@@ -223,6 +223,10 @@ def test_http_server_and_open_loop_load(model):
             assert st["truth"]["totals"]["finished"] == len(load.requests) + 1
             assert st["engine"]["model"] == "tiny"
             assert json.load(urllib.request.urlopen(srv.url + "/v1/models", timeout=5))["data"][0]["id"] == "tiny"
+            tr = json.load(urllib.request.urlopen(srv.url + "/trace", timeout=5))
+            ev = [e for e in tr["traceEvents"] if e["ph"] == "X"]
+            assert {e["cat"] for e in ev} == {"prefill", "decode"} and all(e["dur"] > 0 for e in ev)
+            assert sum(e["args"]["tokens"] for e in ev if e["cat"] == "decode") + sum(1 for e in ev if e["cat"] == "prefill") >= 5
     finally:
         eng.stop()
 

@@ -91,8 +91,8 @@ class LlmServer:
                 if not r.done.wait(outer.request_timeout):
                     self._json(504, {"error": "timed out", "id": r.rid})
                     return
-                if r.error:
-                    self._json(400, {"error": r.error, "id": r.rid})
+                if r.error:                      # a bad prompt is the caller's fault, anything else the server's
+                    self._json(400 if r.error.startswith("prompt") else 503, {"error": r.error, "id": r.rid})
                     return
                 self._json(200, {"id": f"cmpl-{r.rid}", "object": "text_completion", "model": outer.engine.mcfg.name,
                                  "choices": [{"index": 0, "token_ids": r.out, "finish_reason": "length"}],

@@ -122,8 +122,12 @@ class Router:
                     out = json.loads(r.read())
                 out["replica"] = i
                 return 200, json.dumps(out).encode()
-            except urllib.error.HTTPError as e:          # the replica answered: its verdict stands
-                return e.code, e.read() or b"{}"
+            except urllib.error.HTTPError as e:
+                if e.code != 503:                        # the replica judged the request: its verdict stands
+                    return e.code, e.read() or b"{}"
+                with self._lock:                         # 503: the replica is stopping or failed the launch: try another
+                    self.failed[i] += 1
+                tried.append(i)
             except (urllib.error.URLError, OSError):
                 with self._lock:
                     self.failed[i] += 1

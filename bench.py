@@ -40,11 +40,16 @@ def parse_args():
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--no-validation", action="store_true",
                     help="skip the fidelity / overhead / alert-latency phases")
+    ap.add_argument("--validation-phases", default="all",
+                    help="comma list of hbm,activity,mem,overhead,latency,llm,vllm,xgmi (xgmi needs a process group)")
     ap.add_argument("--no-probe", action="store_true", help="skip the RCCL all-reduce size sweep (N > 1)")
     ap.add_argument("--probe-max-bytes", type=int, default=1 << 28)
     ap.add_argument("--cpu-rehearsal", action="store_true",
                     help="run the same step loop on CPU with gloo and a torch.matmul stand-in (tests the launch / "
                          "reduction / JSON contract without a GPU; the number it prints is not a benchmark)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path (process group, communication stream, probe, xGMI check) even with "
+                         "one rank: a one-rank RCCL communicator rehearses the launch on a single-GPU box")
     ap.add_argument("--sample-period", type=float, default=0.0,
                     help="telemetry period in s during the timed region (0 = config default 5 s)")
     return ap.parse_args()
@@ -68,7 +73,8 @@ def main():
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    distributed = world > 1 or a.force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if a.cpu_rehearsal:
@@ -80,7 +86,7 @@ def main():
     result = benchlib.run(a, rank=rank, world=world, dev=dev, ops=ops)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

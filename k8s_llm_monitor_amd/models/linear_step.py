@@ -26,14 +26,15 @@ class LinearLayerStep:
     2*size^2-byte all-reduce per step.
     """
 
-    def __init__(self, torch, dist, ops, dev, world: int, size: int, gemm=None):
+    def __init__(self, torch, dist, ops, dev, world: int, size: int, gemm=None, distributed=None):
         self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
+        dd = self.distributed = (world > 1) if distributed is None else bool(distributed)
         # `gemm(a, b, out)` computes out = a @ b.T; the default is the hand-written MFMA kernel.
         # CPU tests of the stream/event/all-reduce logic pass a torch.matmul stand-in.
         self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out, variant=1))
         self.gpu = dev.type == "cuda"
         g = torch.Generator(device=dev)
-        g.manual_seed(1234 + (dist.get_rank() if world > 1 else 0))
+        g.manual_seed(1234 + (dist.get_rank() if dd else 0))
 
         def rnd():
             # uniform [-1, 1) operands: zero-filled operands read ~15-20 % high (DVFS)
@@ -47,11 +48,11 @@ class LinearLayerStep:
         self.c = [torch.empty(size, size, device=dev, dtype=torch.bfloat16) for _ in range(2)]    # dW, double-buffered
         self.size = size
         self.flops = 3 * 2.0 * size * size * size
-        self.comm = torch.cuda.Stream(device=dev) if (world > 1 and self.gpu) else None
+        self.comm = torch.cuda.Stream(device=dev) if (dd and self.gpu) else None
         self.ev_gemm = [torch.cuda.Event() for _ in range(2)] if self.gpu else []
         self.ev_comm = [torch.cuda.Event() for _ in range(2)] if self.gpu else []
         self.i = 0
-        self.allreduce_bytes = size * size * 2 if world > 1 else 0
+        self.allreduce_bytes = size * size * 2 if dd else 0
 
     def step(self):
         torch = self.torch
@@ -60,7 +61,7 @@ class LinearLayerStep:
             self.gemm(self.x, self.w, self.y)
             self.gemm(self.dy, self.wt, self.dx)
             self.gemm(self.dyt, self.xt, self.c[k])
-            if self.world > 1:
+            if self.distributed:
                 self.dist.all_reduce(self.c[k])
             self.i += 1
             return

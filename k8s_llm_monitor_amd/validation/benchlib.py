@@ -10,11 +10,11 @@ import time
 from typing import Any, Dict
 
 
-def _sync_all(torch, dist, world):
+def _sync_all(torch, dist, distributed):
     gpu = torch.cuda.is_available()
     if gpu:
         torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     if gpu:
         torch.cuda.synchronize()
@@ -23,19 +23,20 @@ def _sync_all(torch, dist, world):
 from ..models.linear_step import LinearLayerStep as _Load   # noqa: E402  (kept under its old name for callers)
 
 
-def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int) -> float:
+def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int, distributed=None) -> float:
     """Seconds for exactly `steps` steps: barrier + synchronize on both sides, MAX over ranks."""
+    dd = (world > 1) if distributed is None else bool(distributed)   # a one-rank group still takes the collective path
     for _ in range(warmup):
         load.step()
     load.drain()
-    _sync_all(torch, dist, world)
+    _sync_all(torch, dist, dd)
     t0 = time.perf_counter()
     for _ in range(steps):
         load.step()
     load.drain()
-    _sync_all(torch, dist, world)
+    _sync_all(torch, dist, dd)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dd:
         t = torch.tensor([dt], device=load.x.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -70,7 +71,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     gemm = None
     if dev.type != "cuda":                      # --cpu-rehearsal
         gemm = lambda x, w, out: out.copy_(x.float() @ w.float().t())
-    load = _Load(torch, dist, ops, dev, world, size, gemm=gemm)
+    dd = world > 1 or bool(getattr(a, "force_dist", False))       # a process group exists (one rank with --force-dist)
+    load = _Load(torch, dist, ops, dev, world, size, gemm=gemm, distributed=dd)
     extras: Dict[str, Any] = {}
 
     sampler = None
@@ -82,22 +84,23 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     extras["flop_per_step"] = load.flops
     wall["setup"] = round(time.perf_counter() - t_run0, 2)
     t_sec = time.perf_counter()
-    dt = timed_steps(torch, dist, load, world, a.steps, a.warmup)
+    dt = timed_steps(torch, dist, load, world, a.steps, a.warmup, distributed=dd)
     wall["warmup_and_timed_steps"] = round(time.perf_counter() - t_sec, 3)
     wall["timed_steps_only"] = round(dt, 4)
     ms = dt / a.steps * 1e3
     tflops = load.flops * world / (dt / a.steps) / 1e12
-    if world > 1:
+    if dd:
         algbw = load.allreduce_bytes / (dt / a.steps) / 1e9
         extras["allreduce_bytes_per_step"] = load.allreduce_bytes
         extras["allreduce_algbw_GBps_overlapped"] = round(algbw, 2)
         extras["allreduce_busbw_GBps_overlapped"] = round(algbw * 2 * (world - 1) / world, 2)
+        extras["distributed_backend"] = dist.get_backend()
 
     if sampler is not None:
         extras["sampler_stats"] = sampler.stats()
 
     t_sec = time.perf_counter()
-    if world > 1 and not getattr(a, "no_probe", False):
+    if dd and not getattr(a, "no_probe", False):
         # the RCCL all-reduce curve at this GPU count (outside the timed region)
         try:
             from ..parallel import dist_probe, probe
@@ -115,7 +118,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         except Exception as e:
             extras["rccl_allreduce"] = {"error": f"{type(e).__name__}: {e}"}
 
-    if world > 1 and not a.no_validation:
+    which = getattr(a, "validation_phases", "all") or "all"
+    if dd and not a.no_validation and (which == "all" or "xgmi" in which.split(",")):
         # xGMI counter fidelity: only measurable with peers (every rank takes part in the collectives)
         try:
             from . import phases as _ph
@@ -128,7 +132,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
 
     wall["rccl_probe_and_xgmi_check"] = round(time.perf_counter() - t_sec, 2)
     t_sec = time.perf_counter()
-    if not a.no_validation and rank == 0 and dev.type == "cuda":
+    if not a.no_validation and rank == 0 and dev.type == "cuda" and which == "all":
         # the other validation-load kernels, 1 s each (outside the timed region)
         try:
             from ..loadgen.burner import Burner
@@ -185,11 +189,12 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
 
     wall["other_kernels_and_llm_serving"] = round(time.perf_counter() - t_sec, 2)
     t_sec = time.perf_counter()
-    if not a.no_validation:
+    local_phases = ",".join(p for p in which.split(",") if p != "xgmi")
+    if not a.no_validation and local_phases:
         try:
             from . import phases
             t0 = time.time()
-            v = phases.run_all(torch, dist, ops, dev, rank, world, load, sampler, a, quick=True)
+            v = phases.run_all(torch, dist, ops, dev, rank, world, load, sampler, a, quick=True, which=local_phases)
             if v:
                 extras["validation"] = v.get("summary")
                 extras["validation_detail"] = {k: x for k, x in v.items() if k != "summary"}

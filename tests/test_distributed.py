@@ -84,3 +84,20 @@ def test_bench_contract_two_ranks_rehearsal():
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     d = check_bench_line(r.stdout, 2, 4, 2)
     assert d["allreduce_bytes_per_step"] == 256 * 256 * 2 and d["allreduce_busbw_GBps_overlapped"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_one_rank_rccl_takes_the_multi_gpu_path():
+    """The N > 1 launch on real RCCL, as far as one GPU allows: torchrun, backend "nccl", the communication stream with
+    the double-buffered dW all-reduce, the size sweep and the xGMI counter check, all on a one-rank communicator."""
+    r = torchrun(1, [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "6", "--warmup", "2",
+                     "--probe-max-bytes", str(1 << 24), "--validation-phases", "xgmi"], timeout=280)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [l[l.index('{"metric"'):] for l in r.stdout.splitlines() if '{"metric"' in l]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["distributed_backend"] == "nccl" and d["allreduce_bytes_per_step"] == 8192 * 8192 * 2
+    assert d["value"] > 500, d["value"]                                  # the GEMMs ran at speed next to the collective
+    assert "error" not in d["rccl_allreduce"] and d["rccl_allreduce"]["verified"], d["rccl_allreduce"]
+    assert d["xgmi_fidelity"]["world"] == 1 and d["xgmi_fidelity"]["expected_bytes_per_gpu"] == 0, d["xgmi_fidelity"]

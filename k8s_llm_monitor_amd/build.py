@@ -73,6 +73,9 @@ def targets() -> List[Target]:
         out.append(Target("klm_rccl_probe", BIN_DIR / "klm_rccl_probe", [probe], "hip-exe",
                           extra=[f"-I{ROCM}/include/rccl", f"-L{ROCM}/lib", "-lrccl",
                                  f"-Wl,-rpath,{ROCM}/lib", "-lpthread"]))
+    xgmi = PKG / "parallel" / "csrc" / "xgmi_allreduce.hip"
+    if xgmi.exists():
+        out.append(Target("klm_xgmi", LIB_DIR / "libklm_xgmi.so", [xgmi], "hip-shared"))
     smi = PKG / "collectors" / "native" / "amdsmi_sampler.cpp"
     if smi.exists():
         out.append(Target("klm_amdsmi_sampler", BIN_DIR / "klm_amdsmi_sampler", [smi], "cxx-exe",

@@ -60,7 +60,7 @@ def test_llm_loadgen_manifest_runs_the_cli_and_looks_like_a_vllm_pod():
 
 
 def test_cmake_project_lists_every_native_source():
-    """CMakeLists.txt and build.py describe the same four targets and sources."""
+    """CMakeLists.txt and build.py describe the same targets and sources."""
     from k8s_llm_monitor_amd import build
     text = open(os.path.join(ROOT, "CMakeLists.txt")).read()
     for t in build.targets():

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import signal
 import sys
 import threading
@@ -125,16 +126,78 @@ def _cmd_serve_llm_replicas(a) -> int:
     return 0
 
 
-def _cmd_serve_llm(a) -> int:
+def _cmd_serve_llm_tp_launch(a, argv: Sequence[str]) -> int:
+    """--tp N: start N rank processes of this same command (one per GPU) and wait for them."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.tp):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.tp), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), KLM_TP_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+        procs.append(subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        signal.signal(sig, lambda *_: procs[0].terminate())          # rank 0 stops the engine, the others follow it out
+    try:
+        rc = procs[0].wait()
+        for p in procs[1:]:
+            try:
+                p.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def _tp_group(a):
+    """This process is rank KLM_TP_RANK of a --tp job: join the process group, pick the device, build the TP group."""
+    import torch
+    import torch.distributed as dist
+    from .parallel.tp import TPGroup
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if a.device == "cpu":
+        dev, backend = torch.device("cpu"), "gloo"
+    elif a.tp_same_device or torch.cuda.device_count() < world:
+        if not a.tp_same_device:
+            raise SystemExit(f"--tp {world} needs {world} GPUs ({torch.cuda.device_count()} visible); "
+                             f"--tp-same-device rehearses the ranks on one")
+        dev, backend = torch.device("cuda", 0), "gloo"        # RCCL refuses two ranks on one device: mesh kernels only
+    else:
+        dev, backend = torch.device("cuda", rank), "nccl"
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    return TPGroup(dev, data=a.tp_comm if dev.type == "cuda" else "gloo"), dev
+
+
+def _cmd_serve_llm(a, argv: Sequence[str] = ()) -> int:
     if a.gpus > 1:
         return _cmd_serve_llm_replicas(a)
+    if a.tp > 1 and "KLM_TP_RANK" not in os.environ:
+        return _cmd_serve_llm_tp_launch(a, argv)
     from .serving import Engine, EngineConfig
     from .serving.loadclient import OpenLoopLoad
     from .serving.server import LlmServer
-    eng = Engine(EngineConfig(model=a.model, device=a.device, max_num_seqs=a.max_num_seqs, max_model_len=a.max_model_len,
+    tp, device = (None, a.device)
+    if a.tp > 1:
+        tp, dev = _tp_group(a)
+        device = str(dev)
+    eng = Engine(EngineConfig(model=a.model, device=device, max_num_seqs=a.max_num_seqs, max_model_len=a.max_model_len,
                               kv_blocks=a.kv_blocks, kv_fraction=a.kv_fraction, use_graphs=not a.no_graphs,
-                              decode_weights=a.decode_weights, kv_cache_dtype=a.kv_cache_dtype))
+                              decode_weights=a.decode_weights, kv_cache_dtype=a.kv_cache_dtype), tp=tp)
     eng.warmup()
+    if tp is not None and tp.rank != 0:
+        for sig in (signal.SIGINT, signal.SIGTERM):
+            signal.signal(sig, signal.SIG_IGN)          # rank 0 decides when the job ends
+        eng.follow()
+        tp.close()
+        return 0
     eng.start()
     srv = LlmServer(eng, host=a.host, port=a.port).start()
     print(f"llm engine: {json.dumps(eng.describe())}", flush=True)
@@ -155,6 +218,8 @@ def _cmd_serve_llm(a) -> int:
             load.stop()
         srv.stop()
         eng.stop()
+        if tp is not None:
+            tp.close()
         print(json.dumps(eng.metrics.truth()), flush=True)
     return 0
 
@@ -197,7 +262,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--phases", default="all", help="all or a comma list of hbm,activity,mem,overhead,latency,llm,vllm")
     p.add_argument("--device", type=int, default=0)
     p = sub.add_parser("serve-llm")
-    p.add_argument("--model", default="llama3-8b", help="llama3-8b, llama3-70b, mistral-7b, small, tiny")
+    p.add_argument("--model", default="llama3-8b", help="llama3-8b, llama3-70b, llama3-405b (needs --tp), mistral-7b, wide, small, tiny")
     p.add_argument("--device", default="cuda")
     p.add_argument("--host", default="0.0.0.0")
     p.add_argument("--port", type=int, default=8000)
@@ -207,6 +272,12 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--kv-fraction", type=float, default=0.5, help="share of the free HBM given to the KV cache")
     p.add_argument("--no-graphs", action="store_true")
     p.add_argument("--gpus", type=int, default=1, help="N > 1: one engine process per GPU behind a router on --port")
+    p.add_argument("--tp", type=int, default=1,
+                   help="tensor parallel over N GPUs (2, 4, 8): one process per GPU, all-reduce on the xGMI mesh kernels; "
+                        "for models beyond one GPU's 288 GB (llama3-405b)")
+    p.add_argument("--tp-comm", default="auto", choices=["auto", "xgmi", "rccl"],
+                   help="auto: mesh kernels for small (decode) messages, RCCL for large (prefill)")
+    p.add_argument("--tp-same-device", action="store_true", help="rehearsal: every rank on GPU 0 (mesh kernels only)")
     p.add_argument("--replica-base-port", type=int, default=0, help="first replica port (default: --port + 1)")
     p.add_argument("--ready-timeout", type=float, default=300.0)
     p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
@@ -224,7 +295,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         return _cmd_serve(a, demo=True)
     return {"sample": _cmd_sample, "build": _cmd_build, "burner": _cmd_burner, "probe": _cmd_probe,
             "validate": _cmd_validate,
-            "serve-llm": _cmd_serve_llm}[a.cmd](a)
+            "serve-llm": lambda x: _cmd_serve_llm(x, list(argv) if argv is not None else sys.argv[1:])}[a.cmd](a)
 
 
 if __name__ == "__main__":

@@ -24,12 +24,13 @@ MI355X-first choices:
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 from typing import Dict, List, Optional
 
 import torch
 
 from ..ops import llm
+from ..parallel.tp import SingleGroup
 
 HEAD_DIM = llm.HEAD_DIM
 BLOCK = llm.BLOCK
@@ -56,6 +57,16 @@ class LlamaConfig:
     def qkv_dim(self) -> int:
         return (self.n_q + 2 * self.n_kv) * HEAD_DIM
 
+    def shard(self, world: int) -> "LlamaConfig":
+        """The shapes one of `world` tensor-parallel ranks holds: heads, FFN columns and vocabulary rows are
+        split, the hidden size (the residual stream, replicated) is not."""
+        if world == 1:
+            return self
+        if self.n_q % world or self.n_kv % world or self.ffn % (8 * world) or self.vocab % world:
+            raise ValueError(f"{self.name}: {self.n_q} q heads / {self.n_kv} kv heads / ffn {self.ffn} / vocab {self.vocab} "
+                             f"do not split over {world} ranks")
+        return replace(self, n_q=self.n_q // world, n_kv=self.n_kv // world, ffn=self.ffn // world, vocab=self.vocab // world)
+
     def params(self) -> int:
         per_layer = self.hidden * self.qkv_dim + self.q_dim * self.hidden + 3 * self.hidden * self.ffn + 2 * self.hidden
         return self.layers * per_layer + 2 * self.vocab * self.hidden + self.hidden
@@ -74,11 +85,15 @@ PRESETS: Dict[str, LlamaConfig] = {
     "llama3-8b": LlamaConfig("llama3-8b", vocab=128256, hidden=4096, layers=32, n_q=32, n_kv=8, ffn=14336),
     "llama3-70b": LlamaConfig("llama3-70b", vocab=128256, hidden=8192, layers=80, n_q=64, n_kv=8, ffn=28672),
     # the same decoder block with other published shapes (GQA, head_dim 128, SwiGLU, no biases)
+    # 810 GB in bf16: the one preset that does not fit a GPU and needs tensor parallelism (serve-llm --tp 4 / 8)
+    "llama3-405b": LlamaConfig("llama3-405b", vocab=128256, hidden=16384, layers=126, n_q=128, n_kv=8, ffn=53248, max_pos=8192),
     "mistral-7b": LlamaConfig("mistral-7b", vocab=32768, hidden=4096, layers=32, n_q=32, n_kv=8, ffn=14336,
                               rope_theta=1000000.0, max_pos=32768),
     # same block structure, sized for CPU tests and smoke runs
     "tiny": LlamaConfig("tiny", vocab=512, hidden=256, layers=2, n_q=4, n_kv=2, ffn=512, max_pos=1024),
     "small": LlamaConfig("small", vocab=32000, hidden=2048, layers=4, n_q=16, n_kv=4, ffn=8192, max_pos=8192),
+    # the 405B block at 4 layers: every tensor-parallel shape of the big model (16 q heads per kv head, hidden 16384)
+    "wide": LlamaConfig("wide", vocab=32000, hidden=16384, layers=4, n_q=128, n_kv=8, ffn=53248, max_pos=8192),
 }
 
 
@@ -128,15 +143,24 @@ class PrefillMeta:
 
 
 class LlamaModel:
-    def __init__(self, cfg: LlamaConfig, device="cuda", seed: int = 0, dtype=torch.bfloat16):
+    """`tp`: a parallel.tp group. With more than one rank this instance holds ONE shard (Megatron layout: q/k/v
+    heads, gate/up rows and vocabulary rows split by rank; wo and w_down split along their input, their partial
+    products summed by an all-reduce of the residual-stream update) and `lcfg` are its local shapes."""
+
+    def __init__(self, cfg: LlamaConfig, device="cuda", seed: int = 0, dtype=torch.bfloat16, tp=None):
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.tp = tp if tp is not None else SingleGroup()
+        self.lcfg = cfg.shard(self.tp.world)
         g = torch.Generator(device=self.device)
         g.manual_seed(seed)
 
         def w(*shape, std=0.02):
             return torch.empty(shape, dtype=dtype, device=self.device).normal_(0.0, std, generator=g)
 
-        self.embed = w(cfg.vocab, cfg.hidden)
+        self.embed = w(cfg.vocab, cfg.hidden)                      # replicated: the same on every rank
+        if self.tp.world > 1:
+            g.manual_seed(seed * 7919 + 1 + self.tp.rank)          # every rank draws its own shard
+        cfg = self.lcfg
         self.lm_head = w(cfg.vocab, cfg.hidden)                    # final norm gain folded in
         # the norm gains live inside wqkv / w_gate_up / lm_head; the stand-alone norm kernel gets ones
         self.unit_gain = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
@@ -191,12 +215,12 @@ class LlamaModel:
         return n * per
 
     def new_cache(self, num_blocks: int, dtype=None) -> KVCache:
-        return KVCache(self.cfg, num_blocks, self.device, dtype or self.dtype)
+        return KVCache(self.lcfg, num_blocks, self.device, dtype or self.dtype)
 
     # ------------------------------------------------------------------ the decoder stack
     def _stack(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
         """Library-GEMM path (prefill, decode at batch > 16) -> the final residual stream's norm."""
-        cfg, g = self.cfg, self.unit_gain
+        cfg, g, tp = self.lcfg, self.unit_gain, self.tp
         h = self.embed[tokens]                                   # [T, hidden]
         residual = None
         for li, L in enumerate(self.layers):
@@ -208,17 +232,19 @@ class LlamaModel:
             qkv = torch.matmul(x, L["wqkv"].t())
             llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
             a = attend(qkv, cache.k[li], cache.v[li])
-            h = torch.matmul(a, L["wo"].t())
+            h = tp.all_reduce(torch.matmul(a, L["wo"].t()))
             x = llm.rmsnorm(h, g, cfg.eps, residual=residual)
             act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
-            h = torch.matmul(act, L["w_down"].t())
+            h = tp.all_reduce(torch.matmul(act, L["w_down"].t()))
         return llm.rmsnorm(h, g, cfg.eps, residual=residual)
 
     def _stack_skinny(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
         """Batch <= 16: every projection is one pass of the skinny kernel over its weights, with the
         norm / residual add / SwiGLU fused in; `h` is the residual stream, updated in place."""
-        cfg = self.cfg
+        cfg, tp = self.lcfg, self.tp
         f8 = self.fp8_decode
+        # the residual add rides on rank 0's partial product; the all-reduce then yields the new residual stream
+        res = (lambda h: {"epilogue": "residual", "residual": h}) if tp.rank == 0 else (lambda h: {})
 
         def lin(x, L, name, **kw):
             if f8:
@@ -230,20 +256,20 @@ class LlamaModel:
             qkv = lin(h, L, "wqkv", rms=True)
             llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
             a = attend(qkv, cache.k[li], cache.v[li])
-            lin(a, L, "wo", epilogue="residual", residual=h, out=h)
+            tp.all_reduce(lin(a, L, "wo", out=h, **res(h)))
             act = lin(h, L, "w_gate_up", rms=True, epilogue="swiglu")
-            lin(act, L, "w_down", epilogue="residual", residual=h, out=h)
+            tp.all_reduce(lin(act, L, "w_down", out=h, **res(h)))
         return h
 
     def skinny(self, batch: int) -> bool:
-        c = self.cfg
+        c = self.lcfg
         ok = batch <= llm.SKINNY_MAX_ROWS and c.hidden % 128 == 0 and c.ffn % 128 == 0 and c.vocab % 16 == 0
         return ok and (not self.fp8_decode or (c.hidden % 64 == 0 and c.ffn % 64 == 0))
 
     def decode(self, tokens, positions, slots, cache: KVCache, meta: DecodeMeta, logits: bool = False) -> torch.Tensor:
         """One token per sequence -> greedy next token ids [B] (int64), or the logits [B, vocab].
         Capture-safe."""
-        cfg = self.cfg
+        cfg = self.lcfg
 
         def attend(qkv, kc, vc):
             return llm.paged_attn_decode(qkv, kc, vc, meta.block_tables, meta.ctx_lens, self.scale, cfg.n_q,
@@ -257,20 +283,56 @@ class LlamaModel:
                 out = llm.skinny_linear(h, self.lm_head, rms=True, eps=cfg.eps)
         else:
             out = torch.matmul(self._stack(tokens, positions, slots, cache, attend), self.lm_head.t())
-        return out if logits else out.argmax(dim=-1)
+        return self._sample(out, logits)
+
+    def _sample(self, out: torch.Tensor, logits: bool) -> torch.Tensor:
+        """Local logits [B, vocab / world] -> greedy token ids [B] (or the full logits [B, vocab])."""
+        tp = self.tp
+        if tp.world == 1:
+            return out if logits else out.argmax(dim=-1)
+        B, vl = out.shape
+        if logits:
+            return tp.all_gather(out.contiguous()).permute(1, 0, 2).reshape(B, tp.world * vl)
+        # every rank offers its best (value, global id); ids fit fp32 exactly (< 2^24); rows padded to 16 bytes
+        vals, idx = out.float().max(dim=-1)
+        cand = torch.zeros((B + (B & 1), 2), dtype=torch.float32, device=out.device)
+        cand[:B, 0] = vals
+        cand[:B, 1] = (idx + tp.rank * vl).float()
+        allc = tp.all_gather(cand)                                   # [world, B', 2]: the same bits on every rank
+        best = allc[:, :B, 0].argmax(dim=0)
+        return allc[:, :B, 1].gather(0, best[None])[0].long()
 
     def prefill(self, tokens, positions, slots, cache: KVCache, meta: PrefillMeta, logits: bool = False) -> torch.Tensor:
         """Variable-length batch of prompts (or prompt chunks) -> next token id of each sequence [S]
         (or the logits [S, vocab])."""
-        cfg = self.cfg
+        cfg = self.lcfg
 
         def attend(qkv, kc, vc):
             return llm.paged_attn_prefill(qkv, kc, vc, meta.block_tables, meta.seq_info, meta.tiles, self.scale,
                                           cfg.n_q, q_tiles=meta.q_tiles)
 
         x = self._stack(tokens, positions, slots, cache, attend)
-        out = torch.matmul(x[meta.last_rows], self.lm_head.t())
-        return out if logits else out.argmax(dim=-1)
+        return self._sample(torch.matmul(x[meta.last_rows], self.lm_head.t()), logits)
+
+    def load_shard_from(self, full: "LlamaModel") -> "LlamaModel":
+        """Cut this rank's shard out of an unsharded instance (tests: the sharded model must compute what the
+        whole one computes)."""
+        c, l, r = full.cfg, self.lcfg, self.tp.rank
+        if full.tp.world != 1 or c != self.cfg:
+            raise ValueError("load_shard_from wants the unsharded model of the same config")
+        D = HEAD_DIM
+        q0, k0, v0 = 0, c.n_q * D, (c.n_q + c.n_kv) * D
+        rows = torch.cat([torch.arange(q0 + r * l.n_q * D, q0 + (r + 1) * l.n_q * D),
+                          torch.arange(k0 + r * l.n_kv * D, k0 + (r + 1) * l.n_kv * D),
+                          torch.arange(v0 + r * l.n_kv * D, v0 + (r + 1) * l.n_kv * D)]).to(full.device)
+        self.embed.copy_(full.embed)
+        self.lm_head.copy_(full.lm_head[r * l.vocab:(r + 1) * l.vocab])
+        for mine, theirs in zip(self.layers, full.layers):
+            mine["wqkv"].copy_(theirs["wqkv"][rows])
+            mine["wo"].copy_(theirs["wo"][:, r * l.q_dim:(r + 1) * l.q_dim])
+            mine["w_gate_up"].copy_(theirs["w_gate_up"][2 * r * l.ffn:2 * (r + 1) * l.ffn])      # interleaved by 8: contiguous
+            mine["w_down"].copy_(theirs["w_down"][:, r * l.ffn:(r + 1) * l.ffn])
+        return self
 
     def load_from(self, other: "LlamaModel") -> "LlamaModel":
         """Copy another instance's weights (any device / dtype) into this one."""

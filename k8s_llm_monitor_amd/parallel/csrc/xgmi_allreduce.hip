@@ -24,8 +24,9 @@
 //     (it needs every peer's flag to pass a barrier), so writing slot (e+1)&1 never touches what a
 //     peer still reads for call e, and passing the first barrier of call e+1 proves call e is over
 //     everywhere before call e+2 reuses its slot. No trailing barrier is needed.
-//   * every spin is bounded (about 2 s of the 100 MHz wall clock): a missing peer sets a status
-//     word and the kernel ends with a wrong result instead of hanging the GPU.
+//   * every spin is bounded (a limit in seconds of the 100 MHz wall clock): a missing peer sets a status
+//     word and the kernel ends with a wrong result instead of hanging the GPU. The epochs keep advancing, so
+//     the protocol is in step again as soon as the late rank arrives.
 // Sums run in rank order in fp32 on every rank, so all ranks hold bit-identical results.
 //
 // No reference counterpart (the reference has no GPU code).
@@ -40,7 +41,7 @@ int klm_xgmi_close(void* ptr);
 int klm_xgmi_free(void* ptr);
 int klm_xgmi_collective(void* const* data, const void* sig_table, void* my_sig, int rank, int world, const void* x,
                         void* out, size_t nbytes, int mode, int blocks, void* counters, void* status,
-                        size_t slot_bytes, void* stream);
+                        size_t slot_bytes, double spin_limit_s, void* stream);
 int klm_xgmi_limits(int* max_ranks, int* max_blocks, int* sig_bytes, int* counter_bytes);
 }
 
@@ -51,7 +52,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // 16 bytes in reg
 constexpr int MAXR = 8;            // ranks
 constexpr int MAXB = 128;          // blocks per call
 constexpr int NT = 512;            // threads per block
-constexpr long long SPIN_LIMIT = 200000000LL;   // wall_clock64 ticks (100 MHz): 2 s
 
 enum Mode { SUM_ONE_SHOT = 0, SUM_TWO_SHOT = 1, GATHER = 2 };
 
@@ -89,7 +89,7 @@ struct Acc8 {
 // Barrier between block b of every rank. All of this block's earlier stores are made visible to the
 // system before the flags go out; all of its later loads see what the peers stored before theirs.
 template <int N>
-__device__ __forceinline__ void block_barrier(const Peers& p, int rank, int stage, uint32_t epoch, int* status) {
+__device__ __forceinline__ void block_barrier(const Peers& p, int rank, int stage, uint32_t epoch, int* status, long long spin_limit) {
   __threadfence_system();
   __syncthreads();
   const int t = threadIdx.x;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void block_barrier(const Peers& p, int rank, int stag
     const uint32_t* mine = p.my_sig + slot + t;
     const long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      if (wall_clock64() - t0 > SPIN_LIMIT) {
+      if (wall_clock64() - t0 > spin_limit) {
         __hip_atomic_fetch_or(status, 1 << stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -113,13 +113,13 @@ __device__ __forceinline__ void block_barrier(const Peers& p, int rank, int stag
 // n16: 16-byte units of the vector. Block b owns the units i with (i / NT) % gridDim.x == b.
 template <int N, int MODE>
 __global__ __launch_bounds__(NT) void xgmi_one_shot(Peers p, int rank, const u32x4* x, u32x4* out,
-                                                    size_t n16, uint32_t* counters, int* status, size_t slot_bytes) {
+                                                    size_t n16, uint32_t* counters, int* status, size_t slot_bytes, long long spin_limit) {
   const uint32_t epoch = counters[blockIdx.x] + 1;
   const size_t off = (epoch & 1) * slot_bytes;
   const size_t first = (size_t)blockIdx.x * NT + threadIdx.x, step = (size_t)gridDim.x * NT;
   u32x4* mine = reinterpret_cast<u32x4*>(p.my_data + off);
   for (size_t i = first; i < n16; i += step) mine[i] = x[i];
-  block_barrier<N>(p, rank, 0, epoch, status);
+  block_barrier<N>(p, rank, 0, epoch, status, spin_limit);
   for (size_t i = first; i < n16; i += step) {
     u32x4 v[N];
 #pragma unroll
@@ -142,14 +142,14 @@ __global__ __launch_bounds__(NT) void xgmi_one_shot(Peers p, int rank, const u32
 // Slot layout: [input: slot_bytes/2][reduced part of this rank: slot_bytes/2]. part16 = n16 / N.
 template <int N>
 __global__ __launch_bounds__(NT) void xgmi_two_shot(Peers p, int rank, const u32x4* x, u32x4* out,
-                                                    size_t part16, uint32_t* counters, int* status, size_t slot_bytes) {
+                                                    size_t part16, uint32_t* counters, int* status, size_t slot_bytes, long long spin_limit) {
   const uint32_t epoch = counters[blockIdx.x] + 1;
   const size_t off = (epoch & 1) * slot_bytes, res = off + slot_bytes / 2;
   const size_t first = (size_t)blockIdx.x * NT + threadIdx.x, step = (size_t)gridDim.x * NT;
   u32x4* mine = reinterpret_cast<u32x4*>(p.my_data + off);
   for (int q = 0; q < N; ++q)
     for (size_t j = first; j < part16; j += step) mine[q * part16 + j] = x[q * part16 + j];
-  block_barrier<N>(p, rank, 0, epoch, status);
+  block_barrier<N>(p, rank, 0, epoch, status, spin_limit);
   u32x4* my_res = reinterpret_cast<u32x4*>(p.my_data + res);
   for (size_t j = first; j < part16; j += step) {
     u32x4 v[N];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT) void xgmi_two_shot(Peers p, int rank, const u32
     my_res[j] = s;
     out[rank * part16 + j] = s;
   }
-  block_barrier<N>(p, rank, 1, epoch, status);
+  block_barrier<N>(p, rank, 1, epoch, status, spin_limit);
   for (size_t j = first; j < part16; j += step) {
     u32x4 v[N];
 #pragma unroll
@@ -179,18 +179,18 @@ __global__ __launch_bounds__(NT) void xgmi_two_shot(Peers p, int rank, const u32
 
 template <int N>
 int launch(const Peers& p, int rank, const void* x, void* out, size_t nbytes, int mode, int blocks, void* counters, void* status,
-           size_t slot_bytes, hipStream_t s) {
+           size_t slot_bytes, long long spin, hipStream_t s) {
   const size_t n16 = nbytes / 16;
   auto* xi = static_cast<const u32x4*>(x);
   auto* oi = static_cast<u32x4*>(out);
   auto* c = static_cast<uint32_t*>(counters);
   auto* st = static_cast<int*>(status);
   if (mode == SUM_ONE_SHOT)
-    hipLaunchKernelGGL((xgmi_one_shot<N, SUM_ONE_SHOT>), dim3(blocks), dim3(NT), 0, s, p, rank, xi, oi, n16, c, st, slot_bytes);
+    hipLaunchKernelGGL((xgmi_one_shot<N, SUM_ONE_SHOT>), dim3(blocks), dim3(NT), 0, s, p, rank, xi, oi, n16, c, st, slot_bytes, spin);
   else if (mode == GATHER)
-    hipLaunchKernelGGL((xgmi_one_shot<N, GATHER>), dim3(blocks), dim3(NT), 0, s, p, rank, xi, oi, n16, c, st, slot_bytes);
+    hipLaunchKernelGGL((xgmi_one_shot<N, GATHER>), dim3(blocks), dim3(NT), 0, s, p, rank, xi, oi, n16, c, st, slot_bytes, spin);
   else
-    hipLaunchKernelGGL((xgmi_two_shot<N>), dim3(blocks), dim3(NT), 0, s, p, rank, xi, oi, n16 / N, c, st, slot_bytes);
+    hipLaunchKernelGGL((xgmi_two_shot<N>), dim3(blocks), dim3(NT), 0, s, p, rank, xi, oi, n16 / N, c, st, slot_bytes, spin);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -243,7 +243,8 @@ int klm_xgmi_free(void* ptr) { return hipFree(ptr) == hipSuccess ? 0 : -2; }
 // mode 0: sum, one shot (nbytes <= slot_bytes). 1: sum, two shot (nbytes <= slot_bytes / 2, nbytes % (16 world) == 0).
 // 2: all-gather, out holds world x nbytes (nbytes <= slot_bytes). x and out are 16-byte aligned; x may equal out for sums.
 int klm_xgmi_collective(void* const* data, const void* sig_table, void* my_sig, int rank, int world, const void* x, void* out,
-                        size_t nbytes, int mode, int blocks, void* counters, void* status, size_t slot_bytes, void* stream) {
+                        size_t nbytes, int mode, int blocks, void* counters, void* status, size_t slot_bytes, double spin_limit_s,
+                        void* stream) {
   if (world < 1 || world > MAXR || rank < 0 || rank >= world || blocks < 1 || blocks > MAXB) return -1;
   if (!x || !out || !counters || !status || !sig_table || !my_sig || nbytes == 0 || nbytes % 16) return -1;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return -1;
@@ -258,11 +259,12 @@ int klm_xgmi_collective(void* const* data, const void* sig_table, void* my_sig, 
   p.my_data = p.data[rank];
   p.my_sig = static_cast<uint32_t*>(my_sig);
   auto s = static_cast<hipStream_t>(stream);
+  const long long spin = (long long)((spin_limit_s > 0 ? spin_limit_s : 2.0) * 1e8);    // wall_clock64 runs at 100 MHz
   switch (world) {
-    case 1: return launch<1>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, s);
-    case 2: return launch<2>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, s);
-    case 4: return launch<4>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, s);
-    case 8: return launch<8>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, s);
+    case 1: return launch<1>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, spin, s);
+    case 2: return launch<2>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, spin, s);
+    case 4: return launch<4>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, spin, s);
+    case 8: return launch<8>(p, rank, x, out, nbytes, mode, blocks, counters, status, slot_bytes, spin, s);
     default: return -1;
   }
 }

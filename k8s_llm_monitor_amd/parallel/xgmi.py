@@ -41,7 +41,7 @@ def load_lib():
         L.klm_xgmi_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
         L.klm_xgmi_close.argtypes = [vp]
         L.klm_xgmi_free.argtypes = [vp]
-        L.klm_xgmi_collective.argtypes = [ctypes.POINTER(vp), vp, vp, ci, ci, vp, vp, sz, ci, ci, vp, vp, sz, vp]
+        L.klm_xgmi_collective.argtypes = [ctypes.POINTER(vp), vp, vp, ci, ci, vp, vp, sz, ci, ci, vp, vp, sz, ctypes.c_double, vp]
         L.klm_xgmi_limits.argtypes = [ctypes.POINTER(ci)] * 4
         for f in (L.klm_xgmi_alloc, L.klm_xgmi_open, L.klm_xgmi_close, L.klm_xgmi_free, L.klm_xgmi_collective, L.klm_xgmi_limits):
             f.restype = ci
@@ -79,7 +79,7 @@ class XgmiComm:
     SIG_PAD = 1 << 16
 
     def __init__(self, rank: int, world: int, device, exchange: Callable[[bytes], List[bytes]],
-                 slot_bytes: int = 16 << 20, blocks: int = 32, one_shot_max: int = 256 << 10):
+                 slot_bytes: int = 16 << 20, blocks: int = 32, one_shot_max: int = 256 << 10, spin_limit_s: float = 20.0):
         import torch
         lim = limits()
         if world not in (1, 2, 4, 8) or world > lim["max_ranks"] or not 0 <= rank < world:
@@ -87,6 +87,7 @@ class XgmiComm:
         if not 1 <= blocks <= lim["max_blocks"] or slot_bytes % (32 * world) or lim["sig_bytes"] > self.SIG_PAD:
             raise ValueError("blocks or slot_bytes out of range")
         self.torch, self.L = torch, load_lib()
+        self.spin_limit_s = float(spin_limit_s)        # how long a kernel waits for a peer before it gives up (status != 0)
         self.rank, self.world, self.device = rank, world, torch.device(device)
         self.slot_bytes, self.blocks, self.one_shot_max = int(slot_bytes), int(blocks), int(one_shot_max)
         torch.cuda.set_device(self.device)
@@ -132,7 +133,7 @@ class XgmiComm:
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         rc = self.L.klm_xgmi_collective(self._data, self._sig_table.data_ptr(), self.base, self.rank, self.world, x_ptr, out_ptr,
                                         nbytes, mode, self.blocks, self._counters.data_ptr(), self._status.data_ptr(),
-                                        self.slot_bytes, s)
+                                        self.slot_bytes, self.spin_limit_s, s)
         if rc != 0:
             raise XgmiError(f"klm_xgmi_collective rejected the call ({rc}): {nbytes} bytes, mode {mode}")
 

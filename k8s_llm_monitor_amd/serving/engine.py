@@ -112,7 +112,9 @@ def _buckets(limit: int) -> List[int]:
 
 class Engine:
     def __init__(self, cfg: Optional[EngineConfig] = None, model: Optional[LlamaModel] = None,
-                 clock: Callable[[], float] = time.monotonic):
+                 clock: Callable[[], float] = time.monotonic, tp=None):
+        """`tp`: a parallel.tp.TPGroup. Every rank then runs this same engine in lock-step (see `_tp_sync`):
+        requests enter at rank 0, every rank schedules them identically and holds its shard of model and cache."""
         self.cfg = cfg or EngineConfig()
         self.clock = clock
         mcfg: LlamaConfig = model.cfg if model is not None else PRESETS[self.cfg.model]
@@ -121,7 +123,10 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.on_gpu = self.device.type == "cuda"
         self.max_len = min(self.cfg.max_model_len, mcfg.max_pos)
-        self.model = model or LlamaModel(mcfg, self.device, seed=self.cfg.seed)
+        self.model = model or LlamaModel(mcfg, self.device, seed=self.cfg.seed, tp=tp)
+        self.tp = self.model.tp
+        self.lcfg: LlamaConfig = self.model.lcfg          # this rank's shapes (== mcfg without tensor parallelism)
+        self._inbox: List[Request] = []                   # tensor parallel: submitted at rank 0, not yet seen by the others
         if self.cfg.decode_weights == "fp8" and not self.model.fp8_decode:
             self.model.enable_fp8_decode()
         elif self.cfg.decode_weights not in ("bf16", "fp8"):
@@ -171,11 +176,11 @@ class Engine:
         self._h_tokens, self._h_i32, self._h_bt = (self._h_tokens_t.numpy(), self._h_i32_t.numpy(),
                                                    self._h_bt_t.numpy())
         self._graphs: Dict[int, object] = {}
-        self._workspace = llm.DecodeWorkspace(B, mcfg.n_q, 64, dev) if self.on_gpu else None
+        self._workspace = llm.DecodeWorkspace(B, self.lcfg.n_q, 64, dev) if self.on_gpu else None
 
     # ------------------------------------------------------------------ sizing
     def _auto_blocks(self) -> int:
-        per_block = KVCache.bytes_per_block(self.mcfg, self.kv_dtype or torch.bfloat16)
+        per_block = KVCache.bytes_per_block(self.lcfg, self.kv_dtype or torch.bfloat16)
         if self.on_gpu:
             free, _total = torch.cuda.mem_get_info(self.device)
             n = int(free * self.cfg.kv_fraction) // per_block
@@ -202,14 +207,47 @@ class Engine:
                 return r
             r.max_tokens = min(r.max_tokens, self.max_len - len(r.prompt),
                                self.alloc.total * BLOCK - len(r.prompt))
-            self.waiting.append(r)
-            self.metrics.set_queue(len(self.running), len(self.waiting), self.alloc.usage)
+            if self.tp.world > 1:
+                if self.tp.rank != 0:
+                    raise RuntimeError("tensor parallel: requests are submitted at rank 0")
+                self._inbox.append(r)              # enters `waiting` on every rank at the next _tp_sync
+            else:
+                self.waiting.append(r)
+            self.metrics.set_queue(len(self.running), len(self.waiting) + len(self._inbox), self.alloc.usage)
         self._wake.set()
         return r
 
     def idle(self) -> bool:
         with self._lock:
             return not self.waiting and not self.running and not self.prefilling
+
+    # ------------------------------------------------------------------ tensor parallel lock-step
+    def _tp_sync(self, stop: bool = False) -> bool:
+        """Collective over the control group, once before every step: rank 0's new requests (and its wish to
+        stop) reach every rank. Scheduling is a deterministic function of the queue contents and the sampled
+        tokens are the same bits everywhere, so the ranks stay in step without exchanging scheduler output.
+        Returns True when the engine is to stop."""
+        if self.tp.world == 1:
+            return stop
+        if self.tp.rank == 0:
+            with self._lock:
+                new, self._inbox = self._inbox, []
+            msg = self.tp.broadcast_object((bool(stop), [(r.rid, r.prompt, r.max_tokens) for r in new]))
+            with self._lock:
+                self.waiting.extend(new)
+            return msg[0]
+        stop, new = self.tp.broadcast_object(None)
+        now = self.clock()
+        with self._lock:
+            for rid, prompt, max_tokens in new:
+                self.waiting.append(Request(rid, list(prompt), int(max_tokens), now))
+        return bool(stop)
+
+    def step_all(self) -> int:
+        """`step()` for callers that drive a tensor-parallel engine by hand: every rank calls it the same
+        number of times."""
+        self._tp_sync()
+        return self.step()
 
     # ------------------------------------------------------------------ one iteration
     def step(self) -> int:
@@ -273,9 +311,9 @@ class Engine:
             bt[i, :len(r.blocks)] = r.blocks
             last_rows.append(len(toks) - 1)
         dev = self.device
-        g = self.mcfg.n_q // self.mcfg.n_kv
+        g = self.lcfg.n_q // self.lcfg.n_kv
         q_lens = [n for (_, n, _) in info]
-        qt = llm.pick_q_tiles(q_lens, g, self.mcfg.n_kv)
+        qt = llm.pick_q_tiles(q_lens, g, self.lcfg.n_kv)
         meta = PrefillMeta(torch.from_numpy(bt).to(dev), torch.tensor(info, dtype=torch.int32, device=dev),
                            llm.prefill_tiles(q_lens, g, qt, ctx_lens=[c for (_, _, c) in info]).to(dev),
                            torch.tensor(last_rows, dtype=torch.int64, device=dev), qt)
@@ -382,7 +420,7 @@ class Engine:
 
     def _decode_call(self, b: int) -> None:
         meta = DecodeMeta(self._d_bt[:b], self._d_ctx[:b],
-                          num_splits=llm.pick_splits(b, self.mcfg.n_kv, self.max_len) if self.on_gpu else 1,
+                          num_splits=llm.pick_splits(b, self.lcfg.n_kv, self.max_len) if self.on_gpu else 1,
                           workspace=self._workspace)
         out = self.model.decode(self._d_tokens[:b], self._d_pos[:b], self._d_slots[:b], self.cache, meta)
         self._d_next[:b].copy_(out)
@@ -427,7 +465,16 @@ class Engine:
     def _loop(self) -> None:
         if self.on_gpu:
             torch.cuda.set_device(self.device)
-        while not self._stop.is_set():
+        while True:
+            if self.tp.world > 1:
+                if self.tp.rank == 0 and not self._stop.is_set() and self.idle() and not self._inbox:
+                    self._wake.wait(0.05)          # nothing to do: the other ranks wait in the control broadcast
+                    self._wake.clear()
+                    continue
+                if self._tp_sync(self._stop.is_set()):
+                    break
+            elif self._stop.is_set():
+                break
             try:
                 n = self.step()
             except Exception as e:      # a failed launch (out of memory, bad shape) must not strand the callers
@@ -435,14 +482,18 @@ class Engine:
                 self.errors += 1
                 self._fail_all(self.last_error)
                 n = 0
-            if n == 0:
+            if n == 0 and self.tp.world == 1:
                 self._wake.wait(0.05)
                 self._wake.clear()
+
+    def follow(self) -> None:
+        """Ranks other than 0 of a tensor-parallel engine: run the loop in this thread until rank 0 stops."""
+        self._loop()
 
     def _fail_all(self, why: str) -> None:
         now = self.clock()
         with self._lock:
-            for r in list(self.waiting) + list(self.prefilling) + list(self.running):
+            for r in list(self._inbox) + list(self.waiting) + list(self.prefilling) + list(self.running):
                 if r.blocks:
                     self.alloc.release(r.blocks)
                 r.blocks = []
@@ -450,6 +501,7 @@ class Engine:
                 r.t_done = now
                 r.done.set()
             self.waiting.clear()
+            self._inbox = []
             self.running = []
             self.prefilling = []
             self.metrics.set_queue(0, 0, self.alloc.usage)
@@ -486,4 +538,4 @@ class Engine:
                 "decode_weights": "fp8 (W8A16, batch <= 16)" if self.model.fp8_decode else "bf16",
                 "kv_cache_dtype": self.cfg.kv_cache_dtype,
                 "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts),
-                "errors": self.errors, "last_error": self.last_error}
+                "tensor_parallel": self.tp.describe(), "errors": self.errors, "last_error": self.last_error}

@@ -53,3 +53,60 @@ def test_xgmi_collectives_between_processes(world):
         assert r["modes"]["4096"] == [0] and r["modes"]["1048576"] == [1], r["modes"]      # one shot / two shot
         assert r["repeat_mismatches"] == 0 and r["gather_ok"] and r["graph_ok"] and r["status"] == 0, r
     print("xgmi collectives:", {k: res[0][k] for k in ("describe", "us_32KiB", "us_2MiB")})
+
+
+@pytest.mark.timeout(400)
+def test_tensor_parallel_model_and_engine_two_ranks_on_one_gpu():
+    """Two processes, each holding half of the `small` model, on the one GPU: every projection all-reduce and the
+    sharded argmax run on the mesh kernels (also inside the decode hipGraphs), the engine runs in lock-step."""
+    res = run_ranks("tp_worker.py", 2, ["--gpu", "--model", "small"], timeout=380)
+    for r in res:
+        assert r["tp"]["backend"] == "xgmi" and r["tp"]["xgmi"]["world"] == 2
+        assert r["local_shapes"] == [8, 2, 4096, 16000]
+        assert r["model_max_abs_err"] < 0.04 * max(1.0, r["model_logit_scale"]), r          # bf16 partial sums
+        assert r["sharded_argmax_agrees"] and r["loop_ok"], r
+        assert r["engine_counts"] == res[0]["engine_counts"] and r["graphs"] == res[0]["graphs"] and r["graphs"]
+    r0 = [r for r in res if r["rank"] == 0][0]
+    assert r0["engine_done"] and r0["engine_tokens"] == 24 and r0["graph_equals_eager"], r0
+    print("tp2 on one GPU:", {k: r0[k] for k in ("model_max_abs_err", "model_logit_scale", "engine_tokens_match",
+                                                 "engine_first_tokens_match", "engine_counts", "graphs")})
+
+
+@pytest.mark.timeout(400)
+def test_serve_llm_tp_cli_two_ranks_share_the_gpu():
+    """`serve-llm --tp 2 --tp-same-device`: launcher, two rank processes, HTTP at rank 0, hipGraph decode with the mesh
+    all-reduce inside, clean exit of both ranks on SIGTERM."""
+    import signal
+    import time
+    import urllib.request
+    port = free_port()
+    p = subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--model", "small", "--tp", "2", "--tp-same-device",
+                          "--host", "127.0.0.1", "--port", str(port), "--max-num-seqs", "16", "--max-model-len", "1024",
+                          "--kv-blocks", "512"], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    try:
+        url = f"http://127.0.0.1:{port}"
+        t_end = time.time() + 240
+        while True:
+            try:
+                urllib.request.urlopen(url + "/health", timeout=1).read()
+                break
+            except OSError:
+                assert p.poll() is None and time.time() < t_end, "server did not come up"
+                time.sleep(0.5)
+        outs = []
+        for i in range(3):
+            req = urllib.request.Request(url + "/v1/completions", headers={"Content-Type": "application/json"},
+                                         data=json.dumps({"prompt_len": 200 + 50 * i, "max_tokens": 24, "seed": i}).encode())
+            outs.append(json.loads(urllib.request.urlopen(req, timeout=120).read()))
+        assert all(len(o["choices"][0]["token_ids"]) == 24 for o in outs)
+        st = json.loads(urllib.request.urlopen(url + "/stats", timeout=5).read())["engine"]
+        assert st["tensor_parallel"]["backend"] == "xgmi" and st["tensor_parallel"]["world"] == 2 and st["graphs"], st
+        assert st["errors"] == 0 and st["step_counts"]["decode"] >= 69
+        text = urllib.request.urlopen(url + "/metrics", timeout=5).read().decode()
+        assert "vllm:generation_tokens_total" in text
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=120) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()

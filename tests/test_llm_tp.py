@@ -1,0 +1,96 @@
+"""Tensor parallelism of the serving model and engine on CPU: two gloo ranks, fp32, against the unsharded model.
+The GPU version (xGMI mesh kernels, hipGraph decode) is tests/test_gpu_tp.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(world, args=(), timeout=240):
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "tp_worker.py"), *args], cwd=ROOT,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                       PYTHONPATH=ROOT, OMP_NUM_THREADS="2"),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    res = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=timeout)
+            assert p.returncode == 0, so[-1500:] + se[-3000:]
+            res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return res
+
+
+def test_config_shards():
+    from k8s_llm_monitor_amd.models.llama import PRESETS
+    big = PRESETS["llama3-405b"]
+    assert 400e9 < big.params() < 410e9
+    l = big.shard(8)
+    assert (l.n_q, l.n_kv, l.ffn, l.vocab, l.hidden) == (16, 1, 6656, 16032, 16384) and l.ffn % 128 == 0 and l.vocab % 16 == 0
+    assert big.shard(1) is big
+    with pytest.raises(ValueError):
+        PRESETS["tiny"].shard(4)                     # 2 kv heads do not split over 4 ranks
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_model_and_engine_match_the_unsharded_model():
+    res = run_ranks(2)
+    for r in res:
+        assert r["tp"]["world"] == 2 and r["tp"]["backend"] == "gloo"
+        assert r["local_shapes"] == [2, 1, 256, 256]
+        assert r["model_max_abs_err"] < 2e-4 * max(1.0, r["model_logit_scale"]), r          # fp32: only the sum order differs
+        assert r["sharded_argmax_agrees"] and r["loop_ok"], r
+        assert r["engine_steps"] == res[0]["engine_steps"] and r["engine_counts"] == res[0]["engine_counts"]   # lock-step
+    r0 = [r for r in res if r["rank"] == 0][0]
+    assert r0["engine_tokens_match"] and r0["engine_done"] and r0["engine_tokens"] == 24, r0
+    assert r0["engine_counts"]["prefill"] >= 3            # 242 prompt tokens at 96 per launch: chunked
+
+
+@pytest.mark.timeout(300)
+def test_serve_llm_tp_cli_two_cpu_ranks():
+    """`serve-llm --tp 2` end to end on CPU: the launcher starts both ranks, rank 0 answers HTTP, a completion runs
+    through both shards, SIGTERM at the launcher ends rank 0 and, through the control channel, rank 1."""
+    import signal
+    import time
+    import urllib.request
+    port = free_port()
+    p = subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--model", "tiny", "--device", "cpu", "--tp", "2",
+                          "--host", "127.0.0.1", "--port", str(port), "--max-num-seqs", "4", "--max-model-len", "128", "--kv-blocks", "32"],
+                         cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    try:
+        url = f"http://127.0.0.1:{port}"
+        t_end = time.time() + 120
+        while True:
+            try:
+                urllib.request.urlopen(url + "/health", timeout=1).read()
+                break
+            except OSError:
+                assert p.poll() is None and time.time() < t_end, "server did not come up"
+                time.sleep(0.3)
+        req = urllib.request.Request(url + "/v1/completions", data=json.dumps({"prompt_len": 30, "max_tokens": 5, "seed": 1}).encode(),
+                                     headers={"Content-Type": "application/json"})
+        out = json.loads(urllib.request.urlopen(req, timeout=60).read())
+        assert len(out["choices"][0]["token_ids"]) == 5 and out["usage"]["prompt_tokens"] == 30
+        st = json.loads(urllib.request.urlopen(url + "/stats", timeout=5).read())
+        assert st["engine"]["tensor_parallel"] == {"world": 2, "rank": 0, "backend": "gloo"}
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=90) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()

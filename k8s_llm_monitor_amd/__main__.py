@@ -176,11 +176,11 @@ def _tp_group(a):
     return TPGroup(dev, data=a.tp_comm if dev.type == "cuda" else "gloo"), dev
 
 
-def _cmd_serve_llm(a, argv: Sequence[str] = ()) -> int:
+def _cmd_serve_llm(a) -> int:
     if a.gpus > 1:
         return _cmd_serve_llm_replicas(a)
     if a.tp > 1 and "KLM_TP_RANK" not in os.environ:
-        return _cmd_serve_llm_tp_launch(a, argv)
+        return _cmd_serve_llm_tp_launch(a, a.argv)
     from .serving import Engine, EngineConfig
     from .serving.loadclient import OpenLoopLoad
     from .serving.server import LlmServer
@@ -289,13 +289,14 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--output-len", type=int, default=128)
     p.add_argument("--duration", type=float, default=0.0)
     a = ap.parse_args(argv)
+    a.argv = list(argv) if argv is not None else sys.argv[1:]      # --tp re-runs this command once per rank
     if a.cmd == "serve":
         return _cmd_serve(a)
     if a.cmd == "demo":
         return _cmd_serve(a, demo=True)
     return {"sample": _cmd_sample, "build": _cmd_build, "burner": _cmd_burner, "probe": _cmd_probe,
             "validate": _cmd_validate,
-            "serve-llm": lambda x: _cmd_serve_llm(x, list(argv) if argv is not None else sys.argv[1:])}[a.cmd](a)
+            "serve-llm": _cmd_serve_llm}[a.cmd](a)
 
 
 if __name__ == "__main__":

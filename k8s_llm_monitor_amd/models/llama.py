@@ -176,6 +176,7 @@ class LlamaModel:
         self.cos_sin = llm.rope_table(cfg.max_pos, cfg.rope_theta, self.device)
         self.scale = 1.0 / math.sqrt(HEAD_DIM)
         self.fp8_decode = False
+        self.skinny_limit: Optional[int] = None                    # overrides skinny_rows() (benchmarks)
         self.lm_head8: Optional[torch.Tensor] = None
         self.lm_head_s: Optional[torch.Tensor] = None
 
@@ -261,9 +262,18 @@ class LlamaModel:
             tp.all_reduce(lin(act, L, "w_down", out=h, **res(h)))
         return h
 
+    def skinny_rows(self) -> int:
+        """Largest batch that decodes on the weight-streaming kernel. Measured per layer on MI355X
+        (scripts/gpu_skinny_tp_bench.py): with 4096-wide rows it beats hipBLASLt + separate norm / SwiGLU kernels up
+        to its 16 rows; with rows of 8192 and more (70B, 405B shards) the library GEMMs win from 8 rows on (12 %
+        at 8, 25 % at 16). fp8 weight copies halve the bytes and keep the kernel ahead throughout."""
+        if self.skinny_limit is not None:
+            return self.skinny_limit
+        return llm.SKINNY_MAX_ROWS if (self.cfg.hidden <= 4096 or self.fp8_decode) else 4
+
     def skinny(self, batch: int) -> bool:
         c = self.lcfg
-        ok = batch <= llm.SKINNY_MAX_ROWS and c.hidden % 128 == 0 and c.ffn % 128 == 0 and c.vocab % 16 == 0
+        ok = batch <= self.skinny_rows() and c.hidden % 128 == 0 and c.ffn % 128 == 0 and c.vocab % 16 == 0
         return ok and (not self.fp8_decode or (c.hidden % 64 == 0 and c.ffn % 64 == 0))
 
     def decode(self, tokens, positions, slots, cache: KVCache, meta: DecodeMeta, logits: bool = False) -> torch.Tensor:

@@ -107,14 +107,18 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
 // tiled != 0: W is stored in the kernel's streaming order instead of row-major: [N/16][K/32] tiles
 // of 1 KiB, each holding, for lane l = 0..63, the 8 elements W[16 nt + l%16][32 ks + 8 (l/16) .. +8]
 // (fp8: [N/16][K/64] tiles, 16 elements per lane); see ops.llm.tile_weights.
+// w_stride: elements between consecutive rows of a row-major W (0 = K; a multiple of 8, of 16 for fp8). Rows a
+// power of two apart (K = 16384: 32 KiB) make the 16 rows of a tile collide in the memory system: 64 elements of
+// padding per row are worth 12 % there (docs/KERNELS.md).
 int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, const void* residual, int M, int N,
-                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, int tiled, void* stream);
+                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, int tiled, int w_stride,
+                      void* stream);
 
 // The same with OCP e4m3 weights W8[N][K] (bytes) and one fp32 scale per output row (W8A16): the
 // weights are converted to bf16 in registers, x stays bf16. wscale has N entries, 16-byte aligned.
 int klm_skinny_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, void* out,
                          const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
-                         int row_tiles, int tiled, void* stream);
+                         int row_tiles, int tiled, int w_stride, void* stream);
 
 const char* klm_version(void);
 

@@ -8,11 +8,12 @@ namespace {
 
 // ------------------------------------------------------------------------------------
 // RMSNorm (optionally fused with the residual add): one 256-thread block per token, the
-// row stays in registers between the sum of squares and the scaled write (H <= 8192).
+// row stays in registers between the sum of squares and the scaled write: CH vectors of 8 per
+// thread, CH = 4 for H <= 8192, 8 up to 16384 (the 405B hidden size).
 //   RES: residual <- bf16(x + residual); out <- rmsnorm(residual) * w
 //  !RES:                                 out <- rmsnorm(x) * w
 // ------------------------------------------------------------------------------------
-template <bool RES>
+template <bool RES, int CH>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict__ x,
                                                       uint16_t* __restrict__ res,
                                                       const uint16_t* __restrict__ w,
@@ -20,10 +21,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict
   __shared__ float red[4];
   const size_t base = (size_t)blockIdx.x * H;
   const int tid = threadIdx.x;
-  float v[4][8];
+  float v[CH][8];
   float ss = 0.f;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < CH; ++c) {
     const int e = (c * 256 + tid) * 8;
     if (e < H) {
       const uint4 a = *reinterpret_cast<const uint4*>(x + base + e);
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict
   ss = red[0] + red[1] + red[2] + red[3];
   const float inv = rsqrtf(ss / (float)H + eps);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < CH; ++c) {
     const int e = (c * 256 + tid) * 8;
     if (e < H) {
       const uint4 wa = *reinterpret_cast<const uint4*>(w + e);
@@ -168,16 +169,18 @@ extern "C" {
 
 int klm_rmsnorm(const void* x, void* residual, const void* weight, void* out, int T, int H, float eps,
                 void* stream) {
-  if (T <= 0 || H <= 0 || H % 8 != 0 || H > 8192) return KLM_ERR_SHAPE;
+  if (T <= 0 || H <= 0 || H % 8 != 0 || H > 16384) return KLM_ERR_SHAPE;
   if (!x || !weight || !out) return KLM_ERR_ARG;
   if (!aligned16(x) || !aligned16(weight) || !aligned16(out) || !aligned16(residual)) return KLM_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (residual)
-    hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(T), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)residual,
-                       (const uint16_t*)weight, (uint16_t*)out, H, eps);
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(T), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)residual, (const uint16_t*)weight,
+                       (uint16_t*)out, H, eps);
+  };
+  if (H <= 8192)
+    residual ? go(rmsnorm_kernel<true, 4>) : go(rmsnorm_kernel<false, 4>);
   else
-    hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(T), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)nullptr,
-                       (const uint16_t*)weight, (uint16_t*)out, H, eps);
+    residual ? go(rmsnorm_kernel<true, 8>) : go(rmsnorm_kernel<false, 8>);
   return launch_status();
 }
 

@@ -38,7 +38,7 @@ enum { EPI_NONE = 0, EPI_RES = 1, EPI_SWIGLU = 2 };
 template <bool RMS, int EPI, int RT, bool W8>
 __global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
     const uint16_t* __restrict__ x, int x_stride, const void* __restrict__ Wv, const float* __restrict__ wscale,
-    uint16_t* out, const uint16_t* res, int M, int N, int K, int kslice, float eps, int tiled) {
+    uint16_t* out, const uint16_t* res, int M, int N, int K, int kslice, float eps, int tiled, int w_stride) {
   constexpr int MAXW = RT == 1 ? 16 : 8;
   __shared__ f32x4 part[MAXW][RT][64];
   __shared__ float ssq[MAXW][16];
@@ -52,13 +52,13 @@ __global__ __launch_bounds__(RT == 1 ? 1024 : 512) void skinny_linear_kernel(
   // MFMA step is 64 bytes further along the row. Tiled (`tiled` != 0): the 1 KiB that one wave
   // instruction loads (16 rows x 64 bytes) is stored contiguously in lane order, tiles ordered
   // [row tile][k step], so a wave streams one contiguous run of kslice*16 elements - the access
-  // pattern HBM likes best. Both layouts have the same distance between row tiles (16*K elements).
+  // pattern HBM likes best. Both layouts have the same distance between row tiles (16*w_stride elements).
   const size_t wlane = tiled ? ((size_t)(n0 >> 4) * K + (size_t)w * kslice) * 16 + lane * (W8 ? 16 : 8)
-                             : (size_t)(n0 + fr) * K + k0;
+                             : (size_t)(n0 + fr) * w_stride + k0;
   const int wstep = tiled ? (W8 ? 1024 : 512) : (W8 ? 64 : 32);    // elements between consecutive MFMA steps
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(Wv) + wlane;      // bf16
   const uint8_t* wp8 = reinterpret_cast<const uint8_t*>(Wv) + wlane;       // fp8
-  const size_t tile_stride = (size_t)16 * K;
+  const size_t tile_stride = (size_t)16 * w_stride;          // w_stride == K unless row-major rows are padded
   const bool valid = fr < M;
   const uint16_t* xp = x + (size_t)(valid ? fr : 0) * x_stride + k0;
   f32x4 acc[RT], sq = {0.f, 0.f, 0.f, 0.f};
@@ -194,7 +194,9 @@ extern "C" {
 
 static int skinny_launch(const void* x, int x_stride, const void* W, const float* wscale, bool w8, void* out,
                          const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
-                         int row_tiles, int tiled, void* stream) {
+                         int row_tiles, int tiled, int w_stride, void* stream) {
+  if (w_stride == 0) w_stride = K;
+  if (w_stride < K || w_stride % (w8 ? 16 : 8) != 0 || (tiled && w_stride != K)) return KLM_ERR_SHAPE;
   if (M <= 0 || M > 16 || N <= 0 || N % 16 != 0 || K <= 0 || K % 128 != 0) return KLM_ERR_SHAPE;
   if (epilogue < 0 || epilogue > 2) return KLM_ERR_VARIANT;
   if (!x || !W || !out || ((epilogue == EPI_RES) != (residual != nullptr)) || (w8 && !wscale)) return KLM_ERR_ARG;
@@ -220,7 +222,7 @@ static int skinny_launch(const void* x, int x_stride, const void* W, const float
   const uint16_t* rr = (const uint16_t*)residual;
 #define KLM_SKINNY_L(R, E, T, Q)                                                                            \
   hipLaunchKernelGGL((skinny_linear_kernel<R, E, T, Q>), grid, block, 0, s, xx, x_stride, W, wscale, oo, rr, M, N, \
-                     K, kslice, eps, tiled)
+                     K, kslice, eps, tiled, w_stride)
 #define KLM_SKINNY(R, E)                         \
   do {                                           \
     if (w8) {                                    \
@@ -246,16 +248,17 @@ static int skinny_launch(const void* x, int x_stride, const void* W, const float
 }
 
 int klm_skinny_linear(const void* x, int x_stride, const void* W, void* out, const void* residual, int M, int N,
-                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, int tiled, void* stream) {
+                      int K, int rms, int epilogue, float eps, int waves, int row_tiles, int tiled, int w_stride,
+                      void* stream) {
   return skinny_launch(x, x_stride, W, nullptr, false, out, residual, M, N, K, rms, epilogue, eps, waves, row_tiles,
-                       tiled, stream);
+                       tiled, w_stride, stream);
 }
 
 int klm_skinny_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, void* out,
                          const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
-                         int row_tiles, int tiled, void* stream) {
+                         int row_tiles, int tiled, int w_stride, void* stream) {
   return skinny_launch(x, x_stride, W8, wscale, true, out, residual, M, N, K, rms, epilogue, eps, waves, row_tiles,
-                       tiled, stream);
+                       tiled, w_stride, stream);
 }
 
 }  // extern "C"

@@ -36,8 +36,8 @@ def _lib():
         lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, i, vp]
         lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, vp]
         lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, i, i, vp]
-        lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, i, vp]
-        lib.klm_skinny_linear_w8.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, f, i, i, i, vp]
+        lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, i, i, vp]
+        lib.klm_skinny_linear_w8.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, f, i, i, i, i, vp]
         lib.klm_skinny_linear_w8.restype = i
         for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
                   "klm_skinny_linear"):
@@ -196,7 +196,9 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epil
     if w8 and (tuple(weight_scale.shape) != (N,) or weight_scale.dtype != torch.float32 or not weight_scale.is_contiguous()
                or not weight_scale.is_cuda):
         raise KlmOpsError("skinny_linear: weight_scale must be contiguous fp32 [N] on the GPU")
-    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or not weight.is_contiguous() or not skinny_ok(M, N, K):
+    # row-major weights may be a column slice of a wider allocation (rows further apart than K)
+    w_ok = weight.is_contiguous() or (not tiled and weight.stride(1) == 1 and weight.stride(0) >= K)
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or not w_ok or not skinny_ok(M, N, K):
         raise KlmOpsError(f"skinny_linear: x {tuple(x.shape)} weight {tuple(weight.shape)}")
     n_out = N // 2 if epi == 2 else N
     if residual is not None and (tuple(residual.shape) != (M, N) or not residual.is_contiguous() or residual.dtype != x.dtype):
@@ -209,11 +211,11 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epil
     if w8:
         rc = _lib().klm_skinny_linear_w8(x.data_ptr(), x.stride(0), weight.data_ptr(), weight_scale.data_ptr(),
                                          out.data_ptr(), rp, M, N, K, int(bool(rms)), epi, float(eps), int(waves),
-                                         int(row_tiles), int(bool(tiled)), _stream(x))
+                                         int(row_tiles), int(bool(tiled)), int(weight.stride(0)), _stream(x))
     else:
         rc = _lib().klm_skinny_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), out.data_ptr(), rp, M, N, K,
                                       int(bool(rms)), epi, float(eps), int(waves), int(row_tiles), int(bool(tiled)),
-                                      _stream(x))
+                                      int(weight.stride(0)), _stream(x))
     _check(rc, f"klm_skinny_linear(M={M},N={N},K={K},rms={rms},{epilogue})")
     return out
 

@@ -45,15 +45,15 @@ def decode_step_ms(eng: Engine, batch: int, ctx: int, iters: int = 20, warmup: i
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    c = eng.mcfg
+    c, lc, world = eng.mcfg, eng.lcfg, eng.tp.world        # figures are per rank: this GPU's bytes and FLOPs
     if eng.model.skinny(b):
         weight_bytes = eng.model.decode_stream_bytes()
     else:
         weight_bytes = eng.model.weight_bytes() - c.vocab * c.hidden * 2      # the embedding is only gathered
-    kv_bytes = batch * ctx * c.kv_bytes_per_token() // (2 if eng.cfg.kv_cache_dtype == "fp8" else 1)
+    kv_bytes = batch * ctx * lc.kv_bytes_per_token() // (2 if eng.cfg.kv_cache_dtype == "fp8" else 1)
     return {"batch": batch, "bucket": b, "ctx": ctx, "ms": ms, "tokens_per_s": batch / ms * 1e3,
             "bytes": weight_bytes + kv_bytes, "TBps": (weight_bytes + kv_bytes) / ms / 1e9,
-            "TFLOPs": batch * c.flops_per_token(ctx) / ms / 1e9}
+            "TFLOPs": batch * c.flops_per_token(ctx) / world / ms / 1e9}
 
 
 def prefill_ms(eng: Engine, n_seqs: int, prompt_len: int, iters: int = 3, warmup: int = 1) -> Dict[str, float]:
@@ -72,7 +72,7 @@ def prefill_ms(eng: Engine, n_seqs: int, prompt_len: int, iters: int = 3, warmup
         idx = np.arange(prompt_len)
         slots[i * prompt_len:(i + 1) * prompt_len] = blocks[idx // BLOCK] * BLOCK + idx % BLOCK
     info = [(i * prompt_len, prompt_len, prompt_len) for i in range(n_seqs)]
-    meta = PrefillMeta.build(c, [prompt_len] * n_seqs, torch.from_numpy(bt).to(dev),
+    meta = PrefillMeta.build(eng.lcfg, [prompt_len] * n_seqs, torch.from_numpy(bt).to(dev),
                              torch.tensor(info, dtype=torch.int32, device=dev),
                              torch.tensor([(i + 1) * prompt_len - 1 for i in range(n_seqs)], dtype=torch.int64, device=dev),
                              dev)
@@ -89,7 +89,7 @@ def prefill_ms(eng: Engine, n_seqs: int, prompt_len: int, iters: int = 3, warmup
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = sum(c.flops_per_token(p) for p in range(prompt_len)) * n_seqs
+    flops = sum(c.flops_per_token(p) for p in range(prompt_len)) * n_seqs / eng.tp.world
     eng.cache.k.zero_()
     eng.cache.v.zero_()
     return {"n_seqs": n_seqs, "prompt_len": prompt_len, "ms": ms, "tokens_per_s": T / ms * 1e3,

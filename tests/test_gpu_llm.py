@@ -24,7 +24,7 @@ def _close(a, b, atol, rtol=2e-2):
     assert bool((err <= bound).all()), f"max err {err.max().item():.4g} (at |ref| {b.abs().flatten()[err.argmax()].item():.4g})"
 
 
-@pytest.mark.parametrize("T,H", [(37, 4096), (3, 256), (130, 8192)])
+@pytest.mark.parametrize("T,H", [(37, 4096), (3, 256), (130, 8192), (9, 16384), (5, 12288)])
 def test_rmsnorm_matches_reference(T, H):
     torch.manual_seed(1)
     x, w = _rand(T, H), _rand(H)
@@ -192,6 +192,19 @@ def test_skinny_linear_reads_a_strided_input():
     x = big[:, 4096:8192]                                # row stride 12288
     w = _rand(4096, 4096, scale=0.05)
     _close(llm.skinny_linear(x, w), _lin_ref(x, w, False, "none", None), 5e-2, 2e-2)
+
+
+@pytest.mark.parametrize("M,rt", [(1, 1), (9, 4)])
+def test_skinny_linear_reads_weights_with_a_row_stride(M, rt):
+    """The weight may be a column slice of a wider allocation (w_stride > K): the columns beyond K are never read."""
+    torch.manual_seed(18)
+    N, K, PAD = 1024, 16384, 64
+    big = torch.full((N, K + PAD), float("nan"), dtype=torch.bfloat16, device=DEV)
+    w = big[:, :K]
+    w.copy_(_rand(N, K, scale=0.03))
+    x, res = _rand(M, K), _rand(M, N)
+    want = _lin_ref(x, w.contiguous(), True, "residual", res)
+    _close(llm.skinny_linear(x, w, rms=True, epilogue="residual", residual=res, row_tiles=rt), want, 5e-2, 2e-2)
 
 
 def test_interleaved_gate_up_is_the_plain_swiglu():

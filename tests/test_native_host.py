@@ -28,15 +28,16 @@ def built():
 
 
 def test_all_targets_exist_and_carry_gfx950_code(built):
-    assert set(built) == {"klm_ops", "klm_burner", "klm_rccl_probe", "klm_amdsmi_sampler"}
+    assert set(built) == {"klm_ops", "klm_burner", "klm_rccl_probe", "klm_xgmi", "klm_amdsmi_sampler"}
     for name, path in built.items():
         assert path.exists(), name
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if os.path.exists(objdump):
         import tempfile
         with tempfile.TemporaryDirectory() as td:      # --offloading extracts the code objects into the cwd
-            r = subprocess.run([objdump, "--offloading", str(built["klm_ops"])], capture_output=True, text=True, cwd=td)
-        assert "gfx950" in r.stdout + r.stderr
+            for lib in ("klm_ops", "klm_xgmi"):
+                r = subprocess.run([objdump, "--offloading", str(built[lib])], capture_output=True, text=True, cwd=td)
+                assert "gfx950" in r.stdout + r.stderr, lib
 
 
 def test_executables_fail_with_json_when_no_gpu(built):
@@ -82,3 +83,4 @@ def test_sampler_json_writer_under_asan_ubsan_feeds_the_python_reader(built, tmp
         assert len(s[0]["xgmi"]["links"]) == 7 and s[0]["peak"]["gfx_activity"] == 30
     finally:
         src.close()
+

@@ -141,13 +141,24 @@ def _cmd_serve_llm_tp_launch(a, argv: Sequence[str]) -> int:
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     for sig in (signal.SIGINT, signal.SIGTERM):
         signal.signal(sig, lambda *_: procs[0].terminate())          # rank 0 stops the engine, the others follow it out
+    rc = 0
     try:
-        rc = procs[0].wait()
-        for p in procs[1:]:
-            try:
-                p.wait(timeout=60)
-            except subprocess.TimeoutExpired:
-                p.kill()
+        # a rank that dies takes the job with it: the others would otherwise wait for it in a collective forever
+        while procs[0].poll() is None:
+            dead = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() is not None]
+            if dead:
+                print(f"[tp] rank {dead[0][0]} exited with {dead[0][1]} while the job was running: stopping all ranks",
+                      file=sys.stderr, flush=True)
+                rc = dead[0][1] or 1
+                break
+            time.sleep(0.5)
+        else:
+            rc = procs[0].returncode
+            for p in procs[1:]:
+                try:
+                    p.wait(timeout=60)
+                except subprocess.TimeoutExpired:
+                    pass
     finally:
         for p in procs:
             if p.poll() is None:

@@ -94,3 +94,39 @@ def test_serve_llm_tp_cli_two_cpu_ranks():
     finally:
         if p.poll() is None:
             p.kill()
+
+
+@pytest.mark.timeout(300)
+def test_tp_launcher_stops_the_job_when_a_rank_dies():
+    import signal
+    import time
+    import urllib.request
+    port = free_port()
+    p = subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--model", "tiny", "--device", "cpu", "--tp", "2",
+                          "--host", "127.0.0.1", "--port", str(port), "--max-num-seqs", "4", "--max-model-len", "128", "--kv-blocks", "32"],
+                         cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    try:
+        t_end = time.time() + 120
+        while True:
+            try:
+                urllib.request.urlopen(f"http://127.0.0.1:{port}/health", timeout=1).read()
+                break
+            except OSError:
+                assert p.poll() is None and time.time() < t_end, "server did not come up"
+                time.sleep(0.3)
+        # find rank 1 among the launcher's children and kill exactly that process
+        kids = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()
+        assert len(kids) == 2, kids
+        rank1 = None
+        for k in kids:
+            env = open(f"/proc/{k}/environ", "rb").read().split(b"\0")
+            if b"KLM_TP_RANK=1" in env:
+                rank1 = int(k)
+        assert rank1 is not None
+        os.kill(rank1, signal.SIGKILL)
+        assert p.wait(timeout=60) != 0
+        assert "rank 1 exited" in p.stderr.read()
+    finally:
+        if p.poll() is None:
+            p.kill()

@@ -59,7 +59,7 @@ def targets() -> List[Target]:
     ops = PKG / "ops" / "csrc"
     hdr = ops / "klm_ops.h"
     ops_src = [ops / "gemm_bf16.hip", ops / "gemm_mx.hip", ops / "hbm.hip", ops / "llm_elementwise.hip", ops / "llm_attention.hip",
-               ops / "llm_skinny.hip"]
+               ops / "llm_skinny.hip", ops / "llm_mid.hip"]
     ops_src = [s for s in ops_src if s.exists()]
     out: List[Target] = [
         Target("klm_ops", LIB_DIR / "libklm_ops.so", ops_src, "hip-shared", deps=[hdr, ops / "llm_common.h"]),

@@ -177,6 +177,7 @@ class LlamaModel:
         self.scale = 1.0 / math.sqrt(HEAD_DIM)
         self.fp8_decode = False
         self.skinny_limit: Optional[int] = None                    # overrides skinny_rows() (benchmarks)
+        self.mid_limit: Optional[int] = None                       # overrides mid_rows()
         self.lm_head8: Optional[torch.Tensor] = None
         self.lm_head_s: Optional[torch.Tensor] = None
 
@@ -262,6 +263,58 @@ class LlamaModel:
             tp.all_reduce(lin(act, L, "w_down", out=h, **res(h)))
         return h
 
+    def _stack_mid(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
+        """Batches (or prompt chunks) of up to 128 rows: every projection on the mid-batch weight-streaming kernel
+        (ops/csrc/llm_mid.hip), whose epilogue does what `_stack` needs a kernel of its own for: the residual add +
+        RMSNorm after wo and w_down, SwiGLU after gate_up. Returns the final norm of the residual stream."""
+        cfg, tp = self.lcfg, self.tp
+        residual = self.embed[tokens]
+        x = llm.rmsnorm(residual, self.unit_gain, cfg.eps)
+
+        def close(y, L, name):
+            """residual += y @ W^T (summed over the tensor-parallel ranks); -> its norm"""
+            if tp.world == 1:
+                return llm.mid_linear(y, L[name], kind="res_rms", residual=residual, eps=cfg.eps)
+            h = tp.all_reduce(llm.mid_linear(y, L[name]))
+            return llm.rmsnorm(h, self.unit_gain, cfg.eps, residual=residual)
+
+        # above 64 rows the widest projection is the one shape where the library GEMM still wins (54 vs 63 us at 128
+        # rows of the 8B gate_up): x staging per 224-row block then rivals the weight stream
+        wide_lib = tokens.shape[0] > 64
+        for li, L in enumerate(self.layers):
+            qkv = llm.mid_linear(x, L["wqkv"])
+            llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
+            x = close(attend(qkv, cache.k[li], cache.v[li]), L, "wo")
+            if wide_lib:
+                act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
+            else:
+                act = llm.mid_linear(x, L["w_gate_up"], kind="swiglu")
+            x = close(act, L, "w_down")
+        return x
+
+    def mid_rows(self) -> int:
+        """Largest batch on the mid-batch kernel (beyond skinny_rows()). Per layer it beats hipBLASLt + separate norm /
+        SwiGLU kernels by 15 - 23 % on the 8B shapes at 24 - 128 rows and by 6 - 14 % on the 70B shapes at 32 - 64
+        (scripts/gpu_mid_bench.py)."""
+        if self.mid_limit is not None:
+            return self.mid_limit
+        return llm.MID_MAX_ROWS if self.cfg.hidden <= 4096 else 64
+
+    def mid(self, rows: int) -> bool:
+        c = self.lcfg
+        # wide models: whole-model decode is level with the library path up to 32 rows (70B: 31.0 vs 31.3 ms at 24,
+        # 31.8 vs 30.7 at 32) and ahead beyond (32.4 vs 38.5 ms at 48, 34.4 vs 37.3 at 64)
+        if self.cfg.hidden > 4096 and rows <= 32 and self.mid_limit is None:
+            return False
+        return (not self.skinny(rows) and rows <= self.mid_rows() and self.device.type == "cuda" and c.hidden % 512 == 0
+                and c.ffn % 512 == 0 and c.qkv_dim % 64 == 0 and c.q_dim % 512 == 0 and (2 * c.ffn) % 64 == 0)
+
+    def _trunk(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
+        """The decoder stack on the path that fits the number of rows -> the final norm [T, hidden]."""
+        if self.mid(tokens.shape[0]):
+            return self._stack_mid(tokens, positions, slots, cache, attend)
+        return self._stack(tokens, positions, slots, cache, attend)
+
     def skinny_rows(self) -> int:
         """Largest batch that decodes on the weight-streaming kernel. Measured per layer on MI355X
         (scripts/gpu_skinny_tp_bench.py): with 4096-wide rows it beats hipBLASLt + separate norm / SwiGLU kernels up
@@ -292,7 +345,7 @@ class LlamaModel:
             else:
                 out = llm.skinny_linear(h, self.lm_head, rms=True, eps=cfg.eps)
         else:
-            out = torch.matmul(self._stack(tokens, positions, slots, cache, attend), self.lm_head.t())
+            out = torch.matmul(self._trunk(tokens, positions, slots, cache, attend), self.lm_head.t())
         return self._sample(out, logits)
 
     def _sample(self, out: torch.Tensor, logits: bool) -> torch.Tensor:
@@ -321,7 +374,7 @@ class LlamaModel:
             return llm.paged_attn_prefill(qkv, kc, vc, meta.block_tables, meta.seq_info, meta.tiles, self.scale,
                                           cfg.n_q, q_tiles=meta.q_tiles)
 
-        x = self._stack(tokens, positions, slots, cache, attend)
+        x = self._trunk(tokens, positions, slots, cache, attend)
         return self._sample(torch.matmul(x[meta.last_rows], self.lm_head.t()), logits)
 
     def load_shard_from(self, full: "LlamaModel") -> "LlamaModel":

@@ -120,6 +120,16 @@ int klm_skinny_linear_w8(const void* x, int x_stride, const void* W8, const floa
                          const void* residual, int M, int N, int K, int rms, int epilogue, float eps, int waves,
                          int row_tiles, int tiled, int w_stride, void* stream);
 
+// Linear layers of decode at batch 17 - 128 (llm_mid.hip): out = x[M][K] . W[N][K]^T with W streamed from HBM into
+// MFMA operands and x staged through LDS; fp32 partial sums part[ksplit][M][N], then an epilogue kernel that sums the
+// K splits and applies kind 0: plain (out[M][N] bf16), 1: SwiGLU on gate/up columns interleaved by 8 (out[M][N/2]),
+// 2: residual[M][N] += sum, out = rmsnorm(residual) with unit gain. M <= 128, N % 64 == 0, K % 128 == 0.
+// klm_mid_linear_plan fills in the zeros among ksplit / waves (4, 8) / row_tiles (1, 2) the way the launcher would.
+int klm_mid_linear_plan(int M, int N, int K, int* ksplit, int* waves, int* row_tiles);
+int klm_mid_linear(const void* x, int x_stride, const void* W, int w_stride, float* part, int M, int N, int K, int ksplit,
+                   int waves, int row_tiles, void* stream);
+int klm_mid_epilogue(const float* part, int ksplit, int M, int N, int kind, void* out, void* residual, float eps, void* stream);
+
 const char* klm_version(void);
 
 #ifdef __cplusplus

@@ -39,6 +39,12 @@ def _lib():
         lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, i, i, vp]
         lib.klm_skinny_linear_w8.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, f, i, i, i, i, vp]
         lib.klm_skinny_linear_w8.restype = i
+        ip = ctypes.POINTER(i)
+        lib.klm_mid_linear_plan.argtypes = [i, i, i, ip, ip, ip]
+        lib.klm_mid_linear.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, vp]
+        lib.klm_mid_epilogue.argtypes = [vp, i, i, i, i, vp, vp, f, vp]
+        for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_epilogue"):
+            getattr(lib, n).restype = i
         for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
                   "klm_skinny_linear"):
             getattr(lib, n).restype = i
@@ -217,6 +223,66 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epil
                                       int(bool(rms)), epi, float(eps), int(waves), int(row_tiles), int(bool(tiled)),
                                       int(weight.stride(0)), _stream(x))
     _check(rc, f"klm_skinny_linear(M={M},N={N},K={K},rms={rms},{epilogue})")
+    return out
+
+
+MID_MAX_ROWS = 128
+_MID_KINDS = {"none": 0, "swiglu": 1, "res_rms": 2}
+
+
+def mid_ok(M: int, N: int, K: int) -> bool:
+    """Shapes the mid-batch kernel takes (decode at batch 17 - 128, short prefill chunks)."""
+    return 0 < M <= MID_MAX_ROWS and N % 64 == 0 and K % 512 == 0
+
+
+def mid_plan(M: int, N: int, K: int, ksplit: int = 0, waves: int = 0, row_tiles: int = 0):
+    """(ksplit, waves, row_tiles) the launcher uses; zeros are filled in by its heuristic."""
+    ks, nw, rt = ctypes.c_int(ksplit), ctypes.c_int(waves), ctypes.c_int(row_tiles)
+    _check(_lib().klm_mid_linear_plan(M, N, K, ctypes.byref(ks), ctypes.byref(nw), ctypes.byref(rt)), f"klm_mid_linear_plan({M},{N},{K})")
+    return ks.value, nw.value, rt.value
+
+
+def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residual: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None, eps: float = 1e-5, ksplit: int = 0, waves: int = 0,
+               row_tiles: int = 0) -> torch.Tensor:
+    """``x[M,K] @ weight[N,K].T`` for M <= 128 with the weight streamed from HBM once (llm_mid.hip), finished by
+    `kind`: "none" -> [M,N]; "swiglu" (gate/up rows interleaved by 8) -> [M,N/2]; "res_rms": `residual` [M,N] is
+    updated in place with the product and its RMSNorm (unit gain) is returned."""
+    k = _MID_KINDS[kind]
+    N, K = weight.shape
+    M = x.shape[0]
+    if (k == 2) != (residual is not None):
+        raise KlmOpsError("mid_linear: `residual` goes with kind='res_rms'")
+    n_out = N // 2 if k == 1 else N
+    if not x.is_cuda:
+        o = x[:, :K].float() @ weight.float().t()
+        if k == 1:
+            o = ref.silu_mul(o)
+        elif k == 2:
+            o, nr = ref.rmsnorm(o.to(x.dtype), torch.ones(N, dtype=x.dtype), eps, residual=residual)
+            residual.copy_(nr)
+        o = o.to(x.dtype)
+        if out is not None:
+            out.copy_(o)
+            return out
+        return o
+    _bf16(x, weight)
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or weight.stride(1) != 1 or weight.stride(0) < K or not mid_ok(M, N, K):
+        raise KlmOpsError(f"mid_linear: x {tuple(x.shape)} weight {tuple(weight.shape)}")
+    if residual is not None and (tuple(residual.shape) != (M, N) or not residual.is_contiguous() or residual.dtype != x.dtype):
+        raise KlmOpsError("mid_linear: residual must be contiguous [M,N]")
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
+        raise KlmOpsError("mid_linear: bad out")
+    ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
+    part = torch.empty((ks, M, N), dtype=torch.float32, device=x.device)
+    st = _stream(x)
+    _check(_lib().klm_mid_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), part.data_ptr(), M, N, K,
+                                 ks, nw, rt, st), f"klm_mid_linear(M={M},N={N},K={K},ks={ks},nw={nw},rt={rt})")
+    _check(_lib().klm_mid_epilogue(part.data_ptr(), ks, M, N, k, out.data_ptr(),
+                                   residual.data_ptr() if residual is not None else None, float(eps), st),
+           f"klm_mid_epilogue(M={M},N={N},{kind})")
     return out
 
 

@@ -328,3 +328,47 @@ def test_prefill_attention_over_an_fp8_cache_matches_the_reference_on_the_same_v
     got = llm.paged_attn_prefill(q, k8, v8, bt, seq_info, tiles, scale, n_q, q_tiles=q_tiles)   # variant 0 is forced
     want = ref.paged_attn_prefill(q, k8.to(torch.bfloat16), v8.to(torch.bfloat16), bt, seq_info, scale)
     _close(got, want, 2e-2)
+
+
+# ------------------------------------------------------------------ mid-batch linear (llm_mid.hip)
+@pytest.mark.parametrize("M", [17, 48, 64, 100, 128])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (256, 512), (28672, 4096)])
+def test_mid_linear_matches_reference(M, N, K):
+    torch.manual_seed(31)
+    x, w = _rand(M, K), _rand(N, K, scale=0.03)
+    want = x.float() @ w.float().t()
+    _close(llm.mid_linear(x, w), want, 5e-2, 2e-2)
+    _close(llm.mid_linear(x, w, kind="swiglu"), ref.silu_mul(want), 5e-2, 2e-2)
+    if N > 16384:                                        # res_rms keeps a row in one block's registers
+        with pytest.raises(llm.KlmOpsError):
+            llm.mid_linear(x, w, kind="res_rms", residual=_rand(M, N))
+        return
+    res = _rand(M, N)
+    res0 = res.clone()
+    got = llm.mid_linear(x, w, kind="res_rms", residual=res)
+    new_res = (want + res0.float()).to(torch.bfloat16)
+    _close(res, new_res, 1e-2, 2 ** -7)                  # one bf16 rounding of (fp32 product + residual); sum order differs
+    hf = res.float()
+    _close(got, hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5), 3e-2, 2e-2)
+
+
+@pytest.mark.parametrize("ksplit,waves,rt", [(1, 4, 1), (4, 8, 1), (8, 4, 2), (2, 8, 2), (8, 4, 1), (16, 8, 2)])
+def test_mid_linear_every_configuration_gives_the_same_product(ksplit, waves, rt):
+    torch.manual_seed(32)
+    M, N, K = 72, 1024, 4096
+    x, w = _rand(M, K), _rand(N, K, scale=0.03)
+    assert llm.mid_plan(M, N, K, ksplit, waves, rt) == (ksplit, waves, rt)
+    _close(llm.mid_linear(x, w, ksplit=ksplit, waves=waves, row_tiles=rt), x.float() @ w.float().t(), 5e-2, 2e-2)
+
+
+def test_mid_linear_reads_strided_operands_and_rejects_bad_shapes():
+    torch.manual_seed(33)
+    big = _rand(40, 3 * 1024)
+    x = big[:, 1024:2048]
+    wbig = _rand(512, 1024 + 64, scale=0.05)
+    w = wbig[:, :1024]
+    _close(llm.mid_linear(x, w), x.float() @ w.float().t(), 5e-2, 2e-2)
+    with pytest.raises(llm.KlmOpsError):
+        llm.mid_linear(_rand(129, 1024), w)
+    with pytest.raises(llm.KlmOpsError):
+        llm.mid_linear(_rand(8, 1000), _rand(512, 1000))

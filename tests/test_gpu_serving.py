@@ -58,9 +58,19 @@ def _rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max())
 
 
-@pytest.mark.parametrize("n_seqs", [3, 20])          # 3: skinny decode path; 20: library GEMM decode path
+@pytest.mark.parametrize("n_seqs", [3, 20, 40])      # decode on the skinny kernel (3) and on the mid-batch kernel (20, 40)
 def test_gpu_logits_match_the_fp32_cpu_model(gpu_model, cpu_model, n_seqs):
+    assert gpu_model.skinny(3) and gpu_model.mid(20) and gpu_model.mid(40) and not gpu_model.mid(129)
     _compare_logits(gpu_model, cpu_model, n_seqs)
+
+
+def test_gpu_logits_on_the_library_gemm_path(gpu_model, cpu_model):
+    gpu_model.mid_limit = 0                              # batches above 16 rows on hipBLASLt + norm / SwiGLU kernels
+    try:
+        assert not gpu_model.mid(20)
+        _compare_logits(gpu_model, cpu_model, 20)
+    finally:
+        gpu_model.mid_limit = None
 
 
 def test_fp8_decode_weights_match_the_fp32_cpu_model_with_the_dequantised_weights():
@@ -79,7 +89,7 @@ def _compare_logits(gpu_model, cpu_model, n_seqs, kv_dtype=None, tol=0.03):
     g = torch.Generator().manual_seed(n_seqs)
     lens = [int(x) for x in torch.randint(5, 90, (n_seqs,), generator=g)]
     prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in lens]
-    mb, nblocks = 8, 200
+    mb, nblocks = 8, 300
     out = {}
     for name, model in (("cpu", cpu_model), ("gpu", gpu_model)):
         dev = model.device

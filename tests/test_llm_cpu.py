@@ -347,3 +347,19 @@ def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model):
     t = eng.metrics.truth()["totals"]
     assert t["finished"] == 14 and t["generation_tokens"] >= sum(len(r.out) for _, r in reqs)
     assert eng.alloc.free == eng.alloc.total
+
+
+def test_mid_batch_stack_computes_what_the_library_stack_computes():
+    """models/llama.py `_stack_mid` (fused residual + norm / SwiGLU epilogues) against `_stack`, on the CPU fallbacks."""
+    from k8s_llm_monitor_amd.models.llama import PRESETS, LlamaModel
+    m = LlamaModel(PRESETS["tiny"], "cpu", seed=2, dtype=torch.float32)
+    T = 24
+    toks = torch.randint(0, m.cfg.vocab, (T,))
+    pos = torch.arange(T, dtype=torch.int32)
+    slots = torch.arange(T, dtype=torch.int32)
+
+    def attend(qkv, kc, vc):                           # any function of qkv will do: the stacks must agree around it
+        return qkv[:, :m.cfg.q_dim].contiguous()
+    a = m._stack(toks, pos, slots, m.new_cache(4), attend)
+    b = m._stack_mid(toks, pos, slots, m.new_cache(4), attend)
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)

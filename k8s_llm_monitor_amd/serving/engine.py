@@ -102,9 +102,13 @@ class Request:
 
 
 def _buckets(limit: int) -> List[int]:
+    """Decode batch sizes that get a hipGraph: powers of two, and from 16 on the midpoints (24, 48, 96, ...): a step
+    costs what its bucket costs (Llama-3-8B: 5.6 ms at 48, 6.2 ms at 64), so 40 running sequences should not pay for 64."""
     out, b = [], 1
     while b < limit:
         out.append(b)
+        if b >= 16 and b + b // 2 < limit:
+            out.append(b + b // 2)
         b *= 2
     out.append(limit)
     return out

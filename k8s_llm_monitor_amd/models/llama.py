@@ -184,7 +184,7 @@ class LlamaModel:
     _PROJ = ("wqkv", "wo", "w_gate_up", "w_down")
 
     def enable_fp8_decode(self) -> "LlamaModel":
-        """W8A16 for the weight-streaming decode path (batch <= 16): every projection gets an e4m3 copy
+        """W8A16 for the weight-streaming decode paths (skinny kernel up to 16 rows, mid-batch kernel up to 128): every projection gets an e4m3 copy
         with one scale per output row, stored in the skinny kernel's streaming order (ops.llm.tile_weights);
         activations stay bf16. The bf16 weights are replaced by the dequantised values, so the library-GEMM
         path (prefill, larger batches) and the fp8 path compute with the same weights. Costs half the
@@ -208,13 +208,16 @@ class LlamaModel:
             n += sum(L[k].numel() for k in self._PROJ)
         return n * 2
 
-    def decode_stream_bytes(self) -> int:
-        """Weight bytes one skinny-path decode step reads (embedding rows excluded)."""
-        per = 1 if self.fp8_decode else 2
-        n = self.lm_head.numel()
-        for L in self.layers:
-            n += sum(L[k].numel() for k in self._PROJ)
-        return n * per
+    def decode_stream_bytes(self, rows: int = 1) -> int:
+        """Weight bytes one decode step of `rows` sequences reads (embedding rows excluded): fp8 copies where the
+        path for that batch uses them (the lm_head is a library GEMM on the mid-batch path: bf16)."""
+        layers = sum(L[k].numel() for L in self.layers for k in self._PROJ)
+        head = self.lm_head.numel()
+        if self.fp8_decode and self.skinny(rows):
+            return layers + head
+        if self.fp8_decode and self.mid(rows):
+            return layers + 2 * head
+        return 2 * (layers + head)
 
     def new_cache(self, num_blocks: int, dtype=None) -> KVCache:
         return KVCache(self.lcfg, num_blocks, self.device, dtype or self.dtype)
@@ -268,27 +271,33 @@ class LlamaModel:
         (ops/csrc/llm_mid.hip), whose epilogue does what `_stack` needs a kernel of its own for: the residual add +
         RMSNorm after wo and w_down, SwiGLU after gate_up. Returns the final norm of the residual stream."""
         cfg, tp = self.lcfg, self.tp
+        f8 = self.fp8_decode
         residual = self.embed[tokens]
         x = llm.rmsnorm(residual, self.unit_gain, cfg.eps)
+
+        def lin(y, L, name, **kw):
+            if f8:
+                return llm.mid_linear(y, L[name + "8"], weight_scale=L[name + "_s"], eps=cfg.eps, **kw)
+            return llm.mid_linear(y, L[name], eps=cfg.eps, **kw)
 
         def close(y, L, name):
             """residual += y @ W^T (summed over the tensor-parallel ranks); -> its norm"""
             if tp.world == 1:
-                return llm.mid_linear(y, L[name], kind="res_rms", residual=residual, eps=cfg.eps)
-            h = tp.all_reduce(llm.mid_linear(y, L[name]))
+                return lin(y, L, name, kind="res_rms", residual=residual)
+            h = tp.all_reduce(lin(y, L, name))
             return llm.rmsnorm(h, self.unit_gain, cfg.eps, residual=residual)
 
-        # above 64 rows the widest projection is the one shape where the library GEMM still wins (54 vs 63 us at 128
-        # rows of the 8B gate_up): x staging per 224-row block then rivals the weight stream
-        wide_lib = tokens.shape[0] > 64
+        # above 64 rows the widest bf16 projection is the one shape where the library GEMM still wins (54 vs 63 us at
+        # 128 rows of the 8B gate_up): x staging per 224-row block then rivals the weight stream
+        wide_lib = tokens.shape[0] > 64 and not f8
         for li, L in enumerate(self.layers):
-            qkv = llm.mid_linear(x, L["wqkv"])
+            qkv = lin(x, L, "wqkv")
             llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
             x = close(attend(qkv, cache.k[li], cache.v[li]), L, "wo")
             if wide_lib:
                 act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
             else:
-                act = llm.mid_linear(x, L["w_gate_up"], kind="swiglu")
+                act = lin(x, L, "w_gate_up", kind="swiglu")
             x = close(act, L, "w_down")
         return x
 
@@ -298,13 +307,13 @@ class LlamaModel:
         (scripts/gpu_mid_bench.py)."""
         if self.mid_limit is not None:
             return self.mid_limit
-        return llm.MID_MAX_ROWS if self.cfg.hidden <= 4096 else 64
+        return llm.MID_MAX_ROWS if (self.cfg.hidden <= 4096 or self.fp8_decode) else 64
 
     def mid(self, rows: int) -> bool:
         c = self.lcfg
         # wide models: whole-model decode is level with the library path up to 32 rows (70B: 31.0 vs 31.3 ms at 24,
         # 31.8 vs 30.7 at 32) and ahead beyond (32.4 vs 38.5 ms at 48, 34.4 vs 37.3 at 64)
-        if self.cfg.hidden > 4096 and rows <= 32 and self.mid_limit is None:
+        if self.cfg.hidden > 4096 and rows <= 32 and self.mid_limit is None and not self.fp8_decode:
             return False
         return (not self.skinny(rows) and rows <= self.mid_rows() and self.device.type == "cuda" and c.hidden % 512 == 0
                 and c.ffn % 512 == 0 and c.qkv_dim % 64 == 0 and c.q_dim % 512 == 0 and (2 * c.ffn) % 64 == 0)

@@ -128,6 +128,8 @@ int klm_skinny_linear_w8(const void* x, int x_stride, const void* W8, const floa
 int klm_mid_linear_plan(int M, int N, int K, int* ksplit, int* waves, int* row_tiles);
 int klm_mid_linear(const void* x, int x_stride, const void* W, int w_stride, float* part, int M, int N, int K, int ksplit,
                    int waves, int row_tiles, void* stream);
+int klm_mid_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, float* part, int M, int N, int K,
+                      int ksplit, int waves, int row_tiles, void* stream);     // e4m3 weights, tiled order, fp32 row scales
 int klm_mid_epilogue(const float* part, int ksplit, int M, int N, int kind, void* out, void* residual, float eps, void* stream);
 
 const char* klm_version(void);

@@ -37,10 +37,16 @@ constexpr int SLOTS = KC / 8;           // 16-byte slots per x row in a chunk
 // load it issued before them, which caps the weight prefetch at one chunk (the first version of this kernel:
 // 3.4 - 4.0 TB/s). With x on waves of its own, a consumer keeps D chunks of weights in flight in a register ring
 // (16 KiB per wave) and its only waits are for the oldest ring entry.
-template <int MT, int RT, int NW>
+//
+// W8: the weights are e4m3 bytes in the skinny kernel's tiled order (ops.llm.tile_weights: the 1 KiB a wave
+// instruction loads - 16 rows x 64 k-values - is contiguous, tiles ordered [row tile][k / 64]) with one fp32 scale per
+// row. A lane's 16 bytes become two bf16 fragments in registers (k-values 0..7 and 8..15 of its 16), multiplied with
+// the x slots at the same k offsets; the scale multiplies the fp32 partial sums. Half the bytes, contiguous runs.
+template <int MT, int RT, int NW, bool W8>
 __global__ __launch_bounds__((NW + (MT + 1) / 2) * 64) void mid_linear_kernel(const uint16_t* __restrict__ x, int x_stride,
-                                                                              const uint16_t* __restrict__ W, int w_stride,
-                                                                              float* __restrict__ part, int M, int N, int kper) {
+                                                                              const void* __restrict__ Wv, int w_stride,
+                                                                              const float* __restrict__ wscale,
+                                                                              float* __restrict__ part, int M, int N, int K, int kper) {
   constexpr int ROWS = MT * 16;                       // x rows held in LDS (rows >= M are zero)
   constexpr int NP = (MT + 1) / 2;                    // producer waves: 8 loads of 16 bytes per lane and chunk
   constexpr int XL = ROWS * SLOTS / (NP * 64);
@@ -105,9 +111,16 @@ __global__ __launch_bounds__((NW + (MT + 1) / 2) * 64) void mid_linear_kernel(co
   // ---------------- consumers
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = (blockIdx.x * NW + w) * RT * 16;
-  const uint16_t* wp[RT];
+  // bf16: a lane's 16 bytes of k step s sit at row n0 + fr, k = chunk + s*32 + fq*8. fp8: tile (row tile, k / 64) is
+  // 1 KiB, lane l at byte 16 l; a 128-wide chunk is two tiles. `cstep` = distance between the chunk's loads.
+  constexpr int LOADS = W8 ? 2 : 4;                   // 16-byte weight loads per row tile and chunk
+  const char* wp[RT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) wp[r] = W + (size_t)(n0 + r * 16 + fr) * w_stride + kb + fq * 8;
+  for (int r = 0; r < RT; ++r)
+    wp[r] = W8 ? static_cast<const char*>(Wv) + ((size_t)((n0 >> 4) + r) * (K >> 6) + (kb >> 6)) * 1024 + lane * 16
+               : static_cast<const char*>(Wv) + ((size_t)(n0 + r * 16 + fr) * w_stride + kb + fq * 8) * 2;
+  constexpr int cstep = W8 ? 1024 : 64;               // bytes
+  auto wofs = [&](int j) { return (size_t)phys(j) * (W8 ? 16 : 2); };     // chunk -> byte offset (fp8 tiled: 2 KiB per chunk)
 
   f32x4 acc[MT][RT];
 #pragma unroll
@@ -117,14 +130,14 @@ __global__ __launch_bounds__((NW + (MT + 1) / 2) * 64) void mid_linear_kernel(co
 
   // The launcher guarantees nchunks % D == 0, and every refill is issued unconditionally (past the end it re-reads
   // the last chunk into a ring entry nobody will use): with no branch around a load the compiler can count the
-  // loads in flight and waits for exactly the oldest ring entry (vmcnt(12)), not for all of them.
-  bf16x8 ring[D][RT][4];
+  // loads in flight and waits for exactly the oldest ring entry, not for all of them.
+  u32x4 ring[D][RT][LOADS];
 #pragma unroll
   for (int d = 0; d < D; ++d)
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ring[d][r][s] = *reinterpret_cast<const bf16x8*>(wp[r] + phys(d) + s * 32);
+      for (int s = 0; s < LOADS; ++s) ring[d][r][s] = *reinterpret_cast<const u32x4*>(wp[r] + wofs(d) + s * cstep);
 
   for (int c0 = 0; c0 < nchunks; c0 += D) {
 #pragma unroll
@@ -132,6 +145,9 @@ __global__ __launch_bounds__((NW + (MT + 1) / 2) * 64) void mid_linear_kernel(co
       const int c = c0 + u;
       __syncthreads();                                // x chunk c is in xs[c & 1]  (D is even: c & 1 == u & 1)
       const u32x4* buf = xs[u & 1];
+      // k step s of the chunk (32 k-values per MFMA): bf16 lanes hold k = s*32 + fq*8 .. +8 = x slot s*4 + fq;
+      // fp8 lanes hold k = (s/2)*64 + fq*16 + (s%2)*8 .. +8 = x slot (s/2)*8 + fq*2 + s%2
+      auto slot = [&](int s) { return W8 ? (s >> 1) * 8 + fq * 2 + (s & 1) : s * 4 + fq; };
       // the x fragments of k step s + 1 are read while the MFMAs of step s run (the scheduler barriers keep the
       // compiler from folding the reads back into read-wait-multiply pairs)
       // (with 128 rows the second fragment buffer would not fit the register budget of 12 waves per CU: there the
@@ -140,28 +156,47 @@ __global__ __launch_bounds__((NW + (MT + 1) / 2) * 64) void mid_linear_kernel(co
       u32x4 xf[XB][MT];
       if (XB == 2) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xf[0][t] = buf[(t * 16 + fr) * SLOTS + (fq ^ fr)];
+        for (int t = 0; t < MT; ++t) xf[0][t] = buf[(t * 16 + fr) * SLOTS + (slot(0) ^ fr)];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int sn = XB == 2 ? s + 1 : s;           // the step whose fragments are fetched now
         if (sn < 4) {
 #pragma unroll
-          for (int t = 0; t < MT; ++t) xf[sn % XB][t] = buf[(t * 16 + fr) * SLOTS + ((sn * 4 + fq) ^ fr)];
+          for (int t = 0; t < MT; ++t) xf[sn % XB][t] = buf[(t * 16 + fr) * SLOTS + (slot(sn) ^ fr)];
         }
         __builtin_amdgcn_sched_barrier(0);
+        bf16x8 wf[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          if (W8) {
+            const u32x4 raw = ring[u][r][s >> 1];
+            wf[r] = (s & 1) ? fp8x8_to_bf16(raw[2], raw[3]) : fp8x8_to_bf16(raw[0], raw[1]);
+          } else {
+            wf[r] = __builtin_bit_cast(bf16x8, ring[u][r][s]);
+          }
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int r = 0; r < RT; ++r)
-            acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[u][r][s], __builtin_bit_cast(bf16x8, xf[s % XB][t]), acc[t][r], 0, 0, 0);
+            acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r], __builtin_bit_cast(bf16x8, xf[s % XB][t]), acc[t][r], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      const int nxt = phys(min(c + D, nchunks - 1));
+      const size_t nxt = wofs(min(c + D, nchunks - 1));
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ring[u][r][s] = *reinterpret_cast<const bf16x8*>(wp[r] + nxt + s * 32);
+        for (int s = 0; s < LOADS; ++s) ring[u][r][s] = *reinterpret_cast<const u32x4*>(wp[r] + nxt + s * cstep);
+    }
+  }
+
+  if (W8) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(wscale + n0 + r * 16 + fq * 4);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][r] *= sc;
     }
   }
 
@@ -253,22 +288,38 @@ __global__ __launch_bounds__(256) void mid_res_rms_kernel(const float* __restric
   }
 }
 
-template <int MT, int RT>
-void launch_nw(int nw, dim3 grid, hipStream_t s, const uint16_t* x, int x_stride, const uint16_t* W, int w_stride, float* part,
-               int M, int N, int kper) {
-  if (nw == 8)
-    hipLaunchKernelGGL((mid_linear_kernel<MT, RT, 8>), grid, dim3((8 + (MT + 1) / 2) * 64), 0, s, x, x_stride, W, w_stride, part, M, N, kper);
-  else if (nw == 7)
-    hipLaunchKernelGGL((mid_linear_kernel<MT, RT, 7>), grid, dim3((7 + (MT + 1) / 2) * 64), 0, s, x, x_stride, W, w_stride, part, M, N, kper);
-  else
-    hipLaunchKernelGGL((mid_linear_kernel<MT, RT, 4>), grid, dim3((4 + (MT + 1) / 2) * 64), 0, s, x, x_stride, W, w_stride, part, M, N, kper);
+struct MidArgs {
+  const uint16_t* x;
+  int x_stride;
+  const void* W;
+  int w_stride;
+  const float* wscale;
+  float* part;
+  int M, N, K, kper;
+};
+
+template <int MT, int RT, bool W8>
+void launch_nw(int nw, dim3 grid, hipStream_t s, const MidArgs& a) {
+#define KLM_MID_GO(NWV)                                                                                                  \
+  hipLaunchKernelGGL((mid_linear_kernel<MT, RT, NWV, W8>), grid, dim3((NWV + (MT + 1) / 2) * 64), 0, s, a.x, a.x_stride, a.W, \
+                     a.w_stride, a.wscale, a.part, a.M, a.N, a.K, a.kper)
+  if (nw == 8) KLM_MID_GO(8);
+  else if (nw == 7) KLM_MID_GO(7);
+  else KLM_MID_GO(4);
+#undef KLM_MID_GO
 }
 
-template <int MT>
-void launch_rt(int rt, int nw, dim3 grid, hipStream_t s, const uint16_t* x, int x_stride, const uint16_t* W, int w_stride,
-               float* part, int M, int N, int kper) {
-  if (rt == 2) launch_nw<MT, 2>(nw, grid, s, x, x_stride, W, w_stride, part, M, N, kper);
-  else launch_nw<MT, 1>(nw, grid, s, x, x_stride, W, w_stride, part, M, N, kper);
+template <int MT, bool W8>
+void launch_rt(int rt, int nw, dim3 grid, hipStream_t s, const MidArgs& a) {
+  if (rt == 2) launch_nw<MT, 2, W8>(nw, grid, s, a);
+  else launch_nw<MT, 1, W8>(nw, grid, s, a);
+}
+
+template <bool W8>
+void launch_mt(int rt, int nw, dim3 grid, hipStream_t s, const MidArgs& a) {
+  if (a.M <= 32) launch_rt<2, W8>(rt, nw, grid, s, a);
+  else if (a.M <= 64) launch_rt<4, W8>(rt, nw, grid, s, a);
+  else launch_rt<8, W8>(rt, nw, grid, s, a);
 }
 
 }  // namespace
@@ -314,24 +365,34 @@ int klm_mid_linear_plan(int M, int N, int K, int* ksplit, int* waves, int* row_t
   return KLM_OK;
 }
 
-// part: fp32 [ksplit][M][N] (written in full). x rows x_stride apart, W rows w_stride apart (elements, multiples of 8).
-int klm_mid_linear(const void* x, int x_stride, const void* W, int w_stride, float* part, int M, int N, int K, int ksplit,
-                   int waves, int row_tiles, void* stream) {
+static int mid_launch(const void* x, int x_stride, const void* W, int w_stride, const float* wscale, bool w8, float* part, int M,
+                      int N, int K, int ksplit, int waves, int row_tiles, void* stream) {
   int ks = ksplit, nw = waves, rt = row_tiles;
   const int rc = klm_mid_linear_plan(M, N, K, &ks, &nw, &rt);
   if (rc != KLM_OK) return rc;
   if (ksplit > 0 && ks != ksplit) return KLM_ERR_SHAPE;          // the caller sized `part` for its own split
-  if (!x || !W || !part) return KLM_ERR_ARG;
-  if (x_stride % 8 != 0 || x_stride < K || w_stride % 8 != 0 || w_stride < K) return KLM_ERR_SHAPE;
-  if (!aligned16(x) || !aligned16(W) || !aligned16(part)) return KLM_ERR_ALIGN;
+  if (!x || !W || !part || (w8 && !wscale)) return KLM_ERR_ARG;
+  if (x_stride % 8 != 0 || x_stride < K) return KLM_ERR_SHAPE;
+  if (w8 ? (w_stride != K) : (w_stride % 8 != 0 || w_stride < K)) return KLM_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(W) || !aligned16(part) || !aligned16(wscale)) return KLM_ERR_ALIGN;
   const dim3 grid(N / (nw * rt * 16), ks);
-  const int kper = K / ks;
+  const MidArgs a{static_cast<const uint16_t*>(x), x_stride, W, w_stride, wscale, part, M, N, K, K / ks};
   auto s = static_cast<hipStream_t>(stream);
-  auto xx = static_cast<const uint16_t*>(x), ww = static_cast<const uint16_t*>(W);
-  if (M <= 32) launch_rt<2>(rt, nw, grid, s, xx, x_stride, ww, w_stride, part, M, N, kper);
-  else if (M <= 64) launch_rt<4>(rt, nw, grid, s, xx, x_stride, ww, w_stride, part, M, N, kper);
-  else launch_rt<8>(rt, nw, grid, s, xx, x_stride, ww, w_stride, part, M, N, kper);
+  if (w8) launch_mt<true>(rt, nw, grid, s, a);
+  else launch_mt<false>(rt, nw, grid, s, a);
   return launch_status();
+}
+
+// part: fp32 [ksplit][M][N] (written in full). x rows x_stride apart, W rows w_stride apart (elements, multiples of 8).
+int klm_mid_linear(const void* x, int x_stride, const void* W, int w_stride, float* part, int M, int N, int K, int ksplit,
+                   int waves, int row_tiles, void* stream) {
+  return mid_launch(x, x_stride, W, w_stride, nullptr, false, part, M, N, K, ksplit, waves, row_tiles, stream);
+}
+
+// The same with e4m3 weights in the tiled order of ops.llm.tile_weights and one fp32 scale per row (W8A16).
+int klm_mid_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, float* part, int M, int N, int K,
+                      int ksplit, int waves, int row_tiles, void* stream) {
+  return mid_launch(x, x_stride, W8, K, wscale, true, part, M, N, K, ksplit, waves, row_tiles, stream);
 }
 
 // kind 0: out[M][N] = sum of the splits. 1: SwiGLU, out[M][N/2]. 2: residual[M][N] += sum, out[M][N] = rmsnorm(residual).

@@ -42,8 +42,9 @@ def _lib():
         ip = ctypes.POINTER(i)
         lib.klm_mid_linear_plan.argtypes = [i, i, i, ip, ip, ip]
         lib.klm_mid_linear.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, vp]
+        lib.klm_mid_linear_w8.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, i, vp]
         lib.klm_mid_epilogue.argtypes = [vp, i, i, i, i, vp, vp, f, vp]
-        for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_epilogue"):
+        for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_linear_w8", "klm_mid_epilogue"):
             getattr(lib, n).restype = i
         for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
                   "klm_skinny_linear"):
@@ -244,18 +245,24 @@ def mid_plan(M: int, N: int, K: int, ksplit: int = 0, waves: int = 0, row_tiles:
 
 def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, eps: float = 1e-5, ksplit: int = 0, waves: int = 0,
-               row_tiles: int = 0) -> torch.Tensor:
+               row_tiles: int = 0, weight_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x[M,K] @ weight[N,K].T`` for M <= 128 with the weight streamed from HBM once (llm_mid.hip), finished by
     `kind`: "none" -> [M,N]; "swiglu" (gate/up rows interleaved by 8) -> [M,N/2]; "res_rms": `residual` [M,N] is
-    updated in place with the product and its RMSNorm (unit gain) is returned."""
+    updated in place with the product and its RMSNorm (unit gain) is returned.
+    `weight` is bf16 row-major (rows may be further apart than K), or e4m3 in the tiled order of `tile_weights` with
+    `weight_scale` [N] (W8A16: half the bytes)."""
     k = _MID_KINDS[kind]
     N, K = weight.shape
     M = x.shape[0]
     if (k == 2) != (residual is not None):
         raise KlmOpsError("mid_linear: `residual` goes with kind='res_rms'")
+    w8 = weight.dtype == torch.float8_e4m3fn
+    if w8 != (weight_scale is not None):
+        raise KlmOpsError("mid_linear: `weight_scale` goes with float8_e4m3fn weights (tiled)")
     n_out = N // 2 if k == 1 else N
     if not x.is_cuda:
-        o = x[:, :K].float() @ weight.float().t()
+        wf = untile_weights(weight).float() * weight_scale.float()[:, None] if w8 else weight.float()
+        o = x[:, :K].float() @ wf.t()
         if k == 1:
             o = ref.silu_mul(o)
         elif k == 2:
@@ -266,7 +273,10 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residu
             out.copy_(o)
             return out
         return o
-    _bf16(x, weight)
+    _bf16(x) if w8 else _bf16(x, weight)
+    if w8 and (not weight.is_contiguous() or tuple(weight_scale.shape) != (N,) or weight_scale.dtype != torch.float32
+               or not weight_scale.is_contiguous() or not weight_scale.is_cuda):
+        raise KlmOpsError("mid_linear: fp8 weights must be contiguous (tiled) with a contiguous fp32 scale [N] on the GPU")
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or weight.stride(1) != 1 or weight.stride(0) < K or not mid_ok(M, N, K):
         raise KlmOpsError(f"mid_linear: x {tuple(x.shape)} weight {tuple(weight.shape)}")
     if residual is not None and (tuple(residual.shape) != (M, N) or not residual.is_contiguous() or residual.dtype != x.dtype):
@@ -278,8 +288,13 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residu
     ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
     part = torch.empty((ks, M, N), dtype=torch.float32, device=x.device)
     st = _stream(x)
-    _check(_lib().klm_mid_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), part.data_ptr(), M, N, K,
-                                 ks, nw, rt, st), f"klm_mid_linear(M={M},N={N},K={K},ks={ks},nw={nw},rt={rt})")
+    if w8:
+        rc = _lib().klm_mid_linear_w8(x.data_ptr(), x.stride(0), weight.data_ptr(), weight_scale.data_ptr(), part.data_ptr(),
+                                      M, N, K, ks, nw, rt, st)
+    else:
+        rc = _lib().klm_mid_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), part.data_ptr(), M, N, K,
+                                   ks, nw, rt, st)
+    _check(rc, f"klm_mid_linear(M={M},N={N},K={K},ks={ks},nw={nw},rt={rt},fp8={w8})")
     _check(_lib().klm_mid_epilogue(part.data_ptr(), ks, M, N, k, out.data_ptr(),
                                    residual.data_ptr() if residual is not None else None, float(eps), st),
            f"klm_mid_epilogue(M={M},N={N},{kind})")

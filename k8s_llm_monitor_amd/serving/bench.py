@@ -46,10 +46,7 @@ def decode_step_ms(eng: Engine, batch: int, ctx: int, iters: int = 20, warmup: i
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     c, lc, world = eng.mcfg, eng.lcfg, eng.tp.world        # figures are per rank: this GPU's bytes and FLOPs
-    if eng.model.skinny(b):
-        weight_bytes = eng.model.decode_stream_bytes()
-    else:
-        weight_bytes = eng.model.weight_bytes() - c.vocab * c.hidden * 2      # the embedding is only gathered
+    weight_bytes = eng.model.decode_stream_bytes(b)
     kv_bytes = batch * ctx * lc.kv_bytes_per_token() // (2 if eng.cfg.kv_cache_dtype == "fp8" else 1)
     return {"batch": batch, "bucket": b, "ctx": ctx, "ms": ms, "tokens_per_s": batch / ms * 1e3,
             "bytes": weight_bytes + kv_bytes, "TBps": (weight_bytes + kv_bytes) / ms / 1e9,

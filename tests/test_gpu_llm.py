@@ -372,3 +372,20 @@ def test_mid_linear_reads_strided_operands_and_rejects_bad_shapes():
         llm.mid_linear(_rand(129, 1024), w)
     with pytest.raises(llm.KlmOpsError):
         llm.mid_linear(_rand(8, 1000), _rand(512, 1000))
+
+
+@pytest.mark.parametrize("M", [20, 64, 128])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (28672, 4096)])
+def test_mid_linear_with_fp8_tiled_weights_matches_the_dequantised_reference(M, N, K):
+    torch.manual_seed(41)
+    x, w = _rand(M, K), _rand(N, K, scale=0.03)
+    w8, sc = llm.quantize_fp8_rows(w)
+    wd = llm.dequantize_fp8_rows(w8, sc, torch.bfloat16)
+    want = x.float() @ (w8.float() * sc[:, None]).t()       # the kernel multiplies the e4m3 value by the fp32 scale: no bf16 rounding
+    w8t = llm.tile_weights(w8)
+    _close(llm.mid_linear(x, w8t, weight_scale=sc), want, 5e-2, 2e-2)
+    _close(llm.mid_linear(x, w8t, weight_scale=sc, kind="swiglu"), ref.silu_mul(want), 5e-2, 2e-2)
+    # the bf16 kernel on the dequantised (bf16-rounded) weights: the same sums up to that rounding
+    _close(llm.mid_linear(x, w8t, weight_scale=sc), llm.mid_linear(x, wd), 5e-2, 1e-2)
+    with pytest.raises(llm.KlmOpsError):
+        llm.mid_linear(x, w8t)                          # fp8 without scales

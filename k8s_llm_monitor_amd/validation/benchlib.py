@@ -164,8 +164,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             # the same decode with W8A16 weight copies (labelled: not the bf16 figure above)
             eng.model.enable_fp8_decode()
             eng._graphs.clear()
-            eng.warmup([1, 16])
-            d8 = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16)]
+            eng.warmup([1, 16, 64])
+            d8 = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64)]
             extras["llm_serving"]["decode_fp8_weights"] = [
                 {"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3), "tokens_per_s": round(r["tokens_per_s"], 1),
                  "TBps": round(r["TBps"], 2)} for r in d8]

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void mid_epilogue_kernel(const float* __restri
     if (KIND == MID_SWIGLU) {
       float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
       const float* p = part + row * N + j * 16;
+#pragma unroll 4
       for (int k = 0; k < ks; ++k) {
         add8(g, p + k * split);
         add8(u, p + k * split + 8);
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(256) void mid_epilogue_kernel(const float* __restri
     } else {
       float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       const float* p = part + row * N + j * 8;
+#pragma unroll 4
       for (int k = 0; k < ks; ++k) add8(v, p + k * split);
       *reinterpret_cast<uint4*>(out + row * N + j * 8) = pack8(v);
     }
@@ -262,7 +264,8 @@ __global__ __launch_bounds__(256) void mid_res_rms_kernel(const float* __restric
       unpack8(*reinterpret_cast<const uint4*>(res + base + e), rv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
-      for (int k = 0; k < ks; ++k) add8(v[c], part + k * split + base + e);
+#pragma unroll 4
+      for (int k = 0; k < ks; ++k) add8(v[c], part + k * split + base + e);      // independent loads: several splits in flight
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[c][j] = bf2f(f2bf(v[c][j] + rv[j]));
       *reinterpret_cast<uint4*>(res + base + e) = pack8(v[c]);

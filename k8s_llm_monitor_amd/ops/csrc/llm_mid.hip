@@ -343,6 +343,7 @@ int klm_mid_linear_plan(int M, int N, int K, int* ksplit, int* waves, int* row_t
   if (rt != 1 && rt != 2) {
     rt = N % (nw * 32) == 0 ? 2 : 1;
     if (rt == 2 && nw == 7 && M <= 32 && N / (nw * 16) <= 256) rt = 1;
+    if (rt == 2 && (long long)N * K <= (1LL << 24)) rt = 1;    // small matrices (8B wo): the same 256 blocks with half the K splits
   }
   if (N % (nw * rt * 16) != 0) rt = 1;
   if (N % (nw * rt * 16) != 0) return KLM_ERR_SHAPE;

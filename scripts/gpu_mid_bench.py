@@ -27,6 +27,7 @@ SETS = {"8b": [("qkv", 6144, 4096), ("wo", 4096, 4096), ("gate_up", 28672, 4096)
 Ms = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [32, 64, 128]
 shapes = SETS[sys.argv[2] if len(sys.argv) > 2 else "8b"]
 full = len(sys.argv) > 3 and sys.argv[3] == "sweep"
+fp8 = len(sys.argv) > 4 and sys.argv[4] == "fp8"       # e4m3 tiled weight copies (half the bytes; TB/s counts fp8 bytes)
 for M in Ms:
     for name, N, K in shapes:
         ncopy = max(2, int(1.5e9 // (N * K * 2)))
@@ -34,7 +35,11 @@ for M in Ms:
         x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         i = [0]
-        gb = N * K * 2 / 1e9
+        gb = N * K * (1 if fp8 else 2) / 1e9
+        if fp8:
+            q = [llm.quantize_fp8_rows(w) for w in ws]
+            w8 = [(llm.tile_weights(a), sc) for a, sc in q]
+            del q
         line = f"M={M:3d} {name:8s}"
         best = None
         cfgs = [(0, 0, 0)]
@@ -43,7 +48,10 @@ for M in Ms:
         for ks, nw, rt in cfgs:
             def ours():
                 i[0] = (i[0] + 1) % ncopy
-                llm.mid_linear(x, ws[i[0]], out=out, ksplit=ks, waves=nw, row_tiles=rt)
+                if fp8:
+                    llm.mid_linear(x, w8[i[0]][0], weight_scale=w8[i[0]][1], out=out, ksplit=ks, waves=nw, row_tiles=rt)
+                else:
+                    llm.mid_linear(x, ws[i[0]], out=out, ksplit=ks, waves=nw, row_tiles=rt)
             a = t(ours)
             if (ks, nw, rt) == (0, 0, 0):
                 line += f" | default{llm.mid_plan(M, N, K)} {a:6.1f}us {gb / a * 1e3:4.2f}"

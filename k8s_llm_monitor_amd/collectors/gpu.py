@@ -94,6 +94,24 @@ class GpuNormalizer:
             umc_avg = share(counter_delta(_int(prev.get("mem_activity_acc")), _int(raw.get("mem_activity_acc")), ACT_ACC_BITS), dacc, 1.0)
             for k in RESIDENCY_KEYS:
                 residency[k] = share(counter_delta(_int(prev.get(f"res_{k}_acc")), _int(raw.get(f"res_{k}_acc"))), dacc, 100.0)
+        # per-XCD busy share over the period (same tick base as the whole-GPU accumulator)
+        xcd_inst = raw.get("xcd_busy_inst") if isinstance(raw.get("xcd_busy_inst"), list) else None
+        xcd_avg: Optional[List[Optional[float]]] = None
+        xa, xb = (prev or {}).get("xcd_busy_acc"), raw.get("xcd_busy_acc")
+        if prev is not None and isinstance(xa, list) and isinstance(xb, list) and len(xa) == len(xb) and dacc:
+            xcd_avg = []
+            for a0, a1 in zip(xa, xb):
+                v = share(counter_delta(_int(a0), _int(a1)), dacc, 1.0)
+                xcd_avg.append(None if v is None else min(100.0, max(0.0, v)))
+        # PCIe link health: cumulative error counters and what they gained since the last reading
+        pcie_err = {}
+        for key, name in (("pcie_replay_acc", "replay"), ("pcie_l0_recovery_acc", "l0Recovery"),
+                          ("pcie_nak_sent_acc", "nakSent"), ("pcie_nak_rcvd_acc", "nakReceived")):
+            cur = _int(raw.get(key))
+            if cur is None:
+                continue
+            before = _int((prev or {}).get(key))
+            pcie_err[name] = {"count": cur, "delta": None if before is None else counter_delta(before, cur)}
         if gfx_avg is not None:
             gfx_avg = min(100.0, max(0.0, gfx_avg))
         if umc_avg is not None:
@@ -179,7 +197,14 @@ class GpuNormalizer:
                      "txGBps": tx_total if any_rate else None,
                      "linkWidth": _int(raw.get("xgmi_link_width")),
                      "linkSpeedGbps": _int(raw.get("xgmi_link_speed"))},
-            "pcieGBps": _num(raw.get("pcie_bandwidth_inst")),
+            # amdsmi's pcie_bandwidth_inst is megabits per second (amd-smi prints it as Mb/s; 700 under launch traffic)
+            "pcieGBps": None if _num(raw.get("pcie_bandwidth_inst")) is None else _num(raw.get("pcie_bandwidth_inst")) / 8000.0,
+            "pcie": {"GBps": None if _num(raw.get("pcie_bandwidth_inst")) is None else _num(raw.get("pcie_bandwidth_inst")) / 8000.0,
+                     "linkSpeedGTs": (_num(raw.get("pcie_link_speed")) or 0) / 10.0 or None,
+                     "linkWidth": _int(raw.get("pcie_link_width")),
+                     "errors": pcie_err},
+            "xcdActivity": xcd_inst,
+            "xcdActivityAvg": xcd_avg,
             "processes": raw.get("processes"),
             "processList": raw.get("process_list"),
             "peak": raw.get("peak"),
@@ -336,8 +361,32 @@ def metrics_to_raw(m: Dict[str, Any]) -> Dict[str, Any]:
         "xgmi_link_width": g("xgmi_link_width"),
         "xgmi_link_speed": g("xgmi_link_speed"),
         "pcie_bandwidth_inst": g("pcie_bandwidth_inst"),
+        "pcie_bandwidth_acc": g("pcie_bandwidth_acc"),
+        "pcie_link_speed": g("pcie_link_speed"),               # 0.1 GT/s
+        "pcie_link_width": g("pcie_link_width"),
+        "pcie_replay_acc": g("pcie_replay_count_acc"),
+        "pcie_replay_rollover_acc": g("pcie_replay_rover_count_acc"),
+        "pcie_l0_recovery_acc": g("pcie_l0_to_recov_count_acc"),
+        "pcie_nak_sent_acc": g("pcie_nak_sent_count_acc"),
+        "pcie_nak_rcvd_acc": g("pcie_nak_rcvd_count_acc"),
+        # per-XCD busy accumulators: one row per compute partition (one row of 8 in SPX mode, 8 rows of 1 in CPX)
+        "xcd_busy_acc": _flatten_ints(g("xcp_stats.gfx_busy_acc")),
+        "xcd_busy_inst": _flatten_ints(g("xcp_stats.gfx_busy_inst")),
     }
     return {k: v for k, v in raw.items() if v is not None and v != "N/A"}
+
+
+def _flatten_ints(rows: Any) -> Optional[List[int]]:
+    """amdsmi's per-partition tables ([[...8...], ["N/A", ...], ...]) -> the populated entries in order."""
+    if not isinstance(rows, (list, tuple)):
+        return None
+    out: List[int] = []
+    for row in rows:
+        for v in (row if isinstance(row, (list, tuple)) else [row]):
+            if isinstance(v, bool) or not isinstance(v, (int, float)):
+                continue
+            out.append(int(v))
+    return out or None
 
 
 class NativeSamplerReader(GpuReader):

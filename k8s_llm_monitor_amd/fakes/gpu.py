@@ -38,6 +38,8 @@ class GpuState:
     link_up: List[bool] = field(default_factory=lambda: [True] * 7)
     xgmi_gbps: float = 0.0       # per link, each direction
     present: bool = True
+    xcd_idle: bool = False       # XCD (index % 8) of this GPU does no work (a kernel whose grid leaves a die out)
+    pcie_replays: int = 0        # cumulative PCIe replay count
 
 
 Scenario = Callable[[float, int], GpuState]
@@ -104,6 +106,16 @@ def _power(t: float, i: int) -> GpuState:
     return s
 
 
+def _pcie(t: float, i: int) -> GpuState:
+    """GPU 2 sits on a marginal PCIe link (replays accumulate); GPU 5 runs a kernel that leaves one XCD idle."""
+    s = _steady(t, i)
+    if i == 2:
+        s.pcie_replays = int(t // 4) * 3
+    if i == 5:
+        s.xcd_idle = True
+    return s
+
+
 def _gone(t: float, i: int) -> GpuState:
     s = _steady(t, i)
     if i == 7 and t >= 10:
@@ -114,7 +126,7 @@ def _gone(t: float, i: int) -> GpuState:
 SCENARIOS: Dict[str, Scenario] = {
     "": _steady, "steady": _steady, "idle": _idle, "hbm_ramp": _hbm_ramp, "thermal": _thermal,
     "ecc": _ecc, "xgmi_down": _xgmi_down, "allreduce": _allreduce, "power": _power,
-    "gpu_lost": _gone,
+    "gpu_lost": _gone, "pcie": _pcie,
 }
 
 
@@ -136,7 +148,7 @@ class FakeGpuReader:
         self._last_t: Optional[float] = None
         # cumulative firmware counters per GPU
         self._acc = [dict(acc=0.0, gfx=0.0, mem=0.0, energy=0.0, ppt=0.0, thm=0.0,
-                          rd=[0.0] * 8, wr=[0.0] * 8) for _ in range(n_gpus)]
+                          rd=[0.0] * 8, wr=[0.0] * 8, xcd=[0.0] * 8) for _ in range(n_gpus)]
 
     def describe(self) -> str:
         return f"fake({self.n}x MI355X, scenario={self.scenario_name})"
@@ -165,6 +177,8 @@ class FakeGpuReader:
             a["acc"] += ticks
             a["gfx"] += s.gfx * ticks
             a["mem"] += s.umc * ticks
+            for x in range(8):                       # XCDs share the load evenly; XCD x of GPU x idles in `xcd_idle`
+                a["xcd"][x] += (0.0 if (s.xcd_idle and x == i % 8) else s.gfx) * ticks
             a["ppt"] += s.ppt_throttle * ticks
             a["thm"] += s.thm_throttle * ticks
             a["energy"] += s.power_w * dt / (ENERGY_RES_UJ * 1e-6)
@@ -188,6 +202,10 @@ class FakeGpuReader:
                 "gfx_activity": round(s.gfx), "umc_activity": round(s.umc),
                 "gfx_activity_acc": int(a["gfx"]) & 0xFFFFFFFF, "mem_activity_acc": int(a["mem"]) & 0xFFFFFFFF,
                 "accumulation_counter": int(a["acc"]),
+                "xcd_busy_acc": [int(v) for v in a["xcd"]], "xcd_busy_inst": [round(s.gfx)] * 8,
+                "pcie_bandwidth_inst": 18, "pcie_link_speed": 320, "pcie_link_width": 16,
+                "pcie_replay_acc": int(s.pcie_replays), "pcie_l0_recovery_acc": 0,
+                "pcie_nak_sent_acc": 0, "pcie_nak_rcvd_acc": 0,
                 "power_w": round(s.power_w), "power_cap_w": POWER_CAP_W,
                 "energy_acc": int(a["energy"]), "energy_resolution_uj": ENERGY_RES_UJ,
                 "temp_hotspot": round(s.temp), "temp_mem": round(s.temp_mem),

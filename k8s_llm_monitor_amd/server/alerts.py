@@ -107,6 +107,7 @@ _MSG = {
         "ecc_ue": ("GPU{g} 出现不可纠正 ECC 错误", "不可纠正 ECC 错误 {n} 个", "建议：1. 迁移该卡上的负载 2. amd-smi bad-pages / RAS 检查 3. 联系硬件更换"),
         "ecc_ce": ("GPU{g} 可纠正 ECC 错误增加", "可纠正 ECC 错误累计 {n} 个 (新增 {d})", "建议：持续观察，增长过快时安排检修"),
         "xgmi": ("GPU{g} xGMI 链路断开", "链路 {l} 状态 down{peer}", "建议：1. amd-smi xgmi 检查链路 2. RCCL 集合通信将绕行或失败，尽快隔离该节点"),
+        "pcie": ("GPU{g} PCIe 链路出现重传", "PCIe replay 新增 {d} 次 (累计 {n})，L0 恢复 {r} 次", "建议：1. 检查 PCIe 插槽 / 线缆 / riser 2. lspci -vv 查看链路速率是否降级 3. 持续增长时安排检修"),
         "throttle_thm": ("GPU{g} 温度降频中", "降频原因: {r}", "建议：检查散热，降低负载；性能数据在降频期间不可信"),
         "throttle_ppt": ("GPU{g} 功耗受限降频", "功耗限制驻留 {p}%", "建议：满载时属正常；若影响吞吐可调整 power cap 或错峰"),
         "vllm_down": ("vLLM 服务不可达", "{n}/{m} 个 vLLM 端点有响应", "建议：1. kubectl get pods 查看推理 Pod 2. 查看 Pod 日志 (OOM / HIP 错误) 3. 检查 /metrics 端口与网络策略"),
@@ -160,6 +161,7 @@ _MSG["en"] = {
     "ecc_ue": ("GPU{g} uncorrectable ECC errors", "{n} uncorrectable ECC error(s)", "Drain the GPU; check amd-smi bad-pages / RAS; schedule replacement"),
     "ecc_ce": ("GPU{g} correctable ECC errors rising", "{n} correctable ECC errors so far (+{d})", "Keep watching; service the GPU if the rate grows"),
     "xgmi": ("GPU{g} xGMI link down", "link {l} is down{peer}", "Check amd-smi xgmi; RCCL collectives will reroute or fail; isolate the node"),
+    "pcie": ("GPU{g} PCIe link replays", "{d} new PCIe replay(s) ({n} so far), {r} L0 recoveries", "Check the slot / cable / riser; lspci -vv for a downgraded link; service the node if the count keeps growing"),
     "throttle_thm": ("GPU{g} thermal throttling", "reasons: {r}", "Check cooling, reduce load; performance numbers are unreliable while throttled"),
     "throttle_ppt": ("GPU{g} power-limited", "power-limit residency {p}%", "Normal at full load; raise the cap or spread load if throughput matters"),
     "vllm_down": ("vLLM endpoint unreachable", "{n} of {m} vLLM endpoint(s) answering", "kubectl get pods for the serving pods; read their logs (OOM / HIP errors); check the /metrics port and network policy"),
@@ -271,6 +273,12 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
                     peer = f" -> {link['peer']}" if link.get("peer") else ""
                     _add(alerts, th.xgmi_link_down_tier, f"{k}/xgmi/{link.get('link')}", t.format(g=g),
                          d.format(l=link.get("link"), peer=peer), f, signal="xgmi")
+        perr = (gpu.get("pcie") or {}).get("errors") or {}
+        rep = perr.get("replay") or {}
+        if isinstance(rep.get("delta"), int) and rep["delta"] > 0:
+            t, d, f = msgs["pcie"]
+            _add(alerts, "minor", f"{k}/pcie", t.format(g=g),
+                 d.format(d=rep["delta"], n=rep.get("count"), r=(perr.get("l0Recovery") or {}).get("count", 0)), f, edge=True, signal="pcie")
         thr = gpu.get("throttle") or {}
         res = thr.get("residencyPercent") or {}
         thermal = [r for r in THERMAL_REASONS if (res.get(r) or 0) > 0]

@@ -70,6 +70,15 @@ def render(snapshot: Mapping[str, Any], stats: Mapping[str, Any]) -> str:
         d.add("klm_gpu_ecc_correctable_total", "Correctable ECC errors.", "counter", ecc.get("correctable"), L)
         d.add("klm_gpu_ecc_uncorrectable_total", "Uncorrectable ECC errors.", "counter", ecc.get("uncorrectable"), L)
         d.add("klm_gpu_throttled", "1 while any throttle reason is active.", "gauge", 1.0 if (g.get("throttle") or {}).get("active") else 0.0, L)
+        for x, v in enumerate(g.get("xcdActivityAvg") or g.get("xcdActivity") or []):
+            d.add("klm_gpu_xcd_activity_percent", "GFX busy share of one XCD (compute die), mean over the last sample period.",
+                  "gauge", v, dict(L, xcd=x))
+        pcie = g.get("pcie") or {}
+        d.add("klm_gpu_pcie_link_speed_gts", "Current PCIe link speed.", "gauge", pcie.get("linkSpeedGTs"), L)
+        d.add("klm_gpu_pcie_link_width", "Current PCIe link width (lanes).", "gauge", pcie.get("linkWidth"), L)
+        for name, metric in (("replay", "klm_gpu_pcie_replay_total"), ("l0Recovery", "klm_gpu_pcie_l0_recovery_total"),
+                             ("nakSent", "klm_gpu_pcie_nak_sent_total"), ("nakReceived", "klm_gpu_pcie_nak_received_total")):
+            d.add(metric, f"PCIe {name} events.", "counter", ((pcie.get("errors") or {}).get(name) or {}).get("count"), L)
         for link in (g.get("xgmi") or {}).get("links") or []:
             LL = dict(L, link=link.get("link"))
             d.add("klm_gpu_xgmi_rx_bytes_total", "xGMI bytes received on the link.", "counter", link.get("rxBytes"), LL)

@@ -78,6 +78,10 @@ def test_burner_duty_is_what_was_asked_and_telemetry_sees_it(torch_dev):
         assert abs(out["duty_achieved"] - 50.0) < 6.0 and out["tflops_busy"] > 300
         assert abs(g["gfxActivityAvg"] - out["duty_achieved"]) < 10.0          # loose here; `validate` measures it
         assert g["powerW"] > 300
+        # per-XCD accumulators: the GEMM grid covers all 8 dies, each reads what the whole GPU reads
+        assert len(g["xcdActivityAvg"]) == 8 and all(abs(v - g["gfxActivityAvg"]) < 3.0 for v in g["xcdActivityAvg"]), g["xcdActivityAvg"]
+        assert g["pcie"]["linkWidth"] == 16 and g["pcie"]["linkSpeedGTs"] >= 16.0 and g["pcie"]["errors"]["replay"]["delta"] == 0
+        assert g["pcie"]["GBps"] < 64.0                                          # Mb/s converted, not GB/s taken at face value
     finally:
         src.close()
 

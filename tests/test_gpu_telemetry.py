@@ -118,3 +118,49 @@ def test_xgmi_down_and_gpu_lost(clock):
 def test_unknown_scenario():
     with pytest.raises(ValueError):
         FakeGpuReader(1, "nope")
+
+
+# ------------------------------------------------------------------ per-XCD activity and PCIe health
+def test_xcd_activity_and_pcie_errors_from_accumulators():
+    from k8s_llm_monitor_amd.collectors.gpu import GpuNormalizer, metrics_to_raw
+    m0 = {"accumulation_counter": 1000, "gfx_activity_acc": 50000,
+          "xcp_stats.gfx_busy_acc": [[100, 200, 300, 400, 500, 600, 700, 800]] + [["N/A"] * 8] * 7,
+          "xcp_stats.gfx_busy_inst": [[10, 20, 30, 40, 50, 60, 70, 0]] + [["N/A"] * 8] * 7,
+          "pcie_replay_count_acc": 4, "pcie_l0_to_recov_count_acc": 1, "pcie_nak_sent_count_acc": 0, "pcie_nak_rcvd_count_acc": 0,
+          "pcie_bandwidth_inst": 800, "pcie_link_speed": 320, "pcie_link_width": 16}
+    r0 = metrics_to_raw(m0)
+    assert r0["xcd_busy_acc"] == [100, 200, 300, 400, 500, 600, 700, 800] and r0["xcd_busy_inst"][-1] == 0
+    m1 = dict(m0, accumulation_counter=2000, gfx_activity_acc=100000, pcie_replay_count_acc=9)
+    m1["xcp_stats.gfx_busy_acc"] = [[100 + 1000 * p for p in (100, 100, 100, 100, 50, 50, 0, 25)][i] + 100 * i for i in range(8)]
+    m1["xcp_stats.gfx_busy_acc"] = [m1["xcp_stats.gfx_busy_acc"]] + [["N/A"] * 8] * 7
+    n = GpuNormalizer()
+    g0 = n.normalize(dict(r0, index=0, t=0.0, vram_total_mib=1000, vram_used_mib=10))
+    assert g0["xcdActivityAvg"] is None and g0["xcdActivity"][:2] == [10, 20]
+    assert g0["pcie"]["errors"]["replay"] == {"count": 4, "delta": None}
+    g1 = n.normalize(dict(metrics_to_raw(m1), index=0, t=1.0, vram_total_mib=1000, vram_used_mib=10))
+    assert g1["xcdActivityAvg"] == [100.0, 100.0, 100.0, 100.0, 50.0, 50.0, 0.0, 25.0]
+    assert g1["pcie"]["errors"]["replay"] == {"count": 9, "delta": 5} and g1["pcie"]["errors"]["l0Recovery"]["delta"] == 0
+    assert g1["pcie"]["linkSpeedGTs"] == 32.0 and g1["pcie"]["linkWidth"] == 16 and g1["pcie"]["GBps"] == pytest.approx(0.1)
+    # CPX mode: eight partitions of one XCD each flatten to the same eight entries
+    cpx = metrics_to_raw({"xcp_stats.gfx_busy_acc": [[7] + ["N/A"] * 7 for _ in range(8)]})
+    assert cpx["xcd_busy_acc"] == [7] * 8
+
+
+def test_fake_pcie_scenario_raises_the_replay_alert_and_shows_the_idle_xcd():
+    from k8s_llm_monitor_amd.collectors.gpu import GpuSource
+    from k8s_llm_monitor_amd.fakes.gpu import FakeGpuReader
+    from k8s_llm_monitor_amd.server.alerts import AlertState, check_alerts
+    clock = {"t": 0.0}
+    src = GpuSource(FakeGpuReader(n_gpus=8, scenario="pcie", clock=lambda: clock["t"]))
+    src.sample()
+    st = AlertState()
+    seen = []
+    for step in range(4):
+        clock["t"] += 5.0
+        gpus = src.sample()
+        alerts, st = check_alerts({"cpu": {"usage": 1}, "memory": {"percent": 1}, "disk": {"percent": 1}}, gpus, [], state=st)
+        seen.append([a["key"] for tier in ("minor", "serious", "critical") for a in alerts[tier] if a.get("key", "").endswith("/pcie")])
+    assert any(k == ["gpu/2/pcie"] for k in seen), seen
+    g5 = [g for g in gpus if g["index"] == 5][0]
+    assert g5["xcdActivityAvg"][5] == 0.0 and min(v for i, v in enumerate(g5["xcdActivityAvg"]) if i != 5) > 10.0
+    assert "XCD" in open(os.path.join(ROOT, "k8s_llm_monitor_amd", "web", "monitor.html"), encoding="utf-8").read()

@@ -407,6 +407,7 @@ def llm_activity(torch, dev, src, smi_idx: int, seconds: float = 2.5, model: str
         s = _gpu_sample(src, smi_idx)
         rows.append(dict(detail, regime=name, launches=n, ms_per_launch=dt / n * 1e3,
                          gfx_activity_avg=s.get("gfxActivityAvg"), mem_activity_avg=s.get("memActivityAvg"),
+                         xcd_activity_avg=[None if v is None else round(v, 1) for v in (s.get("xcdActivityAvg") or [])],
                          power_w=s.get("powerW"), clock_gfx_mhz=s.get("clockGfxMHz")))
 
     try:

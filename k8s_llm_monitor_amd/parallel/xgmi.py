@@ -184,6 +184,7 @@ class XgmiComm:
     def check(self) -> None:
         st = self.status()
         if st:
+            self._status.zero_()           # reported once: the protocol itself is in step again when the peer arrives
             raise XgmiError(f"a peer did not reach barrier stage(s) {st:#x} within the spin limit: results since then are invalid")
 
     def close(self) -> None:

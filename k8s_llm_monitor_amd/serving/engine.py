@@ -131,6 +131,7 @@ class Engine:
         self.tp = self.model.tp
         self.lcfg: LlamaConfig = self.model.lcfg          # this rank's shapes (== mcfg without tensor parallelism)
         self._inbox: List[Request] = []                   # tensor parallel: submitted at rank 0, not yet seen by the others
+        self._tp_reset = False                            # rank 0: tell the other ranks to drop their requests (after a failure)
         if self.cfg.decode_weights == "fp8" and not self.model.fp8_decode:
             self.model.enable_fp8_decode()
         elif self.cfg.decode_weights not in ("bf16", "fp8"):
@@ -236,11 +237,16 @@ class Engine:
         if self.tp.rank == 0:
             with self._lock:
                 new, self._inbox = self._inbox, []
-            msg = self.tp.broadcast_object((bool(stop), [(r.rid, r.prompt, r.max_tokens) for r in new]))
+            reset, self._tp_reset = self._tp_reset, False
+            msg = self.tp.broadcast_object((bool(stop), reset, [(r.rid, r.prompt, r.max_tokens) for r in new]))
             with self._lock:
                 self.waiting.extend(new)
             return msg[0]
-        stop, new = self.tp.broadcast_object(None)
+        stop, reset, new = self.tp.broadcast_object(None)
+        if reset:
+            # rank 0 failed a step (or saw a peer miss a collective) and dropped its requests: drop ours too, or the
+            # ranks would schedule different batches from here on
+            self._fail_all("reset by rank 0")
         now = self.clock()
         with self._lock:
             for rid, prompt, max_tokens in new:
@@ -481,10 +487,13 @@ class Engine:
                 break
             try:
                 n = self.step()
+                if self.tp.world > 1 and n:
+                    self.tp.check()     # a peer that missed a collective left this step's results invalid
             except Exception as e:      # a failed launch (out of memory, bad shape) must not strand the callers
                 self.last_error = f"{type(e).__name__}: {e}"
                 self.errors += 1
                 self._fail_all(self.last_error)
+                self._tp_reset = True   # tensor parallel: the next control message tells every rank to start clean
                 n = 0
             if n == 0 and self.tp.world == 1:
                 self._wake.wait(0.05)

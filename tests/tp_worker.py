@@ -95,15 +95,27 @@ def engine_check(cfg, dev, dtype, tp, out, use_graphs):
         if tp.rank == 0:
             out.update(graph_equals_eager=[r.out for r in reqs2] == got and steps2 == steps)
     # the background loop: rank 0 serves from a thread, the others follow until it stops
+    # ... and a launch that fails (on every rank: a bad shape would) costs the requests in flight, not the lock-step
+    real_prefill, state = eng.model.prefill, {"failed": False}
+
+    def failing_once(*a, **kw):
+        if not state["failed"]:
+            state["failed"] = True
+            raise RuntimeError("injected launch failure")
+        return real_prefill(*a, **kw)
+    eng.model.prefill = failing_once
     if tp.rank == 0:
         eng.start()
+        bad = eng.submit(prompts[2], 3)
+        bad.done.wait(120)
         r = eng.submit(prompts[0], 4)
         ok = r.done.wait(120)
         eng.stop()
-        out.update(loop_ok=bool(ok) and r.out == want[0][:4])
+        out.update(loop_ok=bool(ok) and r.out == want[0][:4], failed_request_error=bad.error, engine_errors=eng.errors)
     else:
         eng.follow()
-        out.update(loop_ok=True)
+        out.update(loop_ok=True, engine_errors=eng.errors)
+    eng.model.prefill = real_prefill
 
 
 def main() -> int:

@@ -307,7 +307,11 @@ class LlamaModel:
         (scripts/gpu_mid_bench.py)."""
         if self.mid_limit is not None:
             return self.mid_limit
-        return llm.MID_MAX_ROWS if (self.cfg.hidden <= 4096 or self.fp8_decode) else 64
+        if self.cfg.hidden <= 4096 or self.fp8_decode:
+            return llm.MID_MAX_ROWS
+        # bf16 weights of wider models: ahead of the library on the 70B shapes up to 64 rows; behind it on the shapes
+        # of a 405B / tp8 shard (37.3 vs 34.7 ms per step at 64 rows), whose projections are narrow and very deep
+        return 64 if self.cfg.hidden <= 8192 else 0
 
     def mid(self, rows: int) -> bool:
         c = self.lcfg
@@ -325,13 +329,17 @@ class LlamaModel:
         return self._stack(tokens, positions, slots, cache, attend)
 
     def skinny_rows(self) -> int:
-        """Largest batch that decodes on the weight-streaming kernel. Measured per layer on MI355X
-        (scripts/gpu_skinny_tp_bench.py): with 4096-wide rows it beats hipBLASLt + separate norm / SwiGLU kernels up
-        to its 16 rows; with rows of 8192 and more (70B, 405B shards) the library GEMMs win from 8 rows on (12 %
-        at 8, 25 % at 16). fp8 weight copies halve the bytes and keep the kernel ahead throughout."""
+        """Largest batch that decodes on the skinny kernel. Measured per model on MI355X (scripts/gpu_tp_shard_bench.py,
+        profiles/r1_tp/): with 4096-wide rows it wins up to its 16 rows. With rows of 8192 and more (70B, 405B shards)
+        its x fragments (M x K x 2 bytes per 16-row block, from L2) grow with K: on bf16 weights the library GEMMs win
+        from 8 rows on (12 % at 8, 25 % at 16); on fp8 weights the mid-batch kernel takes over, from 5 rows for the
+        70B shapes (16.9 vs 20.2 ms per step at 16) and from 9 for a 405B / tp8 shard (17.5 vs 19.5 ms at 8 in favour
+        of this kernel, 24.7 vs 23.0 at 16 against it)."""
         if self.skinny_limit is not None:
             return self.skinny_limit
-        return llm.SKINNY_MAX_ROWS if (self.cfg.hidden <= 4096 or self.fp8_decode) else 4
+        if self.cfg.hidden <= 4096:
+            return llm.SKINNY_MAX_ROWS
+        return 8 if (self.fp8_decode and self.cfg.hidden > 8192) else 4
 
     def skinny(self, batch: int) -> bool:
         c = self.lcfg

@@ -49,6 +49,8 @@ def main() -> int:
     global CASES
     if len(sys.argv) > 4 and sys.argv[4] == "small-batch":
         CASES = ((1, 0), (1, 16), (2, 0), (2, 16), (4, 0), (4, 16))
+    elif len(sys.argv) > 4 and sys.argv[4].startswith("batches="):
+        CASES = tuple((int(b), None) for b in sys.argv[4][8:].split(","))
     name = sys.argv[1] if len(sys.argv) > 1 else "llama3-405b"
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     tag = f"{name}_tp{world}"
@@ -61,14 +63,15 @@ def main() -> int:
     if weights == "fp8":
         model.enable_fp8_decode()
     print(f"shard of {name} / tp{world}: {model.weight_bytes() / 1e9:.1f} GB in {time.time() - t0:.1f} s", flush=True)
-    eng = Engine(EngineConfig(model=name, device="cuda:0", max_num_seqs=64, max_model_len=4096, kv_blocks=20000), model=model)
+    eng = Engine(EngineConfig(model=name, device="cuda:0", max_num_seqs=128, max_model_len=4096,
+                              kv_blocks=int(os.environ.get("KLM_KV_BLOCKS", "20000"))), model=model)
     rows = []
     for b, lim in CASES:
         if lim != model.skinny_limit:
             model.skinny_limit = lim          # batch 8 / 16 on either path: library GEMMs (4) or the skinny kernel (16)
             eng._graphs.clear()
         r = sb.decode_step_ms(eng, b, 1024, iters=10)
-        r["path"] = "skinny" if model.skinny(b) else "library"
+        r["path"] = "skinny" if model.skinny(b) else ("mid" if model.mid(b) else "library")
         r["allreduce_launches_per_step"] = 2 * PRESETS[name].layers
         r["allreduce_bytes_each"] = eng.buckets[[x >= b for x in eng.buckets].index(True)] * PRESETS[name].hidden * 2
         rows.append(r)

@@ -12,7 +12,7 @@ from k8s_llm_monitor_amd.serving import bench as sb  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "llama3-8b"
 batches = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 16, 24, 32, 48, 64, 96, 128]
 rows = []
-for weights in ("bf16", "fp8"):
+for weights in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("bf16", "fp8")):
     eng = Engine(EngineConfig(model=name, max_num_seqs=128, max_model_len=4096, kv_blocks=20000, decode_weights=weights))
     for b in batches:
         r = sb.decode_step_ms(eng, b, 1024, iters=10)

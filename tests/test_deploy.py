@@ -67,3 +67,37 @@ def test_cmake_project_lists_every_native_source():
         assert t.name in text, t.name
         for s in t.sources:
             assert s.name in text, f"{s.name} missing from CMakeLists.txt"
+
+
+def test_grafana_dashboard_and_alert_rules_only_use_metrics_the_monitor_exports():
+    """deploy/grafana-dashboard.json and deploy/prometheus-alerts.yaml against a rendered /metrics of the fake node."""
+    import json
+    import re
+
+    import yaml
+
+    from k8s_llm_monitor_amd.collectors.gpu import GpuSource
+    from k8s_llm_monitor_amd.fakes.gpu import FakeGpuReader
+    from k8s_llm_monitor_amd.server.exporter import render
+    clock = {"t": 0.0}
+    src = GpuSource(FakeGpuReader(n_gpus=8, scenario="pcie", clock=lambda: clock["t"]))
+    src.sample()
+    clock["t"] = 5.0
+    snap = {"host": {"cpu": {"percent": "5.0", "load_1min": 0.4}, "memory": {"percent": "10.0"}, "disk": {"percent": "20"}},
+            "gpus": src.sample(), "pods": [{"status": "Running"}],
+            "vllm": {"available": True, "ttftP50": 0.02, "ttftP99": 0.1, "tokensPerSec": 1000.0, "kvCachePercent": 40.0, "running": 3, "waiting": 0},
+            "alerts": {"minor": [], "serious": [], "critical": []}}
+    text = render(snap, {"tasks": {"gpu": {"calls": 2, "errors": 0, "mean_ms": 1.0, "max_ms": 1.5, "duty_percent": 0.02}}, "uptime_s": 10})
+    exported = set(re.findall(r"^(klm_[a-z0-9_]+)", text, re.M))
+    assert {"klm_gpu_xcd_activity_percent", "klm_gpu_pcie_replay_total", "klm_gpu_hbm_used_bytes"} <= exported
+
+    dash = json.load(open(os.path.join(ROOT, "deploy", "grafana-dashboard.json")))
+    exprs = [t["expr"] for p in dash["panels"] for t in p["targets"]]
+    assert len(dash["panels"]) >= 12 and len({p["id"] for p in dash["panels"]}) == len(dash["panels"])
+    rules = yaml.safe_load(open(os.path.join(ROOT, "deploy", "prometheus-alerts.yaml")))["groups"][0]["rules"]
+    assert {r["labels"]["severity"] for r in rules} == {"minor", "serious", "critical"}
+    exprs += [r["expr"] for r in rules]
+    used = set(re.findall(r"klm_[a-z0-9_]+", " ".join(exprs)))
+    assert used and used <= exported, sorted(used - exported)
+    # the three HBM tiers are the reference's 70 / 85 / 95
+    assert [r["expr"].split(">")[-1].strip() for r in rules if r["alert"].startswith("GpuHbm") and "Hot" not in r["alert"]] == ["70", "85", "95"]

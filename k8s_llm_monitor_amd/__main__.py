@@ -292,7 +292,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--replica-base-port", type=int, default=0, help="first replica port (default: --port + 1)")
     p.add_argument("--ready-timeout", type=float, default=300.0)
     p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
-                   help="fp8: W8A16 weight copies for decode at batch <= 16 (half the bytes per token)")
+                   help="fp8: W8A16 weight copies for decode up to batch 128 (half the bytes per token; costs half the model size in HBM)")
     p.add_argument("--kv-cache-dtype", default="bf16", choices=["bf16", "fp8"],
                    help="fp8: e4m3 KV cache, twice the tokens per GB and half the attention bytes")
     p.add_argument("--load-rps", type=float, default=0.0, help="built-in open-loop load (requests per second)")

@@ -48,7 +48,7 @@ class EngineConfig:
     kv_fraction: float = 0.5
     use_graphs: bool = True
     kv_cache_dtype: str = "bf16"       # "fp8": e4m3 KV cache (half the bytes per token; prefill then uses the register kernel)
-    decode_weights: str = "bf16"       # "fp8": W8A16 copies for the batch <= 16 decode path (LlamaModel.enable_fp8_decode)
+    decode_weights: str = "bf16"       # "fp8": W8A16 copies for decode up to batch 128 (LlamaModel.enable_fp8_decode)
     seed: int = 0
 
 
@@ -548,7 +548,7 @@ class Engine:
                 "kv_blocks": self.alloc.total, "kv_capacity_tokens": self.kv_capacity_tokens,
                 "kv_bytes": self.cache.nbytes, "max_num_seqs": self.cfg.max_num_seqs, "max_model_len": self.max_len,
                 "graphs": sorted(self._graphs), "device": str(self.device),
-                "decode_weights": "fp8 (W8A16, batch <= 16)" if self.model.fp8_decode else "bf16",
+                "decode_weights": "fp8 (W8A16, batch <= 128)" if self.model.fp8_decode else "bf16",
                 "kv_cache_dtype": self.cfg.kv_cache_dtype,
                 "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts),
                 "tensor_parallel": self.tp.describe(), "errors": self.errors, "last_error": self.last_error}

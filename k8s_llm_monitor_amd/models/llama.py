@@ -9,12 +9,16 @@ telemetry check needs. No reference counterpart (vLLM is a README bullet, refere
 MI355X-first choices:
   * 288 GB of HBM3E: 8B (16 GB) and 70B (141 GB) both fit ONE GPU in bf16, so replicas scale as
     one process per GPU (data parallel serving) and no tensor-parallel all-reduce sits on the
-    token path; the KV cache gets the rest of the HBM.
+    token path; the KV cache gets the rest of the HBM. A model beyond that (llama3-405b) is sharded
+    over a tensor-parallel group (parallel/tp.py): the same code with local shapes and two all-reduces
+    per layer on the xGMI mesh kernels.
   * attention, RMSNorm(+residual), RoPE+cache write and SwiGLU are the kernels of ops/csrc/llm_*.hip.
-    At batch <= 16 (decode is then a pure weight-streaming problem) the projections run on the
-    skinny MFMA kernel with the norm, the residual add and SwiGLU fused into it: 4 weight passes
-    + rope + attention per layer. Larger batches and prefill use plain library GEMMs (hipBLASLt
-    through torch.matmul), fused where the operands allow it (one qkv GEMM, one gate_up GEMM).
+    Decode is a weight-streaming problem up to ~128 rows, and three paths cover it (`skinny`, `mid`,
+    `_trunk` pick by batch size, model width and weight format, all from measurements):
+    the skinny MFMA kernel (batch <= 16: norm, residual add and SwiGLU fused in, 4 weight passes + rope +
+    attention per layer), the mid-batch kernel (17 - 128 rows: x staged through LDS, split-K, epilogues that
+    fuse the residual add + RMSNorm and SwiGLU), and beyond that, as for prefill, plain library GEMMs
+    (hipBLASLt through torch.matmul), fused where the operands allow it (one qkv GEMM, one gate_up GEMM).
   * weight layout chosen for those kernels: RMSNorm gains are folded into the columns of the
     projection that consumes the norm, and gate/up rows are interleaved by 8 (ops.llm.interleave_gate_up).
   * decode is launch-bound at small batch (about 10 launches x layers), so the engine captures it

@@ -295,8 +295,9 @@ class LlamaModel:
         # 128 rows of the 8B gate_up): x staging per 224-row block then rivals the weight stream
         wide_lib = tokens.shape[0] > 64 and not f8
         for li, L in enumerate(self.layers):
-            qkv = lin(x, L, "wqkv")
-            llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
+            # the kernel that sums the qkv projection's K splits also rotates q / k and fills the cache slots
+            qkv = llm.mid_qkv_rope(x, L["wqkv8"] if f8 else L["wqkv"], self.cos_sin, positions, slots, cache.k[li], cache.v[li],
+                                   cfg.n_q, cfg.n_kv, weight_scale=L["wqkv_s"] if f8 else None)
             x = close(attend(qkv, cache.k[li], cache.v[li]), L, "wo")
             if wide_lib:
                 act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))

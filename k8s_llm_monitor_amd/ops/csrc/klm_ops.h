@@ -130,6 +130,11 @@ int klm_mid_linear(const void* x, int x_stride, const void* W, int w_stride, flo
                    int waves, int row_tiles, void* stream);
 int klm_mid_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, float* part, int M, int N, int K,
                       int ksplit, int waves, int row_tiles, void* stream);     // e4m3 weights, tiled order, fp32 row scales
+// The qkv projection's epilogue: sums the K splits, applies RoPE, fills `qkv` [T][(n_q + 2 n_kv) * 128] and the caches
+// (klm_rope_cache fed by partials: one launch instead of two).
+int klm_rope_cache_from_partials(const float* part, int ksplit, void* qkv, const float* cos_sin, const int32_t* positions,
+                                 const int32_t* slots, void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos,
+                                 int64_t num_slots, int kv_fp8, void* stream);
 int klm_mid_epilogue(const float* part, int ksplit, int M, int N, int kind, void* out, void* residual, float eps, void* stream);
 
 const char* klm_version(void);

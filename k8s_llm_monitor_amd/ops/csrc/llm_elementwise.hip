@@ -91,14 +91,15 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
 // Eight lanes per (token, head): lane j of the group owns dims 8j..8j+7 and their partners 64+8j..,
 // so every global access of the activation is a 16-byte vector (a 2-byte-per-lane version ran the
 // 4096-token prefill's rope at 2.2 TB/s); only the transposed V cache write stays element-wise.
-template <bool KV8>
+template <bool KV8, bool PART>
 __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv,
                                                          const float* __restrict__ cos_sin,
                                                          const int* __restrict__ positions,
                                                          const int* __restrict__ slots,
                                                          void* __restrict__ kcv,
                                                          void* __restrict__ vcv, int T, int n_q,
-                                                         int n_kv, int max_pos, int num_slots) {
+                                                         int n_kv, int max_pos, int num_slots,
+                                                         const float* __restrict__ part, int ks) {
   uint16_t* kc = reinterpret_cast<uint16_t*>(kcv);
   uint16_t* vc = reinterpret_cast<uint16_t*>(vcv);
   uint8_t* kc8 = reinterpret_cast<uint8_t*>(kcv);
@@ -113,11 +114,33 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
   pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
   const int slot = slots[t];
   const bool cache_ok = slot >= 0 && slot < num_slots;
-  const uint4 a1 = *reinterpret_cast<const uint4*>(row + j * 8);
-  const uint4 a2 = *reinterpret_cast<const uint4*>(row + 64 + j * 8);
   float x1[8], x2[8];
-  unpack8(a1, x1);
-  unpack8(a2, x2);
+  if (PART) {
+    // the projection's K splits are summed here (mid-batch kernel, llm_mid.hip): fp32 [ks][T][heads * 128], rounded to
+    // bf16 once, exactly what the separate epilogue kernel would have stored
+    const size_t split = (size_t)T * heads * HD;
+    const float* p = part + ((size_t)t * heads + hs) * HD + j * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x1[i] = x2[i] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < ks; ++k) {
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(p + k * split), u1 = *reinterpret_cast<const f32x4*>(p + k * split + 4);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p + k * split + 64), w1 = *reinterpret_cast<const f32x4*>(p + k * split + 68);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x1[i] += u0[i]; x1[4 + i] += u1[i];
+        x2[i] += w0[i]; x2[4 + i] += w1[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x1[i] = bf2f(f2bf(x1[i]));
+      x2[i] = bf2f(f2bf(x2[i]));
+    }
+  } else {
+    unpack8(*reinterpret_cast<const uint4*>(row + j * 8), x1);
+    unpack8(*reinterpret_cast<const uint4*>(row + 64 + j * 8), x2);
+  }
   if (hs < n_q + n_kv) {
     const float* cs = cos_sin + (size_t)pos * HD + j * 8;
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);
@@ -147,7 +170,12 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
         *reinterpret_cast<uint4*>(kc + off + 64) = o2;
       }
     }
-  } else if (cache_ok) {
+  } else {
+    if (PART) {                                    // keep the qkv buffer complete (the v columns are not rotated)
+      *reinterpret_cast<uint4*>(row + j * 8) = pack8(x1);
+      *reinterpret_cast<uint4*>(row + 64 + j * 8) = pack8(x2);
+    }
+    if (!cache_ok) return;
     const size_t off = ((size_t)(slot / BLK) * n_kv + (hs - n_q - n_kv)) * BLK_ELEMS + (slot % BLK);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -196,25 +224,43 @@ int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream) {
   return launch_status();
 }
 
-int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
-                   void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
-                   int kv_fp8, void* stream) {
+static int rope_cache_launch(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots, void* k_cache,
+                             void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots, int kv_fp8,
+                             const float* part, int ks, void* stream) {
   if (T <= 0 || n_q <= 0 || n_kv <= 0 || max_pos <= 0 || num_slots <= 0 || num_slots > INT32_MAX)
     return KLM_ERR_SHAPE;
   if (!qkv || !cos_sin || !positions || !slots || !k_cache || !v_cache) return KLM_ERR_ARG;
-  if (!aligned16(qkv) || !aligned16(cos_sin) || !aligned16(k_cache) || !aligned16(v_cache)) return KLM_ERR_ALIGN;
+  if (!aligned16(qkv) || !aligned16(cos_sin) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(part)) return KLM_ERR_ALIGN;
+  if (part && ks <= 0) return KLM_ERR_SHAPE;
   const long pairs = (long)T * (n_q + 2 * n_kv);       // 8 lanes per (token, head): 32 pairs per 256-thread block
   const long blocks = (pairs + 31) / 32;
   if (blocks > INT32_MAX) return KLM_ERR_SHAPE;
-  if (kv_fp8)
-    hipLaunchKernelGGL(rope_cache_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (uint16_t*)qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos,
-                       (int)num_slots);
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), (uint16_t*)qkv, cos_sin,
+                       positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos, (int)num_slots, part, ks);
+  };
+  if (part)
+    kv_fp8 ? go(rope_cache_kernel<true, true>) : go(rope_cache_kernel<false, true>);
   else
-    hipLaunchKernelGGL(rope_cache_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (uint16_t*)qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos,
-                       (int)num_slots);
+    kv_fp8 ? go(rope_cache_kernel<true, false>) : go(rope_cache_kernel<false, false>);
   return launch_status();
+}
+
+int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
+                   void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
+                   int kv_fp8, void* stream) {
+  return rope_cache_launch(qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos, num_slots, kv_fp8, nullptr, 0,
+                           stream);
+}
+
+// The same, fed by the fp32 K-split partials of the qkv projection (llm_mid.hip) instead of a finished qkv tensor:
+// part[ks][T][(n_q + 2 n_kv) * 128]. Sums the splits, rotates, fills `qkv` and the caches: one launch instead of two.
+int klm_rope_cache_from_partials(const float* part, int ksplit, void* qkv, const float* cos_sin, const int32_t* positions,
+                                 const int32_t* slots, void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos,
+                                 int64_t num_slots, int kv_fp8, void* stream) {
+  if (!part) return KLM_ERR_ARG;
+  return rope_cache_launch(qkv, cos_sin, positions, slots, k_cache, v_cache, T, n_q, n_kv, max_pos, num_slots, kv_fp8, part,
+                           ksplit, stream);
 }
 
 }  // extern "C"

@@ -44,7 +44,8 @@ def _lib():
         lib.klm_mid_linear.argtypes = [vp, i, vp, i, vp, i, i, i, i, i, i, vp]
         lib.klm_mid_linear_w8.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, i, vp]
         lib.klm_mid_epilogue.argtypes = [vp, i, i, i, i, vp, vp, f, vp]
-        for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_linear_w8", "klm_mid_epilogue"):
+        lib.klm_rope_cache_from_partials.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i64, i, vp]
+        for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_linear_w8", "klm_mid_epilogue", "klm_rope_cache_from_partials"):
             getattr(lib, n).restype = i
         for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
                   "klm_skinny_linear"):
@@ -243,6 +244,61 @@ def mid_plan(M: int, N: int, K: int, ksplit: int = 0, waves: int = 0, row_tiles:
     return ks.value, nw.value, rt.value
 
 
+def _mid_partials(x, weight, weight_scale, ksplit: int = 0, waves: int = 0, row_tiles: int = 0):
+    """The main kernel of the mid-batch path: fp32 partial sums [ksplit][M][N] (operands already checked)."""
+    N, K = weight.shape
+    M = x.shape[0]
+    ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
+    part = torch.empty((ks, M, N), dtype=torch.float32, device=x.device)
+    st = _stream(x)
+    if weight_scale is not None:
+        rc = _lib().klm_mid_linear_w8(x.data_ptr(), x.stride(0), weight.data_ptr(), weight_scale.data_ptr(), part.data_ptr(),
+                                      M, N, K, ks, nw, rt, st)
+    else:
+        rc = _lib().klm_mid_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), part.data_ptr(), M, N, K,
+                                   ks, nw, rt, st)
+    _check(rc, f"klm_mid_linear(M={M},N={N},K={K},ks={ks},nw={nw},rt={rt},fp8={weight_scale is not None})")
+    return part, ks
+
+
+def _mid_check(x, weight, weight_scale, what: str) -> None:
+    N, K = weight.shape
+    w8 = weight.dtype == torch.float8_e4m3fn
+    if w8 != (weight_scale is not None):
+        raise KlmOpsError(f"{what}: `weight_scale` goes with float8_e4m3fn weights (tiled)")
+    _bf16(x) if w8 else _bf16(x, weight)
+    if w8 and (not weight.is_contiguous() or tuple(weight_scale.shape) != (N,) or weight_scale.dtype != torch.float32
+               or not weight_scale.is_contiguous() or not weight_scale.is_cuda):
+        raise KlmOpsError(f"{what}: fp8 weights must be contiguous (tiled) with a contiguous fp32 scale [N] on the GPU")
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or weight.stride(1) != 1 or weight.stride(0) < K or not mid_ok(x.shape[0], N, K):
+        raise KlmOpsError(f"{what}: x {tuple(x.shape)} weight {tuple(weight.shape)}")
+
+
+def mid_qkv_rope(x: torch.Tensor, wqkv: torch.Tensor, cos_sin: torch.Tensor, positions: torch.Tensor, slots: torch.Tensor,
+                 k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int,
+                 weight_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``rope_cache(mid_linear(x, wqkv))`` in two launches instead of three: the kernel that sums the projection's K
+    splits also rotates q and k and writes k / v into their cache slots. Bit-identical to the separate kernels."""
+    T = x.shape[0]
+    N = wqkv.shape[0]
+    if not x.is_cuda:
+        return rope_cache(mid_linear(x, wqkv, weight_scale=weight_scale), cos_sin, positions, slots, k_cache, v_cache, n_q, n_kv)
+    nb = _check_caches(k_cache, v_cache, n_kv)
+    if N != (n_q + 2 * n_kv) * HEAD_DIM or positions.shape != (T,) or slots.shape != (T,):
+        raise KlmOpsError(f"mid_qkv_rope: wqkv {tuple(wqkv.shape)} for {n_q} + 2 x {n_kv} heads, T = {T}")
+    if cos_sin.dim() != 2 or cos_sin.shape[1] != HEAD_DIM or cos_sin.dtype != torch.float32 or not cos_sin.is_contiguous():
+        raise KlmOpsError("mid_qkv_rope: cos_sin must be fp32 [max_pos, 128]")
+    _mid_check(x, wqkv, weight_scale, "mid_qkv_rope")
+    _i32(positions, slots)
+    part, ks = _mid_partials(x, wqkv, weight_scale)
+    qkv = torch.empty((T, N), dtype=x.dtype, device=x.device)
+    rc = _lib().klm_rope_cache_from_partials(part.data_ptr(), ks, qkv.data_ptr(), cos_sin.data_ptr(), positions.data_ptr(),
+                                             slots.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), T, n_q, n_kv,
+                                             cos_sin.shape[0], nb * BLOCK, _kv8(k_cache), _stream(x))
+    _check(rc, f"klm_rope_cache_from_partials(T={T},ks={ks})")
+    return qkv
+
+
 def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, eps: float = 1e-5, ksplit: int = 0, waves: int = 0,
                row_tiles: int = 0, weight_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -273,28 +329,15 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residu
             out.copy_(o)
             return out
         return o
-    _bf16(x) if w8 else _bf16(x, weight)
-    if w8 and (not weight.is_contiguous() or tuple(weight_scale.shape) != (N,) or weight_scale.dtype != torch.float32
-               or not weight_scale.is_contiguous() or not weight_scale.is_cuda):
-        raise KlmOpsError("mid_linear: fp8 weights must be contiguous (tiled) with a contiguous fp32 scale [N] on the GPU")
-    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or weight.stride(1) != 1 or weight.stride(0) < K or not mid_ok(M, N, K):
-        raise KlmOpsError(f"mid_linear: x {tuple(x.shape)} weight {tuple(weight.shape)}")
+    _mid_check(x, weight, weight_scale, "mid_linear")
     if residual is not None and (tuple(residual.shape) != (M, N) or not residual.is_contiguous() or residual.dtype != x.dtype):
         raise KlmOpsError("mid_linear: residual must be contiguous [M,N]")
     if out is None:
         out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
     elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
         raise KlmOpsError("mid_linear: bad out")
-    ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
-    part = torch.empty((ks, M, N), dtype=torch.float32, device=x.device)
+    part, ks = _mid_partials(x, weight, weight_scale, ksplit, waves, row_tiles)
     st = _stream(x)
-    if w8:
-        rc = _lib().klm_mid_linear_w8(x.data_ptr(), x.stride(0), weight.data_ptr(), weight_scale.data_ptr(), part.data_ptr(),
-                                      M, N, K, ks, nw, rt, st)
-    else:
-        rc = _lib().klm_mid_linear(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), part.data_ptr(), M, N, K,
-                                   ks, nw, rt, st)
-    _check(rc, f"klm_mid_linear(M={M},N={N},K={K},ks={ks},nw={nw},rt={rt},fp8={w8})")
     _check(_lib().klm_mid_epilogue(part.data_ptr(), ks, M, N, k, out.data_ptr(),
                                    residual.data_ptr() if residual is not None else None, float(eps), st),
            f"klm_mid_epilogue(M={M},N={N},{kind})")

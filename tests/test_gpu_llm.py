@@ -389,3 +389,25 @@ def test_mid_linear_with_fp8_tiled_weights_matches_the_dequantised_reference(M, 
     _close(llm.mid_linear(x, w8t, weight_scale=sc), llm.mid_linear(x, wd), 5e-2, 1e-2)
     with pytest.raises(llm.KlmOpsError):
         llm.mid_linear(x, w8t)                          # fp8 without scales
+
+
+@pytest.mark.parametrize("kv8", [False, True])
+@pytest.mark.parametrize("T", [17, 64, 100])
+def test_mid_qkv_rope_equals_the_three_kernel_sequence(T, kv8):
+    """mid_qkv_rope = mid_linear + rope_cache with the split-sum folded into the rope kernel: same bits everywhere."""
+    torch.manual_seed(51)
+    n_q, n_kv, K, nb = 8, 2, 1024, 12
+    N = (n_q + 2 * n_kv) * 128
+    x, w = _rand(T, K), _rand(N, K, scale=0.05)
+    cos_sin = llm.rope_table(512, 500000.0, DEV)
+    pos = torch.randint(0, 512, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(nb * 16, device=DEV)[:T].to(torch.int32)
+    slots[3] = -1                                       # a padded row writes no cache slot
+    dt = torch.float8_e4m3fn if kv8 else torch.bfloat16
+    caches = [(torch.zeros((nb, n_kv, 16, 128), dtype=dt, device=DEV), torch.zeros((nb, n_kv, 128, 16), dtype=dt, device=DEV))
+              for _ in range(2)]
+    a = llm.rope_cache(llm.mid_linear(x, w), cos_sin, pos, slots, *caches[0], n_q, n_kv)
+    b = llm.mid_qkv_rope(x, w, cos_sin, pos, slots, *caches[1], n_q, n_kv)
+    assert torch.equal(a, b)
+    for ca, cb in zip(caches[0], caches[1]):
+        assert torch.equal(ca.view(torch.uint8), cb.view(torch.uint8))

@@ -130,6 +130,9 @@ int klm_mid_linear(const void* x, int x_stride, const void* W, int w_stride, flo
                    int waves, int row_tiles, void* stream);
 int klm_mid_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, float* part, int M, int N, int K,
                       int ksplit, int waves, int row_tiles, void* stream);     // e4m3 weights, tiled order, fp32 row scales
+// gate_up without a K split: SwiGLU inside the main kernel, act[M][N/2] bf16 out, no epilogue launch (wscale: e4m3 tiled W).
+int klm_mid_linear_swiglu(const void* x, int x_stride, const void* W, int w_stride, const float* wscale, void* act, int M, int N,
+                          int K, int waves, int row_tiles, void* stream);
 // The qkv projection's epilogue: sums the K splits, applies RoPE, fills `qkv` [T][(n_q + 2 n_kv) * 128] and the caches
 // (klm_rope_cache fed by partials: one launch instead of two).
 int klm_rope_cache_from_partials(const float* part, int ksplit, void* qkv, const float* cos_sin, const int32_t* positions,

@@ -42,7 +42,7 @@ constexpr int SLOTS = KC / 8;           // 16-byte slots per x row in a chunk
 // instruction loads - 16 rows x 64 k-values - is contiguous, tiles ordered [row tile][k / 64]) with one fp32 scale per
 // row. A lane's 16 bytes become two bf16 fragments in registers (k-values 0..7 and 8..15 of its 16), multiplied with
 // the x slots at the same k offsets; the scale multiplies the fp32 partial sums. Half the bytes, contiguous runs.
-template <int MT, int RT, int NW, bool W8>
+template <int MT, int RT, int NW, bool W8, bool SWIGLU>
 __global__ __launch_bounds__((NW + (MT + 1) / 2) * 64) void mid_linear_kernel(const uint16_t* __restrict__ x, int x_stride,
                                                                               const void* __restrict__ Wv, int w_stride,
                                                                               const float* __restrict__ wscale,
@@ -200,6 +200,29 @@ __global__ __launch_bounds__((NW + (MT + 1) / 2) * 64) void mid_linear_kernel(co
     }
   }
 
+  if (SWIGLU) {
+    // no K split (gridDim.y == 1): the sums are final, and a 16-row tile of gate_up holds 8 gate and the 8 matching up
+    // columns. Lanes fq 0,1 carry gate columns fq*4+i, lanes fq 2,3 the up columns: one cross-lane exchange pairs them and
+    // the activation goes out as bf16 [M][N/2], with no partial sums and no epilogue launch.
+    uint16_t* act = reinterpret_cast<uint16_t*>(part);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int row = t * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        f32x4 u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = __shfl_xor(acc[t][r][i], 32);
+        if (row < M && fq < 2) {
+          bf16x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (__bf16)(acc[t][r][i] / (1.f + __expf(-acc[t][r][i])) * u[i]);
+          *reinterpret_cast<bf16x4*>(act + (size_t)row * (N >> 1) + ((n0 + r * 16) >> 1) + fq * 4) = o;
+        }
+      }
+    }
+    return;
+  }
   // D[w row fq*4+i][x row fr]: four consecutive output columns of one x row per lane
   float* pbase = part + (size_t)blockIdx.y * M * N;
 #pragma unroll
@@ -301,10 +324,10 @@ struct MidArgs {
   int M, N, K, kper;
 };
 
-template <int MT, int RT, bool W8>
+template <int MT, int RT, bool W8, bool SW>
 void launch_nw(int nw, dim3 grid, hipStream_t s, const MidArgs& a) {
 #define KLM_MID_GO(NWV)                                                                                                  \
-  hipLaunchKernelGGL((mid_linear_kernel<MT, RT, NWV, W8>), grid, dim3((NWV + (MT + 1) / 2) * 64), 0, s, a.x, a.x_stride, a.W, \
+  hipLaunchKernelGGL((mid_linear_kernel<MT, RT, NWV, W8, SW>), grid, dim3((NWV + (MT + 1) / 2) * 64), 0, s, a.x, a.x_stride, a.W, \
                      a.w_stride, a.wscale, a.part, a.M, a.N, a.K, a.kper)
   if (nw == 8) KLM_MID_GO(8);
   else if (nw == 7) KLM_MID_GO(7);
@@ -312,17 +335,17 @@ void launch_nw(int nw, dim3 grid, hipStream_t s, const MidArgs& a) {
 #undef KLM_MID_GO
 }
 
-template <int MT, bool W8>
+template <int MT, bool W8, bool SW>
 void launch_rt(int rt, int nw, dim3 grid, hipStream_t s, const MidArgs& a) {
-  if (rt == 2) launch_nw<MT, 2, W8>(nw, grid, s, a);
-  else launch_nw<MT, 1, W8>(nw, grid, s, a);
+  if (rt == 2) launch_nw<MT, 2, W8, SW>(nw, grid, s, a);
+  else launch_nw<MT, 1, W8, SW>(nw, grid, s, a);
 }
 
-template <bool W8>
+template <bool W8, bool SW>
 void launch_mt(int rt, int nw, dim3 grid, hipStream_t s, const MidArgs& a) {
-  if (a.M <= 32) launch_rt<2, W8>(rt, nw, grid, s, a);
-  else if (a.M <= 64) launch_rt<4, W8>(rt, nw, grid, s, a);
-  else launch_rt<8, W8>(rt, nw, grid, s, a);
+  if (a.M <= 32) launch_rt<2, W8, SW>(rt, nw, grid, s, a);
+  else if (a.M <= 64) launch_rt<4, W8, SW>(rt, nw, grid, s, a);
+  else launch_rt<8, W8, SW>(rt, nw, grid, s, a);
 }
 
 }  // namespace
@@ -342,7 +365,7 @@ int klm_mid_linear_plan(int M, int N, int K, int* ksplit, int* waves, int* row_t
   if (N % (nw * 16) != 0) nw = 4;
   if (rt != 1 && rt != 2) {
     rt = N % (nw * 32) == 0 ? 2 : 1;
-    if (rt == 2 && nw == 7 && M <= 32 && N / (nw * 16) <= 256) rt = 1;
+    if (rt == 2 && nw == 7 && M <= 64 && N / (nw * 16) <= 256) rt = 1;   // 256 blocks without a K split (level with 2 x 128 at 33 - 64 rows)
     if (rt == 2 && (long long)N * K <= (1LL << 24)) rt = 1;    // small matrices (8B wo): the same 256 blocks with half the K splits
   }
   if (N % (nw * rt * 16) != 0) rt = 1;
@@ -370,7 +393,7 @@ int klm_mid_linear_plan(int M, int N, int K, int* ksplit, int* waves, int* row_t
 }
 
 static int mid_launch(const void* x, int x_stride, const void* W, int w_stride, const float* wscale, bool w8, float* part, int M,
-                      int N, int K, int ksplit, int waves, int row_tiles, void* stream) {
+                      int N, int K, int ksplit, int waves, int row_tiles, void* stream, bool swiglu = false) {
   int ks = ksplit, nw = waves, rt = row_tiles;
   const int rc = klm_mid_linear_plan(M, N, K, &ks, &nw, &rt);
   if (rc != KLM_OK) return rc;
@@ -382,8 +405,15 @@ static int mid_launch(const void* x, int x_stride, const void* W, int w_stride, 
   const dim3 grid(N / (nw * rt * 16), ks);
   const MidArgs a{static_cast<const uint16_t*>(x), x_stride, W, w_stride, wscale, part, M, N, K, K / ks};
   auto s = static_cast<hipStream_t>(stream);
-  if (w8) launch_mt<true>(rt, nw, grid, s, a);
-  else launch_mt<false>(rt, nw, grid, s, a);
+  if (swiglu) {
+    if (ks != 1) return KLM_ERR_SHAPE;                           // the fused activation needs the whole K in one block
+    if (w8) launch_mt<true, true>(rt, nw, grid, s, a);
+    else launch_mt<false, true>(rt, nw, grid, s, a);
+  } else if (w8) {
+    launch_mt<true, false>(rt, nw, grid, s, a);
+  } else {
+    launch_mt<false, false>(rt, nw, grid, s, a);
+  }
   return launch_status();
 }
 
@@ -397,6 +427,15 @@ int klm_mid_linear(const void* x, int x_stride, const void* W, int w_stride, flo
 int klm_mid_linear_w8(const void* x, int x_stride, const void* W8, const float* wscale, float* part, int M, int N, int K,
                       int ksplit, int waves, int row_tiles, void* stream) {
   return mid_launch(x, x_stride, W8, K, wscale, true, part, M, N, K, ksplit, waves, row_tiles, stream);
+}
+
+// gate_up with ksplit == 1: SwiGLU applied in the kernel, act[M][N/2] bf16 written directly (no partials, no epilogue).
+// W is bf16 (wscale == nullptr) or tiled e4m3 with row scales.
+int klm_mid_linear_swiglu(const void* x, int x_stride, const void* W, int w_stride, const float* wscale, void* act, int M, int N,
+                          int K, int waves, int row_tiles, void* stream) {
+  if (!aligned16(act)) return KLM_ERR_ALIGN;
+  return mid_launch(x, x_stride, W, wscale ? K : w_stride, wscale, wscale != nullptr, static_cast<float*>(act), M, N, K, 1, waves,
+                    row_tiles, stream, true);
 }
 
 // kind 0: out[M][N] = sum of the splits. 1: SwiGLU, out[M][N/2]. 2: residual[M][N] += sum, out[M][N] = rmsnorm(residual).

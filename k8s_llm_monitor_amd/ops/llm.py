@@ -45,7 +45,9 @@ def _lib():
         lib.klm_mid_linear_w8.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, i, vp]
         lib.klm_mid_epilogue.argtypes = [vp, i, i, i, i, vp, vp, f, vp]
         lib.klm_rope_cache_from_partials.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i64, i, vp]
-        for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_linear_w8", "klm_mid_epilogue", "klm_rope_cache_from_partials"):
+        lib.klm_mid_linear_swiglu.argtypes = [vp, i, vp, i, vp, vp, i, i, i, i, i, vp]
+        for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_linear_w8", "klm_mid_epilogue", "klm_rope_cache_from_partials",
+                  "klm_mid_linear_swiglu"):
             getattr(lib, n).restype = i
         for n in ("klm_rmsnorm", "klm_silu_mul", "klm_rope_cache", "klm_paged_attn_decode", "klm_paged_attn_prefill",
                   "klm_skinny_linear"):
@@ -336,8 +338,15 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residu
         out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
     elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
         raise KlmOpsError("mid_linear: bad out")
-    part, ks = _mid_partials(x, weight, weight_scale, ksplit, waves, row_tiles)
     st = _stream(x)
+    if k == 1:
+        ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
+        if ks == 1:                       # no K split: the activation is applied inside the main kernel, no epilogue launch
+            _check(_lib().klm_mid_linear_swiglu(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
+                                                weight_scale.data_ptr() if w8 else None, out.data_ptr(), M, N, K, nw, rt, st),
+                   f"klm_mid_linear_swiglu(M={M},N={N},K={K},nw={nw},rt={rt},fp8={w8})")
+            return out
+    part, ks = _mid_partials(x, weight, weight_scale, ksplit, waves, row_tiles)
     _check(_lib().klm_mid_epilogue(part.data_ptr(), ks, M, N, k, out.data_ptr(),
                                    residual.data_ptr() if residual is not None else None, float(eps), st),
            f"klm_mid_epilogue(M={M},N={N},{kind})")

@@ -358,7 +358,29 @@ def test_mid_linear_every_configuration_gives_the_same_product(ksplit, waves, rt
     M, N, K = 72, 1024, 4096
     x, w = _rand(M, K), _rand(N, K, scale=0.03)
     assert llm.mid_plan(M, N, K, ksplit, waves, rt) == (ksplit, waves, rt)
-    _close(llm.mid_linear(x, w, ksplit=ksplit, waves=waves, row_tiles=rt), x.float() @ w.float().t(), 5e-2, 2e-2)
+    want = x.float() @ w.float().t()
+    _close(llm.mid_linear(x, w, ksplit=ksplit, waves=waves, row_tiles=rt), want, 5e-2, 2e-2)
+    # SwiGLU: inside the main kernel when there is no K split, in the epilogue kernel otherwise
+    _close(llm.mid_linear(x, w, kind="swiglu", ksplit=ksplit, waves=waves, row_tiles=rt), ref.silu_mul(want), 5e-2, 2e-2)
+
+
+@pytest.mark.parametrize("M", [20, 48, 64])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_mid_linear_fused_swiglu_on_the_gate_up_shape(M, fp8):
+    """N = 28672: 7-wave blocks, no K split up to 64 rows -> the activation never leaves the main kernel."""
+    torch.manual_seed(34)
+    N, K = 28672, 4096
+    assert llm.mid_plan(M, N, K)[0] == 1 and llm.mid_plan(M, N, K)[1] == 7
+    x, w = _rand(M, K), _rand(N, K, scale=0.03)
+    if fp8:
+        w8, sc = llm.quantize_fp8_rows(w)
+        want = ref.silu_mul(x.float() @ (w8.float() * sc[:, None]).t())
+        got = llm.mid_linear(x, llm.tile_weights(w8), weight_scale=sc, kind="swiglu")
+    else:
+        want = ref.silu_mul(x.float() @ w.float().t())
+        got = llm.mid_linear(x, w, kind="swiglu")
+    assert tuple(got.shape) == (M, N // 2)
+    _close(got, want, 5e-2, 2e-2)
 
 
 def test_mid_linear_reads_strided_operands_and_rejects_bad_shapes():

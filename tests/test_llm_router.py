@@ -69,16 +69,27 @@ def test_router_spreads_requests_and_merges_metrics():
 
 
 def _free_port_block(n):
-    socks = []
-    try:
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        base = s.getsockname()[1]
-        socks.append(s)
-        return base
-    finally:
-        for s in socks:
-            s.close()
+    """Base of n consecutive ports that can all be bound right now."""
+    for _ in range(50):
+        socks = []
+        try:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            socks.append(s)
+            base = s.getsockname()[1]
+            if base + n > 65535:
+                continue
+            for k in range(1, n):
+                t = socket.socket()
+                socks.append(t)
+                t.bind(("127.0.0.1", base + k))
+            return base
+        except OSError:
+            continue
+        finally:
+            for s in socks:
+                s.close()
+    raise RuntimeError("no block of free ports")
 
 
 def test_serve_llm_gpus_2_runs_two_engine_processes_behind_the_router():

@@ -71,6 +71,7 @@ _SNAPSHOT_PATHS = {"/api/host/metrics", "/api/gpu/metrics", "/api/k8s/pods", "/a
                    "/api/xgmi", "/api/alerts/history", "/metrics"}
 _REASONS = {200: b"OK", 404: b"Not Found", 405: b"Method Not Allowed", 400: b"Bad Request", 500: b"Internal Server Error",
             503: b"Service Unavailable", 431: b"Request Header Fields Too Large"}
+_PUSHED = ("alerts", "realtime", "pods", "vllm")      # sampler events forwarded to /api/events
 _BLOCKING_PATHS = {"/api/history", "/api/cluster", "/api/rccl/probe", "/api/validation"}     # may do I/O: run off the loop
 
 
@@ -113,9 +114,10 @@ class MonitorServer:
 
     # ---- server-sent events ------------------------------------------------------------
     def _on_event(self, kind: str, payload: Any) -> None:
-        if kind != "alerts" or not self._sse or self._closing:
+        if kind not in _PUSHED or not self._sse or self._closing:      # nobody listening: nothing is serialised
             return
-        msg = b"event: alerts\ndata: " + _dumps(self.monitor.alerts_public()) + b"\n\n"
+        doc = self.monitor.alerts_public() if kind == "alerts" else payload
+        msg = b"event: " + kind.encode("ascii") + b"\ndata: " + _dumps(doc) + b"\n\n"
         try:
             self._loop.call_soon_threadsafe(self._broadcast, msg)
         except RuntimeError:
@@ -268,7 +270,10 @@ class MonitorServer:
         import asyncio
         writer.write(b"HTTP/1.1 200 OK\r\n" + self._head_cors + b"Content-Type: text/event-stream; charset=utf-8\r\n"
                      b"Cache-Control: no-store\r\nConnection: close\r\n\r\n")
-        writer.write(b"event: alerts\ndata: " + _dumps(self.monitor.alerts_public()) + b"\n\n")
+        m = self.monitor                                   # first paint: the current state of every pushed panel
+        for kind, doc in (("alerts", m.alerts_public()), ("realtime", {"host": m.get("host"), "gpus": m.get("gpus")}),
+                          ("pods", m.get("pods")), ("vllm", m.get("vllm"))):
+            writer.write(b"event: " + kind.encode("ascii") + b"\ndata: " + _dumps(doc) + b"\n\n")
         self._sse.add(writer)
         try:
             while not self._closing and not writer.is_closing():

@@ -265,6 +265,7 @@ class Monitor:
         with self._lock:
             self._snap["vllm"], self._snap["t_vllm"] = v, now
             self.version += 1
+        self._emit("vllm", v)
 
     def tick_all(self) -> None:
         """One synchronous pass over every source (tests, first paint before the threads run)."""

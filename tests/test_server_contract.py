@@ -159,6 +159,42 @@ def test_sse_stream_delivers_alerts(server):
     s.close()
 
 
+def test_sse_stream_pushes_every_panel(server):
+    """First paint on connect, then one `realtime` / `pods` / `vllm` event per sampler tick: the page needs no polling."""
+    import socket
+    s = socket.create_connection(("127.0.0.1", server.port), timeout=5)
+    s.sendall(b"GET /api/events HTTP/1.1\r\nHost: x\r\n\r\n")
+
+    def events(buf):
+        out = []
+        for block in buf.split(b"\n\n"):
+            m = re.match(rb"event: (\w+)\ndata: (.*)\Z", block, re.S)
+            if m:
+                out.append((m.group(1).decode(), json.loads(m.group(2))))
+        return out
+
+    buf = b""
+    while len(events(buf.split(b"\r\n\r\n", 1)[-1])) < 4:
+        buf += s.recv(65536)
+    first = dict(events(buf.split(b"\r\n\r\n", 1)[1]))
+    assert set(first) == {"alerts", "realtime", "pods", "vllm"}
+    assert first["realtime"]["gpus"] == get_json(server, "/api/gpu/metrics") and first["pods"] == get_json(server, "/api/k8s/pods")
+    mon = server.monitor
+    n0 = len(events(buf.split(b"\r\n\r\n", 1)[1]))
+    mon.tick_all()
+    deadline = time.time() + 5
+    while time.time() < deadline:
+        buf += s.recv(65536)
+        ev = events(buf.split(b"\r\n\r\n", 1)[1])[n0:]
+        if {"realtime", "pods", "vllm"} <= {k for k, _ in ev}:
+            break
+    kinds = [k for k, _ in ev]
+    assert {"realtime", "pods", "vllm"} <= set(kinds)
+    last = [d for k, d in ev if k == "realtime"][-1]
+    assert last["host"]["memory"]["total"] > 0 and len(last["gpus"]) == 8 and "xcdActivity" in last["gpus"][0]
+    s.close()
+
+
 def test_missing_page_is_fatal_like_the_reference(tmp_path):
     cfg = demo_config(server={"static_dir": str(tmp_path)})
     mon = Monitor(cfg)

@@ -103,7 +103,8 @@ def _cmd_serve_llm_replicas(a) -> int:
     child = ["--model", a.model, "--max-num-seqs", str(a.max_num_seqs), "--max-model-len", str(a.max_model_len),
              "--kv-blocks", str(a.kv_blocks), "--kv-fraction", str(a.kv_fraction), "--decode-weights", a.decode_weights,
              "--kv-cache-dtype", a.kv_cache_dtype, "--load-rps", str(a.load_rps / a.gpus), "--prompt-len", str(a.prompt_len),
-             "--output-len", str(a.output_len)] + (["--no-graphs"] if a.no_graphs else [])
+             "--output-len", str(a.output_len), "--max-num-batched-tokens", str(a.max_num_batched_tokens)] + \
+        (["--no-graphs"] if a.no_graphs else []) + (["--no-mixed-batches"] if a.no_mixed_batches else [])
     kind = "cpu" if a.device == "cpu" else "cuda"
     base = a.replica_base_port or a.port + 1
     rs = ReplicaSet(list(range(a.gpus)), base, child, host="127.0.0.1", device_kind=kind).start()
@@ -201,7 +202,8 @@ def _cmd_serve_llm(a) -> int:
         device = str(dev)
     eng = Engine(EngineConfig(model=a.model, device=device, max_num_seqs=a.max_num_seqs, max_model_len=a.max_model_len,
                               kv_blocks=a.kv_blocks, kv_fraction=a.kv_fraction, use_graphs=not a.no_graphs,
-                              decode_weights=a.decode_weights, kv_cache_dtype=a.kv_cache_dtype), tp=tp)
+                              decode_weights=a.decode_weights, kv_cache_dtype=a.kv_cache_dtype,
+                              max_num_batched_tokens=a.max_num_batched_tokens, mixed_batches=not a.no_mixed_batches), tp=tp)
     eng.warmup()
     if tp is not None and tp.rank != 0:
         for sig in (signal.SIGINT, signal.SIGTERM):
@@ -282,6 +284,9 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--kv-blocks", type=int, default=0, help="KV blocks of 16 tokens (0: from --kv-fraction)")
     p.add_argument("--kv-fraction", type=float, default=0.5, help="share of the free HBM given to the KV cache")
     p.add_argument("--no-graphs", action="store_true")
+    p.add_argument("--max-num-batched-tokens", type=int, default=8192, help="token budget of one prefill launch (longer prompts go in chunks)")
+    p.add_argument("--no-mixed-batches", action="store_true",
+                   help="alternate prefill and decode launches instead of decoding the running sequences inside prefill launches")
     p.add_argument("--gpus", type=int, default=1, help="N > 1: one engine process per GPU behind a router on --port")
     p.add_argument("--tp", type=int, default=1,
                    help="tensor parallel over N GPUs (2, 4, 8): one process per GPU, all-reduce on the xGMI mesh kernels; "

@@ -387,14 +387,26 @@ class LlamaModel:
         best = allc[:, :B, 0].argmax(dim=0)
         return allc[:, :B, 1].gather(0, best[None])[0].long()
 
-    def prefill(self, tokens, positions, slots, cache: KVCache, meta: PrefillMeta, logits: bool = False) -> torch.Tensor:
-        """Variable-length batch of prompts (or prompt chunks) -> next token id of each sequence [S]
-        (or the logits [S, vocab])."""
+    def prefill(self, tokens, positions, slots, cache: KVCache, meta: PrefillMeta, logits: bool = False,
+                riders: Optional[DecodeMeta] = None) -> torch.Tensor:
+        """Variable-length batch of prompts (or prompt chunks) -> next token id of each row in `meta.last_rows`
+        (or the logits of those rows). `riders`: the last ``riders.block_tables.shape[0]`` rows are one decode token each
+        of running sequences (a mixed batch): they share the projections with the chunks and attend through the
+        decode kernel."""
         cfg = self.lcfg
+        n_ride = 0 if riders is None else riders.block_tables.shape[0]
+        n_chunk = tokens.shape[0] - n_ride
 
         def attend(qkv, kc, vc):
-            return llm.paged_attn_prefill(qkv, kc, vc, meta.block_tables, meta.seq_info, meta.tiles, self.scale,
-                                          cfg.n_q, q_tiles=meta.q_tiles)
+            if not n_ride:
+                return llm.paged_attn_prefill(qkv, kc, vc, meta.block_tables, meta.seq_info, meta.tiles, self.scale,
+                                              cfg.n_q, q_tiles=meta.q_tiles)
+            o = torch.empty((qkv.shape[0], cfg.q_dim), dtype=qkv.dtype, device=qkv.device)
+            llm.paged_attn_prefill(qkv[:n_chunk], kc, vc, meta.block_tables, meta.seq_info, meta.tiles, self.scale,
+                                   cfg.n_q, out=o[:n_chunk], q_tiles=meta.q_tiles)
+            llm.paged_attn_decode(qkv[n_chunk:], kc, vc, riders.block_tables, riders.ctx_lens, self.scale, cfg.n_q,
+                                  out=o[n_chunk:], num_splits=riders.num_splits, workspace=riders.workspace)
+            return o
 
         x = self._trunk(tokens, positions, slots, cache, attend)
         return self._sample(torch.matmul(x[meta.last_rows], self.lm_head.t()), logits)

@@ -49,6 +49,7 @@ class EngineConfig:
     use_graphs: bool = True
     kv_cache_dtype: str = "bf16"       # "fp8": e4m3 KV cache (half the bytes per token; prefill then uses the register kernel)
     decode_weights: str = "bf16"       # "fp8": W8A16 copies for decode up to batch 128 (LlamaModel.enable_fp8_decode)
+    mixed_batches: bool = True         # running sequences decode inside prefill launches instead of waiting for them
     seed: int = 0
 
 
@@ -158,8 +159,8 @@ class Engine:
         self.last_error: Optional[str] = None
         # the last model launches, for /trace: (start, seconds, kind, sequences, tokens)
         self.step_log: Deque[tuple] = deque(maxlen=4096)
-        self.step_seconds = {"prefill": 0.0, "decode": 0.0}
-        self.step_counts = {"prefill": 0, "decode": 0}
+        self.step_seconds = {"prefill": 0.0, "mixed": 0.0, "decode": 0.0}
+        self.step_counts = {"prefill": 0, "mixed": 0, "decode": 0}
         # decode: static device inputs (graph capture needs stable pointers) + pinned host mirrors
         B = self.cfg.max_num_seqs
         self.buckets = _buckets(B)
@@ -263,10 +264,16 @@ class Engine:
     def step(self) -> int:
         """Run one model launch; returns the number of tokens it produced (0 = nothing to do)."""
         chunks: List[tuple] = []                    # (request, tokens of it in this launch)
+        riders: List[Request] = []                  # running sequences that decode inside a prefill launch
+        mixed = self.cfg.mixed_batches
         with self._lock:
-            decode_turn = self._last_was_prefill and bool(self.running)
-            if not decode_turn:
+            decode_turn = not mixed and self._last_was_prefill and bool(self.running)
+            if not decode_turn and (self.prefilling or self.waiting):
                 budget = self.cfg.max_num_batched_tokens
+                if mixed and self.running:
+                    self._make_room()
+                    riders = list(self.running)
+                    budget = max(budget - len(riders), BLOCK)
                 for r in self.prefilling:
                     take = min(r.n_tokens - r.prefilled, budget)
                     if take <= 0:
@@ -289,7 +296,7 @@ class Engine:
                     budget -= take
         if chunks:
             self._last_was_prefill = True
-            return self._prefill(chunks)
+            return self._prefill(chunks, riders) if riders else self._prefill(chunks)
         self._last_was_prefill = False
         if self.running:
             return self._decode()
@@ -302,7 +309,10 @@ class Engine:
         self.metrics.on_finish(now - r.arrival)
         r.done.set()
 
-    def _prefill(self, chunks: List[tuple]) -> int:
+    def _prefill(self, chunks: List[tuple], riders: Sequence[Request] = ()) -> int:
+        """One launch over prompt chunks and, behind them, one decode token of each of `riders`: the projections see
+        one batch of rows (the weights are streamed once for both), attention runs the prefill kernel on the chunk rows
+        and the decode kernel on the riders' rows."""
         t0 = self.clock()
         toks: List[int] = []
         pos: List[int] = []
@@ -324,12 +334,28 @@ class Engine:
         g = self.lcfg.n_q // self.lcfg.n_kv
         q_lens = [n for (_, n, _) in info]
         qt = llm.pick_q_tiles(q_lens, g, self.lcfg.n_kv)
+        n_chunk_rows = len(toks)
+        dmeta = None
+        if riders:
+            bt_d = np.zeros((len(riders), self.max_blocks), dtype=np.int32)
+            ctx_d = []
+            for j, r in enumerate(riders):
+                nt = r.n_tokens
+                toks.append(r.out[-1])
+                pos.append(nt - 1)
+                slots.append(r.blocks[(nt - 1) // BLOCK] * BLOCK + (nt - 1) % BLOCK)
+                bt_d[j, :len(r.blocks)] = r.blocks
+                ctx_d.append(nt)
+                last_rows.append(n_chunk_rows + j)
+            dmeta = DecodeMeta(torch.from_numpy(bt_d).to(dev), torch.tensor(ctx_d, dtype=torch.int32, device=dev),
+                               num_splits=llm.pick_splits(len(riders), self.lcfg.n_kv, self.max_len) if self.on_gpu else 1,
+                               workspace=self._workspace)
         meta = PrefillMeta(torch.from_numpy(bt).to(dev), torch.tensor(info, dtype=torch.int32, device=dev),
                            llm.prefill_tiles(q_lens, g, qt, ctx_lens=[c for (_, _, c) in info]).to(dev),
                            torch.tensor(last_rows, dtype=torch.int64, device=dev), qt)
         nxt = self.model.prefill(torch.tensor(toks, dtype=torch.int64, device=dev),
                                  torch.tensor(pos, dtype=torch.int32, device=dev),
-                                 torch.tensor(slots, dtype=torch.int32, device=dev), self.cache, meta)
+                                 torch.tensor(slots, dtype=torch.int32, device=dev), self.cache, meta, riders=dmeta)
         nxt = nxt.tolist()                      # synchronises
         now = self.clock()
         new_prompt = produced = 0
@@ -353,11 +379,20 @@ class Engine:
                     self._finish(r, now)
                 else:
                     self.running.append(r)
+            for r, t in zip(riders, nxt[len(chunks):]):
+                self.metrics.on_token_gap(now - (r.t_last or now))
+                r.out.append(int(t))
+                r.t_last = now
+                produced += 1
+                if len(r.out) >= r.max_tokens or r.n_tokens >= self.max_len:
+                    self.running.remove(r)
+                    self._finish(r, now)
             self.metrics.on_step(produced, new_prompt, len(self.running) + len(self.prefilling), len(self.waiting),
                                  self.alloc.usage)
-        self.step_seconds["prefill"] += now - t0
-        self.step_counts["prefill"] += 1
-        self.step_log.append((t0, now - t0, "prefill", len(chunks), len(toks)))
+        kind = "mixed" if riders else "prefill"
+        self.step_seconds[kind] = self.step_seconds.get(kind, 0.0) + now - t0
+        self.step_counts[kind] = self.step_counts.get(kind, 0) + 1
+        self.step_log.append((t0, now - t0, kind, len(chunks) + len(riders), len(toks)))
         return max(produced, 1)
 
     def _make_room(self) -> None:
@@ -535,8 +570,8 @@ class Engine:
         complete events with the batch shape as arguments."""
         ev = []
         for (t0, dt, kind, seqs, toks) in list(self.step_log):
-            ev.append({"name": f"{kind} {seqs}x" if kind == "decode" else f"prefill {toks} tok", "cat": kind, "ph": "X",
-                       "ts": t0 * 1e6, "dur": dt * 1e6, "pid": 1, "tid": 1 if kind == "prefill" else 2,
+            ev.append({"name": f"{kind} {seqs}x" if kind == "decode" else f"{kind} {toks} tok", "cat": kind, "ph": "X",
+                       "ts": t0 * 1e6, "dur": dt * 1e6, "pid": 1, "tid": 2 if kind == "decode" else 1,
                        "args": {"sequences": seqs, "tokens": toks}})
         meta = [{"name": "thread_name", "ph": "M", "pid": 1, "tid": 1, "args": {"name": "prefill launches"}},
                 {"name": "thread_name", "ph": "M", "pid": 1, "tid": 2, "args": {"name": "decode launches"}},
@@ -549,6 +584,7 @@ class Engine:
                 "kv_bytes": self.cache.nbytes, "max_num_seqs": self.cfg.max_num_seqs, "max_model_len": self.max_len,
                 "graphs": sorted(self._graphs), "device": str(self.device),
                 "decode_weights": "fp8 (W8A16, batch <= 128)" if self.model.fp8_decode else "bf16",
-                "kv_cache_dtype": self.cfg.kv_cache_dtype,
+                "kv_cache_dtype": self.cfg.kv_cache_dtype, "mixed_batches": self.cfg.mixed_batches,
+                "max_num_batched_tokens": self.cfg.max_num_batched_tokens,
                 "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts),
                 "tensor_parallel": self.tp.describe(), "errors": self.errors, "last_error": self.last_error}

@@ -109,6 +109,64 @@ def _compare_logits(gpu_model, cpu_model, n_seqs, kv_dtype=None, tol=0.03):
     assert _rel_err(out["gpu"][1], out["cpu"][1]) < tol, "decode logits"
 
 
+@pytest.mark.parametrize("n_ride,new_lens", [(5, [40, 70]), (30, [33]), (60, [100, 90, 17])])   # 115 and 63 rows: mid-batch kernels; 267: library
+def test_mixed_batch_logits_match_the_fp32_cpu_model(gpu_model, cpu_model, n_ride, new_lens):
+    """New prompts and one decode token of each running sequence in ONE launch: chunk rows through the prefill attention
+    kernel, the riders' rows through the decode kernel, the projections over all rows together."""
+    g = torch.Generator().manual_seed(n_ride)
+    lens = [int(x) for x in torch.randint(5, 90, (n_ride,), generator=g)]
+    running = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in lens]
+    fresh = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in new_lens]
+    mb, nblocks, out = 8, 600, {}
+    for name, model in (("cpu", cpu_model), ("gpu", gpu_model)):
+        dev = model.device
+        cache = model.new_cache(nblocks)
+        t, p, s, meta = _prefill_inputs(running, dev, mb)
+        pre = model.prefill(t, p, s, cache, meta, logits=True)
+        out.setdefault("next", pre.argmax(-1).cpu())                  # the CPU model's tokens feed both
+        used = sum(-(-(n + 1) // 16) for n in lens)
+        tb, pb, sb_, mB = _prefill_inputs(fresh, dev, mb, first_block=used)
+        slotd = torch.stack([meta.block_tables[i, n // 16] * 16 + n % 16 for i, n in enumerate(lens)]).to(torch.int32)
+        rows = torch.cat([mB.last_rows, tb.shape[0] + torch.arange(n_ride, device=dev)])
+        mixed = PrefillMeta(mB.block_tables, mB.seq_info, mB.tiles, rows, mB.q_tiles)
+        riders = DecodeMeta(meta.block_tables, torch.tensor([n + 1 for n in lens], dtype=torch.int32, device=dev),
+                            num_splits=2 if dev.type == "cuda" else 1)
+        out[name] = model.prefill(torch.cat([tb, out["next"].to(dev)]), torch.cat([pb, torch.tensor(lens, dtype=torch.int32, device=dev)]),
+                                  torch.cat([sb_, slotd]), cache, mixed, logits=True, riders=riders)
+    assert tuple(out["gpu"].shape) == (len(new_lens) + n_ride, SMALL.vocab)
+    k = len(new_lens)
+    assert _rel_err(out["gpu"][:k], out["cpu"][:k]) < 0.03, "chunk rows"
+    assert _rel_err(out["gpu"][k:], out["cpu"][k:]) < 0.03, "rider rows"
+
+
+def test_engine_with_mixed_batches_keeps_running_sequences_moving(gpu_model):
+    """Arrivals while others decode: with mixed batches no launch leaves the running sequences out, and both modes produce
+    (near-ties aside) the same text."""
+    g = torch.Generator().manual_seed(5)
+    prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in (30, 200, 120, 64, 90, 150)]
+    outs, counts = [], []
+    for mixed in (True, False):
+        eng = Engine(EngineConfig(model="small", max_num_seqs=16, max_model_len=512, kv_blocks=512, max_num_batched_tokens=128,
+                                  mixed_batches=mixed), model=gpu_model)
+        reqs = []
+        for i, p in enumerate(prompts):                 # one arrival every third step
+            reqs.append(eng.submit(p, 12))
+            for _ in range(3):
+                eng.step()
+        n = 0
+        while not eng.idle():
+            eng.step()
+            n += 1
+            assert n < 2000
+        outs.append([r.out for r in reqs])
+        counts.append(dict(eng.step_counts))
+        assert eng.alloc.free == eng.alloc.total and all(len(r.out) == 12 for r in reqs)
+    assert counts[0]["mixed"] >= 5 and counts[1]["mixed"] == 0
+    assert sum(counts[0].values()) < sum(counts[1].values())          # fewer launches for the same work
+    same = sum(a[:4] == b[:4] for a, b in zip(*outs))
+    assert same >= len(prompts) - 2, outs
+
+
 def _run(engine, prompts, max_tokens):
     reqs = [engine.submit(p, max_tokens) for p in prompts]
     n = 0
@@ -181,7 +239,7 @@ def test_chunked_prefill_on_the_gpu_gives_the_first_token_of_the_unchunked_run(g
                                   max_num_batched_tokens=budget), model=gpu_model)
         firsts.append([o[0] for o in _run(eng, prompts, 2)])
         if budget == 64:
-            assert eng.step_counts["prefill"] >= sum(-(-len(p) // 64) for p in prompts) // 2
+            assert eng.step_counts["prefill"] + eng.step_counts["mixed"] >= sum(-(-len(p) // 64) for p in prompts) // 2
         assert eng.alloc.free == eng.alloc.total
     agree = sum(a == b for a, b in zip(*firsts))
     assert agree >= len(prompts) - 1, firsts

@@ -124,26 +124,36 @@ def test_late_arrivals_join_the_running_batch(model):
     assert b.out == dense_generate(model, [9, 8, 7], 6)
 
 
-def test_long_prompts_are_prefilled_in_chunks_between_decode_steps(model):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_long_prompts_are_prefilled_in_chunks_next_to_decode_steps(model, mixed):
     """A 16-token budget turns 45- and 70-token prompts into 3 and 5 launches whose later chunks attend to
-    the earlier ones through the paged cache; a request already decoding gets a token between chunks."""
+    the earlier ones through the paged cache. A request already decoding gets a token between chunks
+    (mixed_batches off) or inside every chunk launch (on: it never waits for a prefill)."""
     eng = _engine(model, max_num_batched_tokens=16, max_model_len=128)
+    eng.cfg.mixed_batches = mixed
     g = torch.Generator().manual_seed(9)
     short = [4, 8, 15, 16, 23, 42]
     a = eng.submit(short, 12)
     eng.step()                                                        # `a` is decoding from here on
     longs = [torch.randint(0, TINY.vocab, (n,), generator=g).tolist() for n in (45, 70)]
     rs = [eng.submit(p, 5) for p in longs]
-    kinds, gaps, last = [], [], len(a.out)
+    kinds, gained = [], []
     while not eng.idle():
-        before = dict(eng.step_counts)
+        before, had, was_running = dict(eng.step_counts), len(a.out), not a.done.is_set()
         eng.step()
-        kinds.append("P" if eng.step_counts["prefill"] > before["prefill"] else "D")
-        if not a.done.is_set() or len(a.out) != last:
-            gaps.append(len(a.out) - last)
-            last = len(a.out)
-    assert eng.step_counts["prefill"] >= 1 + 3 + 5 - 1                 # chunks of different requests share launches
-    assert "PP" not in "".join(kinds[:12])                             # while `a` runs, every chunk is followed by a decode
+        kinds.append("P" if eng.step_counts["prefill"] > before["prefill"] else
+                     "M" if eng.step_counts["mixed"] > before["mixed"] else "D")
+        if was_running:
+            gained.append(len(a.out) - had)
+    k = "".join(kinds)
+    if mixed:
+        assert eng.step_counts["mixed"] >= 3 + 5 - 1 and k.startswith("MMMMMMM")
+        assert all(n == 1 for n in gained)                             # a token in EVERY launch, prefill or not
+        assert eng.step_counts["mixed"] + eng.step_counts["prefill"] + eng.step_counts["decode"] == len(kinds) + 1
+    else:
+        assert eng.step_counts["mixed"] == 0
+        assert eng.step_counts["prefill"] >= 1 + 3 + 5 - 1             # chunks of different requests share launches
+        assert "PP" not in k[:12]                                      # while `a` runs, every chunk is followed by a decode
     assert a.out == dense_generate(model, short, 12)
     for p, r in zip(longs, rs):
         assert r.out == dense_generate(model, p, 5)
@@ -225,7 +235,7 @@ def test_http_server_and_open_loop_load(model):
             assert json.load(urllib.request.urlopen(srv.url + "/v1/models", timeout=5))["data"][0]["id"] == "tiny"
             tr = json.load(urllib.request.urlopen(srv.url + "/trace", timeout=5))
             ev = [e for e in tr["traceEvents"] if e["ph"] == "X"]
-            assert {e["cat"] for e in ev} == {"prefill", "decode"} and all(e["dur"] > 0 for e in ev)
+            assert {"prefill", "decode"} <= {e["cat"] for e in ev} <= {"prefill", "mixed", "decode"} and all(e["dur"] > 0 for e in ev)
             assert sum(e["args"]["tokens"] for e in ev if e["cat"] == "decode") + sum(1 for e in ev if e["cat"] == "prefill") >= 5
     finally:
         eng.stop()
@@ -320,13 +330,15 @@ def test_cpu_dispatch_of_the_ops_matches_the_reference():
     assert llm.pick_q_tiles([2048], 4, 8) == 1 and llm.pick_q_tiles([4096], 4, 8) == 2
 
 
-def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model):
+@pytest.mark.parametrize("mixed,blocks", [(False, 10), (True, 10), (True, 6)])
+def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model, mixed, blocks):
     """Random arrivals and lengths against 10 blocks: whatever the interleaving of prefill, decode
     and preemption, no block is held twice or leaked, every request finishes with exactly the
     tokens of the dense forward, and the counters add up."""
     import random
     rng = random.Random(7)
-    eng = _engine(model, kv_blocks=10, max_model_len=96, max_num_seqs=5, max_num_batched_tokens=24)   # prompts get chunked
+    eng = _engine(model, kv_blocks=blocks, max_model_len=96, max_num_seqs=5, max_num_batched_tokens=24)   # prompts get chunked
+    eng.cfg.mixed_batches = mixed
     reqs, steps = [], 0
     while len(reqs) < 14 or not eng.idle():
         if len(reqs) < 14 and rng.random() < 0.4:
@@ -340,7 +352,8 @@ def test_random_traffic_with_a_tight_cache_keeps_every_invariant(model):
         assert len(held) + eng.alloc.free == eng.alloc.total, "blocks leaked"
         assert all(not r.blocks and r.prefilled == 0 for r in eng.waiting)
         assert len(eng.running) + len(eng.prefilling) <= 5
-    assert eng.metrics.preemptions > 0, "the scenario is meant to preempt"
+    if (mixed, blocks) != (True, 10):          # mixed batches drain this traffic before 10 blocks run out
+        assert eng.metrics.preemptions > 0, "the scenario is meant to preempt"
     for p, r in reqs:
         assert r.done.is_set() and r.error is None
         assert r.out == dense_generate(model, p, r.max_tokens), f"request {r.rid} (preempted {r.preempted}x)"

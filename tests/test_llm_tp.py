@@ -59,7 +59,7 @@ def test_two_rank_model_and_engine_match_the_unsharded_model():
     r0 = [r for r in res if r["rank"] == 0][0]
     assert r0["engine_tokens_match"] and r0["engine_done"] and r0["engine_tokens"] == 24, r0
     assert "injected launch failure" in r0["failed_request_error"] and all(r["engine_errors"] == 1 for r in res)
-    assert r0["engine_counts"]["prefill"] >= 3            # 242 prompt tokens at 96 per launch: chunked
+    assert r0["engine_counts"]["prefill"] + r0["engine_counts"]["mixed"] >= 3 and r0["engine_counts"]["mixed"] >= 1   # 242 prompt tokens at 96 per launch: chunked, running sequences ride along
 
 
 @pytest.mark.timeout(300)

@@ -182,6 +182,7 @@ class LlamaModel:
         self.fp8_decode = False
         self.skinny_limit: Optional[int] = None                    # overrides skinny_rows() (benchmarks)
         self.mid_limit: Optional[int] = None                       # overrides mid_rows()
+        self.fused_rope = True                                     # skinny decode path: RoPE + cache write inside the attention kernel
         self.lm_head8: Optional[torch.Tensor] = None
         self.lm_head_s: Optional[torch.Tensor] = None
 
@@ -247,9 +248,10 @@ class LlamaModel:
             h = tp.all_reduce(torch.matmul(act, L["w_down"].t()))
         return llm.rmsnorm(h, g, cfg.eps, residual=residual)
 
-    def _stack_skinny(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
+    def _stack_skinny(self, tokens, positions, slots, cache: KVCache, attend, rope: bool = True) -> torch.Tensor:
         """Batch <= 16: every projection is one pass of the skinny kernel over its weights, with the
-        norm / residual add / SwiGLU fused in; `h` is the residual stream, updated in place."""
+        norm / residual add / SwiGLU fused in; `h` is the residual stream, updated in place.
+        `rope=False`: `attend` takes the un-rotated qkv and does RoPE + the cache write itself."""
         cfg, tp = self.lcfg, self.tp
         f8 = self.fp8_decode
         # the residual add rides on rank 0's partial product; the all-reduce then yields the new residual stream
@@ -263,7 +265,8 @@ class LlamaModel:
         h = self.embed[tokens]
         for li, L in enumerate(self.layers):
             qkv = lin(h, L, "wqkv", rms=True)
-            llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
+            if rope:
+                llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
             a = attend(qkv, cache.k[li], cache.v[li])
             tp.all_reduce(lin(a, L, "wo", out=h, **res(h)))
             act = lin(h, L, "w_gate_up", rms=True, epilogue="swiglu")
@@ -353,15 +356,21 @@ class LlamaModel:
 
     def decode(self, tokens, positions, slots, cache: KVCache, meta: DecodeMeta, logits: bool = False) -> torch.Tensor:
         """One token per sequence -> greedy next token ids [B] (int64), or the logits [B, vocab].
-        Capture-safe."""
+        `positions` are `meta.ctx_lens - 1` (the token being decoded is the last of its context). Capture-safe."""
         cfg = self.lcfg
 
         def attend(qkv, kc, vc):
             return llm.paged_attn_decode(qkv, kc, vc, meta.block_tables, meta.ctx_lens, self.scale, cfg.n_q,
                                          num_splits=meta.num_splits, workspace=meta.workspace)
 
+        def attend_rope(qkv, kc, vc):
+            # launch-bound regime: rotation and cache write ride inside the attention kernel (one launch less per layer)
+            return llm.paged_attn_decode_rope(qkv, kc, vc, meta.block_tables, meta.ctx_lens, slots, self.cos_sin, self.scale,
+                                              cfg.n_q, num_splits=meta.num_splits, workspace=meta.workspace)
+
         if self.skinny(tokens.shape[0]):
-            h = self._stack_skinny(tokens, positions, slots, cache, attend)
+            fused = self.fused_rope and self.device.type == "cuda" and cache.k.dtype == torch.bfloat16
+            h = self._stack_skinny(tokens, positions, slots, cache, attend_rope if fused else attend, rope=not fused)
             if self.fp8_decode:
                 out = llm.skinny_linear(h, self.lm_head8, rms=True, eps=cfg.eps, weight_scale=self.lm_head_s, tiled=True)
             else:

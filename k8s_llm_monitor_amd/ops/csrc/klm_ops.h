@@ -93,6 +93,12 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
 // token of the tile}; a tile covers q_tiles * 64 / (n_q / n_kv) query tokens (q_tiles = 16-row
 // query tiles per wave: 1, 2 or 4). variant 0: every wave loads K/V fragments from global memory
 // itself (short prompts); 1: the block stages K/V once through a 4-stage LDS ring (long prompts).
+// RoPE (q and the newest key) and the cache write of the newest key / value inside the decode attention kernel;
+// qkv is the un-rotated activation [B][q_stride >= (n_q + 2 n_kv) * 128], the caches are bf16.
+int klm_paged_attn_decode_rope(const void* qkv, void* k_cache, void* v_cache, const int32_t* block_tables,
+                               const int32_t* ctx_lens, const int32_t* slots, const float* cos_sin, void* out, float* tmp_o,
+                               float* tmp_ml, int B, int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total,
+                               int num_splits, float scale, int max_pos, void* stream);
 int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cache, const int32_t* block_tables,
                            const int32_t* seq_info, const int32_t* tiles, void* out, int n_tiles, int n_seqs,
                            int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total, float scale,

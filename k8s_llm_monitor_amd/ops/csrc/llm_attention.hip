@@ -197,14 +197,43 @@ __device__ __forceinline__ void attend_range(const KvView& kv, const bf16x8 (&qf
 
 constexpr int OPAD = HD + 4;
 
+// RoPE inside the decode kernel (bf16 cache): the query rows are rotated in registers, and the wave that owns the step
+// holding the newest token rotates that token's key, writes key and value into the cache and patches them into the
+// fragments it has just loaded, so no separate rope / cache-write launch runs before the attention.
+struct RopeArgs {
+  const float* cos_sin;   // [max_pos][128]: cos of the 64 pairs, then sin
+  const int* slots;       // [B] cache slot of the newest token (< 0: write nothing)
+  int max_pos;
+  int num_slots;
+};
+
+// x[s] holds dims s*32 + fq*8 .. +8: the partner of a dim d < 64 is d + 64 = fragment s + 2 of the same lane.
+// Same arithmetic and rounding as rope_cache_kernel (llm_elementwise.hip).
+__device__ __forceinline__ void rope_frags(bf16x8 (&x)[4], const float* cs, int fq) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float* c = cs + s * 32 + fq * 8;
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(c + 64), s1 = *reinterpret_cast<const f32x4*>(c + 68);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float cc = i < 4 ? c0[i & 3] : c1[i & 3], sn = i < 4 ? s0[i & 3] : s1[i & 3];
+      const float a = (float)x[s][i], b = (float)x[s + 2][i];
+      x[s][i] = (__bf16)(a * cc - b * sn);
+      x[s + 2][i] = (__bf16)(b * cc + a * sn);
+    }
+  }
+}
+
 // Decode: one token per sequence. Block = (kv head, sequence, split); its 4 waves take the
 // 32-token steps of the split round-robin and are combined through LDS.
-template <bool KV8>
+template <bool KV8, bool ROPE = false>
 __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
-    const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+    const uint16_t* __restrict__ q, const uint16_t* kc, const uint16_t* vc,
     const int* __restrict__ block_tables, const int* __restrict__ ctx_lens, uint16_t* __restrict__ out,
     float* __restrict__ tmp_o, float* __restrict__ tmp_ml, int q_stride, int n_q, int n_kv, int G,
-    int max_blocks, int nb_total, int num_splits, float scale_log2) {
+    int max_blocks, int nb_total, int num_splits, float scale_log2, RopeArgs ra) {
+  static_assert(!(KV8 && ROPE), "the fused rope path writes a bf16 cache");
   __shared__ float sm_o[4][16][OPAD];
   __shared__ float sm_m[4][16], sm_l[4][16];
   const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
@@ -238,7 +267,57 @@ __global__ __launch_bounds__(256) void paged_attn_decode_kernel(
   for (int n = 0; n < 8; ++n) a.o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   a.m = -INFINITY;
   a.l = 0.f;
-  attend_range<KV8>(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, ctx - 1, scale_log2, a);
+  if (ROPE) {
+    int pos = ctx - 1;
+    pos = pos < 0 ? 0 : (pos >= ra.max_pos ? ra.max_pos - 1 : pos);
+    const float* cs = ra.cos_sin + (size_t)pos * HD;
+    if (valid) rope_frags(qf, cs, fq);
+    const int last = total_steps - 1;
+    // wave w takes steps s_begin + w, + 4, ...: exactly one wave of one split owns the step of the newest token
+    const bool owner = ctx > 0 && last >= s_begin && last < s_end && ((last - s_begin) & 3) == w;
+    if (!owner) {
+      attend_range<KV8>(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, ctx - 1, scale_log2, a);
+    } else {
+      attend_range<KV8>(kv, qf, s_begin + w, last, 4, fr, fq, qpos, ctx - 1, scale_log2, a);
+      Frags f;
+      load_step<KV8>(kv, last, fr, fq, f);       // the newest token's slot holds stale bytes: patched below
+      const int idx = (ctx - 1) & 31, tok = idx & 15;
+      const int slot = ra.slots[b];
+      const bool store = slot >= 0 && slot < ra.num_slots;
+      const size_t cbase = ((size_t)(store ? slot / BLK : 0) * n_kv + h) * BLK_ELEMS;
+      const uint16_t* krow = q + (size_t)b * q_stride + ((size_t)n_q + h) * HD;
+      const uint16_t* vrow = krow + (size_t)n_kv * HD;
+      // K: load_step gives lane fr the token rows t*4 + ((fr>>2)&1)*8 + (fr&3) of block fr>>3
+      if (fr == (idx >> 4) * 8 + (tok >> 3) * 4 + (tok & 3)) {
+        bf16x8 kn[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) kn[s4] = *reinterpret_cast<const bf16x8*>(krow + s4 * 32 + fq * 8);
+        rope_frags(kn, cs, fq);
+        uint16_t* kw = const_cast<uint16_t*>(kc) + cbase + (size_t)(slot % BLK) * HD + fq * 8;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          if ((tok >> 2) & 1) f.k[1][s4] = kn[s4]; else f.k[0][s4] = kn[s4];
+          if (store) *reinterpret_cast<bf16x8*>(kw + s4 * 32) = kn[s4];
+        }
+      }
+      // V^T: lane (fr, fq) holds dims n*16 + fr for the 8 tokens (fq&1)*8 .. +8 of block fq>>1
+      if (fq == (idx >> 4) * 2 + (tok >> 3)) {
+        uint16_t* vw = const_cast<uint16_t*>(vc) + cbase + (slot % BLK);
+        const int e = tok & 7;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const uint16_t raw = vrow[n * 16 + fr];
+          const __bf16 val = __builtin_bit_cast(__bf16, raw);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f.v[n][j] = (j == e) ? val : f.v[n][j];
+          if (store) vw[(size_t)(n * 16 + fr) * BLK] = raw;
+        }
+      }
+      attend_step(f, qf, last, fq, qpos, ctx - 1, scale_log2, a);
+    }
+  } else {
+    attend_range<KV8>(kv, qf, s_begin + w, s_end, 4, fr, fq, qpos, ctx - 1, scale_log2, a);
+  }
 
 #pragma unroll
   for (int n = 0; n < 8; ++n) *reinterpret_cast<f32x4*>(&sm_o[w][fr][n * 16 + fq * 4]) = a.o[n];
@@ -596,14 +675,46 @@ int klm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
     return KLM_ERR_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float scale_log2 = scale * 1.4426950408889634f;
+  const RopeArgs none{nullptr, nullptr, 0, 0};
   if (kv_fp8)
-    hipLaunchKernelGGL(paged_attn_decode_kernel<true>, dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
+    hipLaunchKernelGGL((paged_attn_decode_kernel<true, false>), dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
                        (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, ctx_lens, (uint16_t*)out,
-                       tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2);
+                       tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2, none);
   else
-    hipLaunchKernelGGL(paged_attn_decode_kernel<false>, dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
+    hipLaunchKernelGGL((paged_attn_decode_kernel<false, false>), dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)q,
                        (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, ctx_lens, (uint16_t*)out,
-                       tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2);
+                       tmp_o, tmp_ml, q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2, none);
+  if (hipGetLastError() != hipSuccess) return KLM_ERR_HIP;
+  if (num_splits > 1)
+    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)B * n_q), dim3(128), 0, s, tmp_o, tmp_ml, ctx_lens,
+                       (uint16_t*)out, n_q, max_blocks, num_splits);
+  return launch_status();
+}
+
+// Decode attention straight from the un-rotated qkv activation [B][(n_q + 2 n_kv) * 128] (bf16 cache): RoPE on q and on
+// the newest key, and the cache write of the newest key / value, happen inside the attention kernel. The position of
+// sequence b's token is ctx_lens[b] - 1; `slots[b]` is its cache slot (< 0: padded row, nothing is written).
+int klm_paged_attn_decode_rope(const void* qkv, void* k_cache, void* v_cache, const int32_t* block_tables,
+                               const int32_t* ctx_lens, const int32_t* slots, const float* cos_sin, void* out, float* tmp_o,
+                               float* tmp_ml, int B, int q_stride, int n_q, int n_kv, int max_blocks, int num_blocks_total,
+                               int num_splits, float scale, int max_pos, void* stream) {
+  if (q_stride < (n_q + 2 * n_kv) * HD || q_stride % 8 != 0) return KLM_ERR_SHAPE;
+  if (B <= 0 || B > 65535 || n_q <= 0 || n_kv <= 0 || n_q % n_kv != 0 || max_blocks <= 0 || num_blocks_total <= 0 || max_pos <= 0 ||
+      (int64_t)num_blocks_total * BLK > INT32_MAX)
+    return KLM_ERR_SHAPE;
+  const int G = n_q / n_kv;
+  if (group_shift(G) < 0) return KLM_ERR_SHAPE;
+  if (num_splits < 1 || num_splits > 256) return KLM_ERR_ARG;
+  if (!qkv || !k_cache || !v_cache || !block_tables || !ctx_lens || !slots || !cos_sin || !out) return KLM_ERR_ARG;
+  if (num_splits > 1 && (!tmp_o || !tmp_ml)) return KLM_ERR_ARG;
+  if (!aligned16(qkv) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out) || !aligned16(tmp_o) || !aligned16(cos_sin))
+    return KLM_ERR_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float scale_log2 = scale * 1.4426950408889634f;
+  const RopeArgs ra{cos_sin, slots, max_pos, num_blocks_total * BLK};
+  hipLaunchKernelGGL((paged_attn_decode_kernel<false, true>), dim3(n_kv, B, num_splits), dim3(256), 0, s, (const uint16_t*)qkv,
+                     (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, ctx_lens, (uint16_t*)out, tmp_o, tmp_ml,
+                     q_stride, n_q, n_kv, G, max_blocks, num_blocks_total, num_splits, scale_log2, ra);
   if (hipGetLastError() != hipSuccess) return KLM_ERR_HIP;
   if (num_splits > 1)
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)B * n_q), dim3(128), 0, s, tmp_o, tmp_ml, ctx_lens,

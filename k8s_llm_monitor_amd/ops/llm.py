@@ -35,6 +35,8 @@ def _lib():
         lib.klm_silu_mul.argtypes = [vp, vp, i, i, vp]
         lib.klm_rope_cache.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i64, i, vp]
         lib.klm_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, vp]
+        lib.klm_paged_attn_decode_rope.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, vp]
+        lib.klm_paged_attn_decode_rope.restype = i
         lib.klm_paged_attn_prefill.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, f, i, i, i, vp]
         lib.klm_skinny_linear.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, f, i, i, i, i, vp]
         lib.klm_skinny_linear_w8.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, f, i, i, i, i, vp]
@@ -452,6 +454,44 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
                                       block_tables.shape[1], nb, int(num_splits), float(scale), _kv8(k_cache),
                                       _stream(q))
     _check(rc, f"klm_paged_attn_decode(B={B},splits={num_splits})")
+    return out
+
+
+def paged_attn_decode_rope(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
+                           ctx_lens: torch.Tensor, slots: torch.Tensor, cos_sin: torch.Tensor, scale: float, n_q: int,
+                           out: Optional[torch.Tensor] = None, num_splits: int = 1,
+                           workspace: Optional[DecodeWorkspace] = None) -> torch.Tensor:
+    """`rope_cache` + `paged_attn_decode` in one launch (bf16 cache, GPU): `qkv` [B, (n_q + 2 n_kv) * 128] is the UN-rotated
+    projection; sequence b's token sits at position ctx_lens[b] - 1 and goes to cache slot slots[b] (< 0: padded row).
+    q and the newest key are rotated in registers, key / value are written by the one wave that attends to them."""
+    B = block_tables.shape[0]
+    n_kv = k_cache.shape[1]
+    nb = _check_caches(k_cache, v_cache, n_kv)
+    if not qkv.is_cuda or _kv8(k_cache):
+        raise KlmOpsError("paged_attn_decode_rope: GPU and a bf16 cache only (use rope_cache + paged_attn_decode)")
+    if qkv.dim() != 2 or qkv.shape[0] != B or qkv.shape[1] != (n_q + 2 * n_kv) * HEAD_DIM or qkv.stride(1) != 1:
+        raise KlmOpsError(f"paged_attn_decode_rope: qkv {tuple(qkv.shape)} strides {qkv.stride()}")
+    if ctx_lens.shape != (B,) or slots.shape != (B,) or cos_sin.dim() != 2 or cos_sin.shape[1] != HEAD_DIM or \
+            cos_sin.dtype != torch.float32 or not cos_sin.is_contiguous():
+        raise KlmOpsError("paged_attn_decode_rope: ctx_lens [B], slots [B], cos_sin fp32 [max_pos, 128]")
+    _bf16(qkv)
+    _i32(block_tables, ctx_lens, slots)
+    if out is None:
+        out = torch.empty((B, n_q * HEAD_DIM), dtype=qkv.dtype, device=qkv.device)
+    elif tuple(out.shape) != (B, n_q * HEAD_DIM) or not out.is_contiguous():
+        raise KlmOpsError("paged_attn_decode_rope: bad out")
+    tmp_o = tmp_ml = None
+    if num_splits > 1:
+        if workspace is None:
+            workspace = DecodeWorkspace(B, n_q, num_splits, qkv.device)
+        if workspace.max_batch < B or workspace.n_q != n_q or workspace.max_splits < num_splits:
+            raise KlmOpsError("paged_attn_decode_rope: workspace too small")
+        tmp_o, tmp_ml = workspace.tmp_o.data_ptr(), workspace.tmp_ml.data_ptr()
+    rc = _lib().klm_paged_attn_decode_rope(qkv.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
+                                           ctx_lens.data_ptr(), slots.data_ptr(), cos_sin.data_ptr(), out.data_ptr(), tmp_o, tmp_ml,
+                                           B, qkv.stride(0), n_q, n_kv, block_tables.shape[1], nb, int(num_splits), float(scale),
+                                           cos_sin.shape[0], _stream(qkv))
+    _check(rc, f"klm_paged_attn_decode_rope(B={B},splits={num_splits})")
     return out
 
 

@@ -103,6 +103,40 @@ def test_paged_decode_attention_matches_reference(n_q, n_kv, splits):
     assert float(got[-1].float().abs().sum()) == 0.0     # ctx 0 -> zeros
 
 
+@pytest.mark.parametrize("n_q,n_kv", [(32, 8), (4, 4), (16, 1)])
+@pytest.mark.parametrize("splits", [1, 4, 16, 0])
+def test_decode_attention_with_rope_inside_equals_the_two_kernel_sequence(n_q, n_kv, splits):
+    """rope_cache + paged_attn_decode against the one launch that rotates q and the newest key in registers and has the
+    wave that attends to the newest token write its key / value: same output, the same bytes in the caches."""
+    torch.manual_seed(40)
+    ctx = [1, 15, 16, 17, 32, 33, 64, 700, 129, 0, 48, 113]          # newest token on every block / step boundary
+    nb, mb = 120, 48
+    kc, vc = _caches(nb, n_kv)
+    bt = _tables(ctx, nb, mb)
+    cl = torch.tensor(ctx, dtype=torch.int32, device=DEV)
+    B = len(ctx)
+    slots = torch.tensor([bt[i, (c - 1) // 16].item() * 16 + (c - 1) % 16 if c else -1 for i, c in enumerate(ctx)],
+                         dtype=torch.int32, device=DEV)
+    pos = (cl - 1).clamp(min=0)
+    qkv = _rand(B, (n_q + 2 * n_kv) * 128)
+    cs = llm.rope_table(4096, 500000.0, DEV)
+    scale = 1.0 / math.sqrt(128)
+    ns = splits or llm.pick_splits(B, n_kv, mb * 16)
+    k2, v2, two = kc.clone(), vc.clone(), qkv.clone()
+    llm.rope_cache(two, cs, pos, slots, k2, v2, n_q, n_kv)
+    want = llm.paged_attn_decode(two, k2, v2, bt, cl, scale, n_q, num_splits=ns)
+    raw = qkv.clone()
+    got = llm.paged_attn_decode_rope(raw, kc, vc, bt, cl, slots, cs, scale, n_q, num_splits=ns)
+    assert torch.equal(raw, qkv)                                       # the activation is left as it came
+    assert torch.equal(kc, k2) and torch.equal(vc, v2)
+    _close(got, want, 1e-3, 1e-3)
+    assert float((got.float() - want.float()).abs().max()) == 0.0      # in fact the same bits
+    _close(got, ref.paged_attn_decode(two[:, : n_q * 128], k2, v2, bt, cl, scale), 2e-2)
+    assert float(got[9].float().abs().sum()) == 0.0                    # ctx 0 -> zeros, nothing written
+    with pytest.raises(llm.KlmOpsError):
+        llm.paged_attn_decode_rope(raw, kc.to(torch.float8_e4m3fn), vc.to(torch.float8_e4m3fn), bt, cl, slots, cs, scale, n_q)
+
+
 @pytest.mark.parametrize("n_q,n_kv", [(32, 8), (2, 2), (8, 1)])
 @pytest.mark.parametrize("q_tiles", [1, 2, 4])
 @pytest.mark.parametrize("variant", [0, 1])

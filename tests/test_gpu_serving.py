@@ -64,6 +64,14 @@ def test_gpu_logits_match_the_fp32_cpu_model(gpu_model, cpu_model, n_seqs):
     _compare_logits(gpu_model, cpu_model, n_seqs)
 
 
+def test_gpu_logits_with_the_separate_rope_kernel(gpu_model, cpu_model):
+    gpu_model.fused_rope = False                         # skinny path: rope_cache launch + attention instead of the fused kernel
+    try:
+        _compare_logits(gpu_model, cpu_model, 3)
+    finally:
+        gpu_model.fused_rope = True
+
+
 def test_gpu_logits_on_the_library_gemm_path(gpu_model, cpu_model):
     gpu_model.mid_limit = 0                              # batches above 16 rows on hipBLASLt + norm / SwiGLU kernels
     try:

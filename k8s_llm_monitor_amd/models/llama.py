@@ -147,6 +147,8 @@ class PrefillMeta:
 
 
 class LlamaModel:
+    WIDE_ROWS = 208      # largest row count sent to the K-split tiled GEMM (llm.WIDE_MAX_ROWS is what the kernel takes)
+
     """`tp`: a parallel.tp group. With more than one rank this instance holds ONE shard (Megatron layout: q/k/v
     heads, gate/up rows and vocabulary rows split by rank; wo and w_down split along their input, their partial
     products summed by an all-reduce of the residual-stream update) and `lcfg` are its local shapes."""
@@ -182,6 +184,7 @@ class LlamaModel:
         self.fp8_decode = False
         self.skinny_limit: Optional[int] = None                    # overrides skinny_rows() (benchmarks)
         self.mid_limit: Optional[int] = None                       # overrides mid_rows()
+        self.wide = True                                           # 129 - 256 rows on the K-split tiled GEMM (else hipBLASLt)
         self.fused_rope = True                                     # skinny decode path: RoPE + cache write inside the attention kernel
         self.lm_head8: Optional[torch.Tensor] = None
         self.lm_head_s: Optional[torch.Tensor] = None
@@ -296,7 +299,8 @@ class LlamaModel:
 
         # above 64 rows the widest bf16 projection is the one shape where the library GEMM still wins (54 vs 63 us at
         # 128 rows of the 8B gate_up): x staging per 224-row block then rivals the weight stream
-        wide_lib = tokens.shape[0] > 64 and not f8
+        # (from 129 rows on the K-split tiled GEMM takes every projection)
+        wide_lib = 64 < tokens.shape[0] <= llm.MID_MAX_ROWS and not f8
         for li, L in enumerate(self.layers):
             # the kernel that sums the qkv projection's K splits also rotates q / k and fills the cache slots
             qkv = llm.mid_qkv_rope(x, L["wqkv8"] if f8 else L["wqkv"], self.cos_sin, positions, slots, cache.k[li], cache.v[li],
@@ -315,6 +319,11 @@ class LlamaModel:
         (scripts/gpu_mid_bench.py)."""
         if self.mid_limit is not None:
             return self.mid_limit
+        if self.cfg.hidden <= 4096 and not self.fp8_decode and self.wide:
+            # 129 - 208 rows: the same epilogues behind the K-split 256 x 256 GEMM. Llama-3-8B decode step against the
+            # library path: 9.9 vs 10.2 ms at 136 rows, 10.5 vs 11.4 at 160, 11.8 vs 13.4 at 192; behind it from 224 on
+            # (13.0 vs 12.8, 14.2 vs 13.9 at 256), where a 256-row tile is full either way (scripts/exp/ab_wide.py)
+            return self.WIDE_ROWS
         if self.cfg.hidden <= 4096 or self.fp8_decode:
             return llm.MID_MAX_ROWS
         # bf16 weights of wider models: ahead of the library on the 70B shapes up to 64 rows; behind it on the shapes
@@ -327,6 +336,8 @@ class LlamaModel:
         # 31.8 vs 30.7 at 32) and ahead beyond (32.4 vs 38.5 ms at 48, 34.4 vs 37.3 at 64)
         if self.cfg.hidden > 4096 and rows <= 32 and self.mid_limit is None and not self.fp8_decode:
             return False
+        if rows > llm.MID_MAX_ROWS and (c.hidden % 256 or c.qkv_dim % 256 or (2 * c.ffn) % 256):
+            return False                     # the tiled GEMM writes 256 output columns per block
         return (not self.skinny(rows) and rows <= self.mid_rows() and self.device.type == "cuda" and c.hidden % 512 == 0
                 and c.ffn % 512 == 0 and c.qkv_dim % 64 == 0 and c.q_dim % 512 == 0 and (2 * c.ffn) % 64 == 0)
 

@@ -157,34 +157,60 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const uint16_t* __restrict_
 #define KLM_SLOT_B1 32768
 #define KLM_SLOT_A1 49152
 
-__global__ __launch_bounds__(512) void gemm_bf16_256(const uint16_t* __restrict__ A,
-                                                     const uint16_t* __restrict__ B,
-                                                     uint16_t* __restrict__ C, int M, int N, int K) {
+//
+// SPLIT (decode at batch 129 - 256, ops/llm.py `_mid_partials`): the grid's y index picks a K range of `Kc`, the result
+// goes out as fp32 partial sums P[split][M][N] (what the mid-batch epilogues and the RoPE kernel consume), A may have
+// any number of rows <= 256 * tiles (rows past M re-read row M-1 and are not stored) and both operands a row stride.
+// The burner instantiation (SPLIT = false) compiles to the code it had before the template existed.
+template <bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_bf16_256_t(const uint16_t* __restrict__ A,
+                                                       const uint16_t* __restrict__ B,
+                                                       void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int Kc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint16_t* const C = reinterpret_cast<uint16_t*>(Cv);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
   int tm, tn;
-  tile_of_block<8>(blockIdx.x, M >> 8, N >> 8, tm, tn);
+  tile_of_block<8>(blockIdx.x, SPLIT ? (M + 255) >> 8 : M >> 8, N >> 8, tm, tn);
   const int brow = tm << 8, bcol = tn << 8;
 
   // ---- staging addresses. Wave `wid` fills slot rows [wid*16, wid*16+16): 2 pieces.
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
   const uint16_t* pa = A + (size_t)(brow + (wid >> 2) * 128 + (wid & 3) * 16 + srow) * K + schunk * 8;
-  const uint16_t* pb = B + (size_t)(bcol + (wid >> 1) * 64 + (wid & 1) * 16 + srow) * K + schunk * 8;
-  const size_t rowsK8 = (size_t)8 * K;
+  const uint16_t* pb = B + (size_t)(bcol + (wid >> 1) * 64 + (wid & 1) * 16 + srow) * (SPLIT ? ldb : K) + schunk * 8;
+  const size_t rowsK8 = (size_t)8 * (SPLIT ? ldb : K);
+  const size_t ldB = SPLIT ? (size_t)ldb : (size_t)K;
   char* const lw = smem + wid * 2048;  // + stage*65536 + slot + i*1024
+  const uint16_t* pas[2][2] = {{pa, pa}, {pa, pa}};   // SPLIT: the four A rows of this lane, clamped to the last real row
+  if (SPLIT) {
+    const int kbeg = blockIdx.y * Kc;
+    pb += kbeg;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int r = brow + (wid >> 2) * 128 + (wid & 3) * 16 + srow + h * 64 + j * 8;
+        r = r < M ? r : M - 1;
+        pas[h][j] = A + (size_t)r * lda + schunk * 8 + kbeg;
+      }
+  }
 
 #define KLM_ISSUE_A(h, stage, k0)                                                              \
   do {                                                                                         \
+    if (SPLIT) {                                                                               \
+      glds16(pas[h][0] + (k0), lw + (stage) * 65536 + ((h) ? KLM_SLOT_A1 : KLM_SLOT_A0));      \
+      glds16(pas[h][1] + (k0), lw + (stage) * 65536 + ((h) ? KLM_SLOT_A1 : KLM_SLOT_A0) + 1024); \
+      break;                                                                                   \
+    }                                                                                          \
     glds16(pa + (size_t)(h) * 64 * K + (k0), lw + (stage) * 65536 + ((h) ? KLM_SLOT_A1 : KLM_SLOT_A0)); \
     glds16(pa + (size_t)(h) * 64 * K + rowsK8 + (k0),                                          \
            lw + (stage) * 65536 + ((h) ? KLM_SLOT_A1 : KLM_SLOT_A0) + 1024);                   \
   } while (0)
 #define KLM_ISSUE_B(h, stage, k0)                                                              \
   do {                                                                                         \
-    glds16(pb + (size_t)(h) * 32 * K + (k0), lw + (stage) * 65536 + ((h) ? KLM_SLOT_B1 : KLM_SLOT_B0)); \
-    glds16(pb + (size_t)(h) * 32 * K + rowsK8 + (k0),                                          \
+    glds16(pb + (size_t)(h) * 32 * ldB + (k0), lw + (stage) * 65536 + ((h) ? KLM_SLOT_B1 : KLM_SLOT_B0)); \
+    glds16(pb + (size_t)(h) * 32 * ldB + rowsK8 + (k0),                                        \
            lw + (stage) * 65536 + ((h) ? KLM_SLOT_B1 : KLM_SLOT_B0) + 1024);                   \
   } while (0)
 
@@ -234,7 +260,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const uint16_t* __restrict_
 #define KLM_ISSUE_A(h, stage, k0) do { } while (0)
 #define KLM_ISSUE_B(h, stage, k0) do { } while (0)
 #endif
-  const int nt = K >> 6;
+  const int nt = (SPLIT ? Kc : K) >> 6;
 
   // ---- prologue: stage K tile 0 into stage 0 in need order A0,B0 | B1 | A1
   KLM_ISSUE_A(0, 0, 0);
@@ -314,7 +340,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const uint16_t* __restrict_
         for (int ni = 0; ni < 2; ++ni) {
           const int m = brow + wr * 128 + ah * 64 + mi * 16 + fr;
           const int n = bcol + wc * 64 + bh * 32 + ni * 16 + fq * 4;
-          store_c4(C, (size_t)m * N + n, acc[ah][bh][mi][ni]);
+          if (SPLIT) {
+            float* const P = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.y * M * N;
+            if (m < M) *reinterpret_cast<f32x4*>(P + (size_t)m * N + n) = acc[ah][bh][mi][ni];
+          } else {
+            store_c4(C, (size_t)m * N + n, acc[ah][bh][mi][ni]);
+          }
         }
 }
 
@@ -333,16 +364,55 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     if ((M & 255) || (N & 255) || (K & 63) || K < 128) return KLM_ERR_SHAPE;
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)gemm_bf16_256, hipFuncAttributeMaxDynamicSharedMemorySize,
+      if (hipFuncSetAttribute((const void*)gemm_bf16_256_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               131072) != hipSuccess)
         return KLM_ERR_HIP;
       attr_set = true;
     }
     const int grid = (M >> 8) * (N >> 8);
-    hipLaunchKernelGGL(gemm_bf16_256, dim3(grid), dim3(512), 131072, s, (const uint16_t*)A,
-                       (const uint16_t*)B, (uint16_t*)C, M, N, K);
+    hipLaunchKernelGGL(gemm_bf16_256_t<false>, dim3(grid), dim3(512), 131072, s, (const uint16_t*)A,
+                       (const uint16_t*)B, (void*)C, M, N, K, K, K, K);
   } else {
     return KLM_ERR_VARIANT;
   }
+  return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+}
+
+// K split chosen for `P[ks][M][N] = A[M][K] . B[N][K]^T` on the 256 x 256 kernel: as many splits as still fit one wave of
+// blocks on the 256 CUs, at most 8 (every split writes M x N fp32 partials) and at least 256 k per block.
+extern "C" int klm_gemm_bf16_splitk_plan(int M, int N, int K, int* ksplit) {
+  if (!ksplit) return KLM_ERR_ARG;
+  if (M <= 0 || N <= 0 || (N & 255) || K < 256 || (K & 63)) return KLM_ERR_SHAPE;
+  const int tiles = ((M + 255) >> 8) * (N >> 8);
+  int ks = *ksplit;
+  if (ks <= 0) {
+    ks = 1;
+    while (ks < 8 && tiles * ks * 2 <= 256 && K % (ks * 2 * 64) == 0 && K / (ks * 2) >= 256) ks *= 2;
+  }
+  if (K % (ks * 64) != 0 || K / ks < 128) return KLM_ERR_SHAPE;
+  *ksplit = ks;
+  return KLM_OK;
+}
+
+// fp32 partial sums of a K-split GEMM for activations of up to a few hundred rows (decode at batch 129 - 256):
+// part[ksplit][M][N]; A bf16 [M][>= K] with row stride lda, B bf16 [N][>= K] with row stride ldb, N % 256 == 0.
+extern "C" int klm_gemm_bf16_splitk(const void* A, int lda, const void* B, int ldb, float* part, int M, int N, int K,
+                                    int ksplit, void* stream) {
+  if (!A || !B || !part) return KLM_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)part) & 15) return KLM_ERR_ALIGN;
+  if (M <= 0 || N <= 0 || (N & 255) || lda < K || ldb < K || (lda & 7) || (ldb & 7)) return KLM_ERR_SHAPE;
+  int ks = ksplit;
+  const int rc = klm_gemm_bf16_splitk_plan(M, N, K, &ks);
+  if (rc != KLM_OK) return rc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_256_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) !=
+        hipSuccess)
+      return KLM_ERR_HIP;
+    attr_set = true;
+  }
+  const int tiles = ((M + 255) >> 8) * (N >> 8);
+  hipLaunchKernelGGL(gemm_bf16_256_t<true>, dim3(tiles, ks), dim3(512), 131072, (hipStream_t)stream, (const uint16_t*)A,
+                     (const uint16_t*)B, (void*)part, M, N, K, lda, ldb, K / ks);
   return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
 }

@@ -80,6 +80,11 @@ int klm_silu_mul(const void* gate_up, void* out, int T, int F, void* stream);
 int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, const int32_t* slots,
                    void* k_cache, void* v_cache, int T, int n_q, int n_kv, int max_pos, int64_t num_slots,
                    int kv_fp8, void* stream);
+// K-split variant of the 256 x 256 bf16 GEMM for decode at batch 129 - 256: fp32 partial sums part[ksplit][M][N]
+// (N % 256 == 0, K % (ksplit * 64) == 0; ksplit 0 = chosen by klm_gemm_bf16_splitk_plan).
+int klm_gemm_bf16_splitk_plan(int M, int N, int K, int* ksplit);
+int klm_gemm_bf16_splitk(const void* A, int lda, const void* B, int ldb, float* part, int M, int N, int K, int ksplit,
+                         void* stream);
 // Decode attention: q (row b at q + b*q_stride elements, n_q heads of 128), block_tables[B][max_blocks],
 // ctx_lens[B] -> out[B][n_q][128]. q_stride lets q be a view of the fused qkv activation.
 // num_splits > 1 splits each context over that many blocks (flash decoding); then

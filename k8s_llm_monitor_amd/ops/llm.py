@@ -48,6 +48,9 @@ def _lib():
         lib.klm_mid_epilogue.argtypes = [vp, i, i, i, i, vp, vp, f, vp]
         lib.klm_rope_cache_from_partials.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i64, i, vp]
         lib.klm_mid_linear_swiglu.argtypes = [vp, i, vp, i, vp, vp, i, i, i, i, i, vp]
+        lib.klm_gemm_bf16_splitk_plan.argtypes = [i, i, i, ip]
+        lib.klm_gemm_bf16_splitk.argtypes = [vp, i, vp, i, vp, i, i, i, i, vp]
+        lib.klm_gemm_bf16_splitk_plan.restype = lib.klm_gemm_bf16_splitk.restype = i
         for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_linear_w8", "klm_mid_epilogue", "klm_rope_cache_from_partials",
                   "klm_mid_linear_swiglu"):
             getattr(lib, n).restype = i
@@ -233,12 +236,23 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, rms: bool = False, epil
 
 
 MID_MAX_ROWS = 128
+WIDE_MAX_ROWS = 256      # 129 - 256 rows: the K-split 256 x 256 MFMA GEMM (gemm_bf16.hip) writes the same fp32 partials
 _MID_KINDS = {"none": 0, "swiglu": 1, "res_rms": 2}
 
 
-def mid_ok(M: int, N: int, K: int) -> bool:
-    """Shapes the mid-batch kernel takes (decode at batch 17 - 128, short prefill chunks)."""
-    return 0 < M <= MID_MAX_ROWS and N % 64 == 0 and K % 512 == 0
+def mid_ok(M: int, N: int, K: int, fp8: bool = False) -> bool:
+    """Shapes the mid-batch path takes: up to 128 rows on the weight-streaming kernel (decode at batch 17 - 128, short
+    prefill chunks), 129 - 256 rows of bf16 weights on the K-split 256 x 256 GEMM."""
+    if 0 < M <= MID_MAX_ROWS:
+        return N % 64 == 0 and K % 512 == 0
+    return MID_MAX_ROWS < M <= WIDE_MAX_ROWS and not fp8 and N % 256 == 0 and K % 512 == 0
+
+
+def wide_plan(M: int, N: int, K: int, ksplit: int = 0) -> int:
+    """K split of the 256 x 256 GEMM for these shapes (0: the launcher's choice)."""
+    ks = ctypes.c_int(ksplit)
+    _check(_lib().klm_gemm_bf16_splitk_plan(M, N, K, ctypes.byref(ks)), f"klm_gemm_bf16_splitk_plan({M},{N},{K})")
+    return ks.value
 
 
 def mid_plan(M: int, N: int, K: int, ksplit: int = 0, waves: int = 0, row_tiles: int = 0):
@@ -252,9 +266,15 @@ def _mid_partials(x, weight, weight_scale, ksplit: int = 0, waves: int = 0, row_
     """The main kernel of the mid-batch path: fp32 partial sums [ksplit][M][N] (operands already checked)."""
     N, K = weight.shape
     M = x.shape[0]
+    st = _stream(x)
+    if M > MID_MAX_ROWS:                       # compute-heavy side of the range: the tiled GEMM, same partial layout
+        ks = wide_plan(M, N, K, ksplit)
+        part = torch.empty((ks, M, N), dtype=torch.float32, device=x.device)
+        _check(_lib().klm_gemm_bf16_splitk(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), part.data_ptr(),
+                                           M, N, K, ks, st), f"klm_gemm_bf16_splitk(M={M},N={N},K={K},ks={ks})")
+        return part, ks
     ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
     part = torch.empty((ks, M, N), dtype=torch.float32, device=x.device)
-    st = _stream(x)
     if weight_scale is not None:
         rc = _lib().klm_mid_linear_w8(x.data_ptr(), x.stride(0), weight.data_ptr(), weight_scale.data_ptr(), part.data_ptr(),
                                       M, N, K, ks, nw, rt, st)
@@ -274,7 +294,8 @@ def _mid_check(x, weight, weight_scale, what: str) -> None:
     if w8 and (not weight.is_contiguous() or tuple(weight_scale.shape) != (N,) or weight_scale.dtype != torch.float32
                or not weight_scale.is_contiguous() or not weight_scale.is_cuda):
         raise KlmOpsError(f"{what}: fp8 weights must be contiguous (tiled) with a contiguous fp32 scale [N] on the GPU")
-    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or weight.stride(1) != 1 or weight.stride(0) < K or not mid_ok(x.shape[0], N, K):
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < K or weight.stride(1) != 1 or weight.stride(0) < K or \
+            not mid_ok(x.shape[0], N, K, w8):
         raise KlmOpsError(f"{what}: x {tuple(x.shape)} weight {tuple(weight.shape)}")
 
 
@@ -341,7 +362,7 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residu
     elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
         raise KlmOpsError("mid_linear: bad out")
     st = _stream(x)
-    if k == 1:
+    if k == 1 and M <= MID_MAX_ROWS:
         ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
         if ks == 1:                       # no K split: the activation is applied inside the main kernel, no epilogue launch
             _check(_lib().klm_mid_linear_swiglu(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),

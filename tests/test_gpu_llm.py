@@ -386,6 +386,37 @@ def test_mid_linear_matches_reference(M, N, K):
     _close(got, hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5), 3e-2, 2e-2)
 
 
+@pytest.mark.parametrize("M", [129, 200, 256])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (28672, 4096), (256, 512)])
+def test_mid_linear_from_129_rows_runs_the_k_split_tiled_gemm(M, N, K):
+    """129 - 256 rows: the 256 x 256 MFMA GEMM with a K split writes the fp32 partials, the mid-batch epilogues finish
+    them (rows past M of the last tile are neither read out of bounds nor stored)."""
+    torch.manual_seed(33)
+    x, w = _rand(M, K), _rand(N, K, scale=0.03)
+    assert llm.mid_ok(M, N, K) and not llm.mid_ok(M, N, K, fp8=True) and not llm.mid_ok(257, N, K)
+    ks = llm.wide_plan(M, N, K)
+    assert K % (ks * 64) == 0 and (N // 256) * ks <= 256
+    want = x.float() @ w.float().t()
+    guard = torch.full((M + 1, N), 7.0, device=DEV, dtype=torch.bfloat16)          # a row behind `out` must stay untouched
+    got = llm.mid_linear(x, w, out=guard[:M])
+    _close(got, want, 5e-2, 2e-2)
+    assert bool((guard[M] == 7.0).all())
+    _close(llm.mid_linear(x, w, kind="swiglu"), ref.silu_mul(want), 5e-2, 2e-2)
+    for forced in (1, 2, 8):
+        if K % (forced * 64) == 0 and K // forced >= 128:
+            _close(llm.mid_linear(x, w, ksplit=forced), want, 5e-2, 2e-2)
+    if N <= 16384:
+        res = _rand(M, N)
+        new_res = (res.float() + want).to(torch.bfloat16)
+        r2 = res.clone()
+        y = llm.mid_linear(x, w, kind="res_rms", residual=r2)
+        _close(r2, new_res, 5e-2, 2e-2)
+        _close(y, ref.rmsnorm(new_res, torch.ones(N, device=DEV, dtype=torch.bfloat16), 1e-5)[0], 5e-2, 2e-2)
+    xs = _rand(M, K + 64)[:, :K]                                                # strided activation rows
+    ws = _rand(N, K + 128, scale=0.03)[:, :K]
+    _close(llm.mid_linear(xs, ws), xs.float() @ ws.float().t(), 5e-2, 2e-2)
+
+
 @pytest.mark.parametrize("ksplit,waves,rt", [(1, 4, 1), (4, 8, 1), (8, 4, 2), (2, 8, 2), (8, 4, 1), (16, 8, 2)])
 def test_mid_linear_every_configuration_gives_the_same_product(ksplit, waves, rt):
     torch.manual_seed(32)
@@ -425,7 +456,9 @@ def test_mid_linear_reads_strided_operands_and_rejects_bad_shapes():
     w = wbig[:, :1024]
     _close(llm.mid_linear(x, w), x.float() @ w.float().t(), 5e-2, 2e-2)
     with pytest.raises(llm.KlmOpsError):
-        llm.mid_linear(_rand(129, 1024), w)
+        llm.mid_linear(_rand(257, 1024), w)                # beyond the tiled GEMM's range
+    with pytest.raises(llm.KlmOpsError):
+        llm.mid_linear(_rand(129, 1024), _rand(320, 1024)) # 129 rows and more need N % 256 == 0
     with pytest.raises(llm.KlmOpsError):
         llm.mid_linear(_rand(8, 1000), _rand(512, 1000))
 
@@ -448,11 +481,11 @@ def test_mid_linear_with_fp8_tiled_weights_matches_the_dequantised_reference(M, 
 
 
 @pytest.mark.parametrize("kv8", [False, True])
-@pytest.mark.parametrize("T", [17, 64, 100])
+@pytest.mark.parametrize("T", [17, 64, 100, 200])
 def test_mid_qkv_rope_equals_the_three_kernel_sequence(T, kv8):
     """mid_qkv_rope = mid_linear + rope_cache with the split-sum folded into the rope kernel: same bits everywhere."""
     torch.manual_seed(51)
-    n_q, n_kv, K, nb = 8, 2, 1024, 12
+    n_q, n_kv, K, nb = 8, 2, 1024, max(12, T // 16 + 2)
     N = (n_q + 2 * n_kv) * 128
     x, w = _rand(T, K), _rand(N, K, scale=0.05)
     cos_sin = llm.rope_table(512, 500000.0, DEV)

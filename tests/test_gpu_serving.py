@@ -58,9 +58,9 @@ def _rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max())
 
 
-@pytest.mark.parametrize("n_seqs", [3, 20, 40])      # decode on the skinny kernel (3) and on the mid-batch kernel (20, 40)
+@pytest.mark.parametrize("n_seqs", [3, 20, 40, 150])  # decode on the skinny kernel (3), the mid-batch kernel (20, 40), the K-split GEMM (150)
 def test_gpu_logits_match_the_fp32_cpu_model(gpu_model, cpu_model, n_seqs):
-    assert gpu_model.skinny(3) and gpu_model.mid(20) and gpu_model.mid(40) and not gpu_model.mid(129)
+    assert gpu_model.skinny(3) and gpu_model.mid(20) and gpu_model.mid(40) and gpu_model.mid(129) and gpu_model.mid(208) and not gpu_model.mid(224)
     _compare_logits(gpu_model, cpu_model, n_seqs)
 
 
@@ -97,7 +97,7 @@ def _compare_logits(gpu_model, cpu_model, n_seqs, kv_dtype=None, tol=0.03):
     g = torch.Generator().manual_seed(n_seqs)
     lens = [int(x) for x in torch.randint(5, 90, (n_seqs,), generator=g)]
     prompts = [torch.randint(0, SMALL.vocab, (n,), generator=g).tolist() for n in lens]
-    mb, nblocks = 8, 300
+    mb, nblocks = 8, max(300, 6 * n_seqs + 8)
     out = {}
     for name, model in (("cpu", cpu_model), ("gpu", gpu_model)):
         dev = model.device

@@ -13,12 +13,13 @@ MI355X-first choices:
     over a tensor-parallel group (parallel/tp.py): the same code with local shapes and two all-reduces
     per layer on the xGMI mesh kernels.
   * attention, RMSNorm(+residual), RoPE+cache write and SwiGLU are the kernels of ops/csrc/llm_*.hip.
-    Decode is a weight-streaming problem up to ~128 rows, and three paths cover it (`skinny`, `mid`,
-    `_trunk` pick by batch size, model width and weight format, all from measurements):
-    the skinny MFMA kernel (batch <= 16: norm, residual add and SwiGLU fused in, 4 weight passes + rope +
-    attention per layer), the mid-batch kernel (17 - 128 rows: x staged through LDS, split-K, epilogues that
-    fuse the residual add + RMSNorm and SwiGLU), and beyond that, as for prefill, plain library GEMMs
-    (hipBLASLt through torch.matmul), fused where the operands allow it (one qkv GEMM, one gate_up GEMM).
+    Decode is a weight-streaming problem up to ~128 rows, and four paths cover it (`skinny`, `mid_spans`,
+    `_trunk` pick by row count, model width and weight format, all from measurements):
+    the skinny MFMA kernel (batch <= 16: norm, residual add and SwiGLU fused in, RoPE + cache write inside the
+    attention kernel: 4 weight passes + attention per layer), the mid-batch kernel (17 - 128 rows: x staged through
+    LDS, split-K, epilogues that fuse the residual add + RMSNorm, SwiGLU and RoPE + cache write), the K-split
+    256 x 256 MFMA GEMM behind the same epilogues (129 - 256 rows), and beyond that, as for long prefill, plain library
+    GEMMs (hipBLASLt through torch.matmul), fused where the operands allow it (one qkv GEMM, one gate_up GEMM).
   * weight layout chosen for those kernels: RMSNorm gains are folded into the columns of the
     projection that consumes the norm, and gate/up rows are interleaved by 8 (ops.llm.interleave_gate_up).
   * decode is launch-bound at small batch (about 10 launches x layers), so the engine captures it
@@ -183,7 +184,8 @@ class LlamaModel:
         self.scale = 1.0 / math.sqrt(HEAD_DIM)
         self.fp8_decode = False
         self.skinny_limit: Optional[int] = None                    # overrides skinny_rows() (benchmarks)
-        self.mid_limit: Optional[int] = None                       # overrides mid_rows()
+        self.mid_limit: Optional[int] = None                       # overrides mid_spans(): rows 1 .. mid_limit
+        self.wide_from: Optional[int] = None                       # rows from which the tiled GEMM also replaces the mid-batch kernel
         self.wide = True                                           # 129 - 256 rows on the K-split tiled GEMM (else hipBLASLt)
         self.fused_rope = True                                     # skinny decode path: RoPE + cache write inside the attention kernel
         self.lm_head8: Optional[torch.Tensor] = None
@@ -285,10 +287,12 @@ class LlamaModel:
         residual = self.embed[tokens]
         x = llm.rmsnorm(residual, self.unit_gain, cfg.eps)
 
+        tiled = self.wide_from is not None and tokens.shape[0] >= self.wide_from and not f8   # below 129 rows: by policy
+
         def lin(y, L, name, **kw):
             if f8:
                 return llm.mid_linear(y, L[name + "8"], weight_scale=L[name + "_s"], eps=cfg.eps, **kw)
-            return llm.mid_linear(y, L[name], eps=cfg.eps, **kw)
+            return llm.mid_linear(y, L[name], eps=cfg.eps, wide=tiled, **kw)
 
         def close(y, L, name):
             """residual += y @ W^T (summed over the tensor-parallel ranks); -> its norm"""
@@ -300,11 +304,11 @@ class LlamaModel:
         # above 64 rows the widest bf16 projection is the one shape where the library GEMM still wins (54 vs 63 us at
         # 128 rows of the 8B gate_up): x staging per 224-row block then rivals the weight stream
         # (from 129 rows on the K-split tiled GEMM takes every projection)
-        wide_lib = 64 < tokens.shape[0] <= llm.MID_MAX_ROWS and not f8
+        wide_lib = 64 < tokens.shape[0] <= llm.MID_MAX_ROWS and not f8 and not tiled
         for li, L in enumerate(self.layers):
             # the kernel that sums the qkv projection's K splits also rotates q / k and fills the cache slots
             qkv = llm.mid_qkv_rope(x, L["wqkv8"] if f8 else L["wqkv"], self.cos_sin, positions, slots, cache.k[li], cache.v[li],
-                                   cfg.n_q, cfg.n_kv, weight_scale=L["wqkv_s"] if f8 else None)
+                                   cfg.n_q, cfg.n_kv, weight_scale=L["wqkv_s"] if f8 else None, wide=tiled)
             x = close(attend(qkv, cache.k[li], cache.v[li]), L, "wo")
             if wide_lib:
                 act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
@@ -313,33 +317,37 @@ class LlamaModel:
             x = close(act, L, "w_down")
         return x
 
-    def mid_rows(self) -> int:
-        """Largest batch on the mid-batch kernel (beyond skinny_rows()). Per layer it beats hipBLASLt + separate norm /
-        SwiGLU kernels by 15 - 23 % on the 8B shapes at 24 - 128 rows and by 6 - 14 % on the 70B shapes at 32 - 64
-        (scripts/gpu_mid_bench.py)."""
+    def mid_spans(self):
+        """Row intervals [lo, hi] (beyond skinny_rows()) whose projections run on the mid-batch path: the weight-streaming
+        kernel up to 128 rows, the K-split tiled GEMM above, both with fused epilogues; everything else is hipBLASLt +
+        separate norm / rope / SwiGLU kernels. Measured per model class on one MI355X, whole decode step at ctx 1024:
+
+        hidden <= 4096 (Llama-3-8B): ahead at every row count up to 208 (15 - 23 % per layer at 24 - 128 rows,
+            scripts/gpu_mid_bench.py; 9.9 vs 10.2 ms at 136 rows, 11.8 vs 13.4 at 192), behind from 224 on (14.2 vs 13.9 ms
+            at 256), where the library's 256-row tile is full too (scripts/exp/ab_wide.py);
+        hidden <= 8192 (Llama-3-70B): level up to 32 rows (31.8 vs 30.7 ms), ahead beyond: 31.0 vs 35.2 ms at 40 rows,
+            36.8 vs 45.0 at 80, 43.5 vs 49.1 at 128, 45.1 vs 58.1 at 136, 58.2 vs 74.7 at 256 (scripts/exp/ab_wide_70b.py);
+        wider (a llama3-405b / tp8 shard: narrow, deep projections): the library wins up to 96 rows (34.7 vs 36.7 ms at 64)
+            and ties at 136 - 192; ahead at 128 (45.9 vs 47.8) and at 256 (59.1 vs 66.4) (scripts/exp/ab_wide_405b_shard.py);
+        fp8 decode weights: the weight-streaming kernel reads the e4m3 copies, up to its 128 rows."""
         if self.mid_limit is not None:
-            return self.mid_limit
-        if self.cfg.hidden <= 4096 and not self.fp8_decode and self.wide:
-            # 129 - 208 rows: the same epilogues behind the K-split 256 x 256 GEMM. Llama-3-8B decode step against the
-            # library path: 9.9 vs 10.2 ms at 136 rows, 10.5 vs 11.4 at 160, 11.8 vs 13.4 at 192; behind it from 224 on
-            # (13.0 vs 12.8, 14.2 vs 13.9 at 256), where a 256-row tile is full either way (scripts/exp/ab_wide.py)
-            return self.WIDE_ROWS
-        if self.cfg.hidden <= 4096 or self.fp8_decode:
-            return llm.MID_MAX_ROWS
-        # bf16 weights of wider models: ahead of the library on the 70B shapes up to 64 rows; behind it on the shapes
-        # of a 405B / tp8 shard (37.3 vs 34.7 ms per step at 64 rows), whose projections are narrow and very deep
-        return 64 if self.cfg.hidden <= 8192 else 0
+            return [(1, self.mid_limit)]
+        if self.fp8_decode:
+            return [(1, llm.MID_MAX_ROWS)]
+        h = self.cfg.hidden
+        if h <= 4096:
+            return [(1, self.WIDE_ROWS if self.wide else llm.MID_MAX_ROWS)]
+        if h <= 8192:
+            return [(33, llm.WIDE_MAX_ROWS if self.wide else llm.MID_MAX_ROWS)]
+        return [(97, llm.MID_MAX_ROWS)] + ([(193, llm.WIDE_MAX_ROWS)] if self.wide else [])
 
     def mid(self, rows: int) -> bool:
         c = self.lcfg
-        # wide models: whole-model decode is level with the library path up to 32 rows (70B: 31.0 vs 31.3 ms at 24,
-        # 31.8 vs 30.7 at 32) and ahead beyond (32.4 vs 38.5 ms at 48, 34.4 vs 37.3 at 64)
-        if self.cfg.hidden > 4096 and rows <= 32 and self.mid_limit is None and not self.fp8_decode:
-            return False
         if rows > llm.MID_MAX_ROWS and (c.hidden % 256 or c.qkv_dim % 256 or (2 * c.ffn) % 256):
             return False                     # the tiled GEMM writes 256 output columns per block
-        return (not self.skinny(rows) and rows <= self.mid_rows() and self.device.type == "cuda" and c.hidden % 512 == 0
-                and c.ffn % 512 == 0 and c.qkv_dim % 64 == 0 and c.q_dim % 512 == 0 and (2 * c.ffn) % 64 == 0)
+        return (not self.skinny(rows) and any(lo <= rows <= hi for lo, hi in self.mid_spans()) and self.device.type == "cuda"
+                and c.hidden % 512 == 0 and c.ffn % 512 == 0 and c.qkv_dim % 64 == 0 and c.q_dim % 512 == 0
+                and (2 * c.ffn) % 64 == 0)
 
     def _trunk(self, tokens, positions, slots, cache: KVCache, attend) -> torch.Tensor:
         """The decoder stack on the path that fits the number of rows -> the final norm [T, hidden]."""

@@ -262,12 +262,17 @@ def mid_plan(M: int, N: int, K: int, ksplit: int = 0, waves: int = 0, row_tiles:
     return ks.value, nw.value, rt.value
 
 
-def _mid_partials(x, weight, weight_scale, ksplit: int = 0, waves: int = 0, row_tiles: int = 0):
+def _wide(M: int, N: int, K: int, fp8: bool, wide: Optional[bool]) -> bool:
+    """Does the K-split tiled GEMM produce the partial sums? Always past 128 rows; below only when asked and possible."""
+    return M > MID_MAX_ROWS or bool(wide and not fp8 and N % 256 == 0 and K % 512 == 0)
+
+
+def _mid_partials(x, weight, weight_scale, ksplit: int = 0, waves: int = 0, row_tiles: int = 0, wide: Optional[bool] = None):
     """The main kernel of the mid-batch path: fp32 partial sums [ksplit][M][N] (operands already checked)."""
     N, K = weight.shape
     M = x.shape[0]
     st = _stream(x)
-    if M > MID_MAX_ROWS:                       # compute-heavy side of the range: the tiled GEMM, same partial layout
+    if _wide(M, N, K, weight_scale is not None, wide):   # compute-heavy side of the range: the tiled GEMM, same partial layout
         ks = wide_plan(M, N, K, ksplit)
         part = torch.empty((ks, M, N), dtype=torch.float32, device=x.device)
         _check(_lib().klm_gemm_bf16_splitk(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), part.data_ptr(),
@@ -301,7 +306,7 @@ def _mid_check(x, weight, weight_scale, what: str) -> None:
 
 def mid_qkv_rope(x: torch.Tensor, wqkv: torch.Tensor, cos_sin: torch.Tensor, positions: torch.Tensor, slots: torch.Tensor,
                  k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int,
-                 weight_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 weight_scale: Optional[torch.Tensor] = None, wide: Optional[bool] = None) -> torch.Tensor:
     """``rope_cache(mid_linear(x, wqkv))`` in two launches instead of three: the kernel that sums the projection's K
     splits also rotates q and k and writes k / v into their cache slots. Bit-identical to the separate kernels."""
     T = x.shape[0]
@@ -315,7 +320,7 @@ def mid_qkv_rope(x: torch.Tensor, wqkv: torch.Tensor, cos_sin: torch.Tensor, pos
         raise KlmOpsError("mid_qkv_rope: cos_sin must be fp32 [max_pos, 128]")
     _mid_check(x, wqkv, weight_scale, "mid_qkv_rope")
     _i32(positions, slots)
-    part, ks = _mid_partials(x, wqkv, weight_scale)
+    part, ks = _mid_partials(x, wqkv, weight_scale, wide=wide)
     qkv = torch.empty((T, N), dtype=x.dtype, device=x.device)
     rc = _lib().klm_rope_cache_from_partials(part.data_ptr(), ks, qkv.data_ptr(), cos_sin.data_ptr(), positions.data_ptr(),
                                              slots.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), T, n_q, n_kv,
@@ -326,8 +331,9 @@ def mid_qkv_rope(x: torch.Tensor, wqkv: torch.Tensor, cos_sin: torch.Tensor, pos
 
 def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, eps: float = 1e-5, ksplit: int = 0, waves: int = 0,
-               row_tiles: int = 0, weight_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``x[M,K] @ weight[N,K].T`` for M <= 128 with the weight streamed from HBM once (llm_mid.hip), finished by
+               row_tiles: int = 0, weight_scale: Optional[torch.Tensor] = None, wide: Optional[bool] = None) -> torch.Tensor:
+    """``x[M,K] @ weight[N,K].T`` for M <= 128 with the weight streamed from HBM once (llm_mid.hip), or for M <= 256 (and on
+    request, `wide=True`, below 129 rows too) on the K-split 256 x 256 GEMM (gemm_bf16.hip, bf16 weights), finished by
     `kind`: "none" -> [M,N]; "swiglu" (gate/up rows interleaved by 8) -> [M,N/2]; "res_rms": `residual` [M,N] is
     updated in place with the product and its RMSNorm (unit gain) is returned.
     `weight` is bf16 row-major (rows may be further apart than K), or e4m3 in the tiled order of `tile_weights` with
@@ -362,14 +368,14 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residu
     elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
         raise KlmOpsError("mid_linear: bad out")
     st = _stream(x)
-    if k == 1 and M <= MID_MAX_ROWS:
+    if k == 1 and not _wide(M, N, K, w8, wide):
         ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
         if ks == 1:                       # no K split: the activation is applied inside the main kernel, no epilogue launch
             _check(_lib().klm_mid_linear_swiglu(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0),
                                                 weight_scale.data_ptr() if w8 else None, out.data_ptr(), M, N, K, nw, rt, st),
                    f"klm_mid_linear_swiglu(M={M},N={N},K={K},nw={nw},rt={rt},fp8={w8})")
             return out
-    part, ks = _mid_partials(x, weight, weight_scale, ksplit, waves, row_tiles)
+    part, ks = _mid_partials(x, weight, weight_scale, ksplit, waves, row_tiles, wide=wide)
     _check(_lib().klm_mid_epilogue(part.data_ptr(), ks, M, N, k, out.data_ptr(),
                                    residual.data_ptr() if residual is not None else None, float(eps), st),
            f"klm_mid_epilogue(M={M},N={N},{kind})")

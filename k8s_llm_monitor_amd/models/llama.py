@@ -225,7 +225,7 @@ class LlamaModel:
         head = self.lm_head.numel()
         if self.fp8_decode and self.skinny(rows):
             return layers + head
-        if self.fp8_decode and self.mid(rows):
+        if self.fp8_decode and self.mid(rows) and rows <= llm.MID_MAX_ROWS:
             return layers + 2 * head
         return 2 * (layers + head)
 
@@ -283,7 +283,7 @@ class LlamaModel:
         (ops/csrc/llm_mid.hip), whose epilogue does what `_stack` needs a kernel of its own for: the residual add +
         RMSNorm after wo and w_down, SwiGLU after gate_up. Returns the final norm of the residual stream."""
         cfg, tp = self.lcfg, self.tp
-        f8 = self.fp8_decode
+        f8 = self.fp8_decode and tokens.shape[0] <= llm.MID_MAX_ROWS      # the e4m3 copies serve the weight-streaming kernel only
         residual = self.embed[tokens]
         x = llm.rmsnorm(residual, self.unit_gain, cfg.eps)
 
@@ -332,14 +332,17 @@ class LlamaModel:
         fp8 decode weights: the weight-streaming kernel reads the e4m3 copies, up to its 128 rows."""
         if self.mid_limit is not None:
             return [(1, self.mid_limit)]
-        if self.fp8_decode:
-            return [(1, llm.MID_MAX_ROWS)]
         h = self.cfg.hidden
+        # past 128 rows the tiled GEMM reads the bf16 weights, whatever the decode weight format
+        above = [] if not self.wide else [(129, self.WIDE_ROWS)] if h <= 4096 else [(129, llm.WIDE_MAX_ROWS)] if h <= 8192 \
+            else [(193, llm.WIDE_MAX_ROWS)]
+        if self.fp8_decode:
+            return [(1, llm.MID_MAX_ROWS)] + above
         if h <= 4096:
-            return [(1, self.WIDE_ROWS if self.wide else llm.MID_MAX_ROWS)]
+            return [(1, llm.MID_MAX_ROWS)] + above
         if h <= 8192:
-            return [(33, llm.WIDE_MAX_ROWS if self.wide else llm.MID_MAX_ROWS)]
-        return [(97, llm.MID_MAX_ROWS)] + ([(193, llm.WIDE_MAX_ROWS)] if self.wide else [])
+            return [(33, llm.MID_MAX_ROWS)] + above
+        return [(97, llm.MID_MAX_ROWS)] + above
 
     def mid(self, rows: int) -> bool:
         c = self.lcfg

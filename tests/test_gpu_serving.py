@@ -86,6 +86,9 @@ def test_fp8_decode_weights_match_the_fp32_cpu_model_with_the_dequantised_weight
     c = LlamaModel(SMALL, "cpu", seed=0, dtype=torch.float32).load_from(g)     # the dequantised weights, no fp8
     assert g.layers[0]["w_down8"].dtype == torch.float8_e4m3fn and not c.fp8_decode
     _compare_logits(g, c, 5)
+    # past 128 rows the same model decodes on the tiled GEMM over its bf16 weights (which hold the dequantised values)
+    assert g.mid(150) and g.decode_stream_bytes(150) == 2 * g.decode_stream_bytes(5)
+    _compare_logits(g, c, 150)
 
 
 def test_fp8_kv_cache_stays_close_to_the_bf16_cache_model(gpu_model, cpu_model):

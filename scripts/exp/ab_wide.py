@@ -11,7 +11,7 @@ eng = Engine(EngineConfig(model="llama3-8b", max_num_seqs=256, max_model_len=409
 eng.buckets = [136, 160, 192, 224, 240, 256]            # time row counts that only prompt chunks / mixed batches see, too
 for rep in range(2):
     for wide in (True, False):
-        eng.model.wide = wide
+        eng.model.mid_limit = 256 if wide else 0          # every row count on either path, whatever the policy says
         eng._graphs.clear()
         row = {"k_split_gemm": wide}
         for b in eng.buckets:

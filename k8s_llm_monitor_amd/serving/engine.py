@@ -585,6 +585,9 @@ class Engine:
                 "graphs": sorted(self._graphs), "device": str(self.device),
                 "decode_weights": "fp8 (W8A16, batch <= 128)" if self.model.fp8_decode else "bf16",
                 "kv_cache_dtype": self.cfg.kv_cache_dtype, "mixed_batches": self.cfg.mixed_batches,
+                # which kernels a launch of n rows runs on (rows outside these ranges: hipBLASLt + separate norm / rope / SwiGLU)
+                "kernel_paths": {"skinny_rows": self.model.skinny_rows(), "mid_spans": [list(x) for x in self.model.mid_spans()],
+                                 "fused_rope_attention": bool(self.model.fused_rope and self.on_gpu and self.kv_dtype is None)},
                 "max_num_batched_tokens": self.cfg.max_num_batched_tokens,
                 "step_seconds": dict(self.step_seconds), "step_counts": dict(self.step_counts),
                 "tensor_parallel": self.tp.describe(), "errors": self.errors, "last_error": self.last_error}

@@ -148,7 +148,7 @@ class PrefillMeta:
 
 
 class LlamaModel:
-    WIDE_ROWS = 208      # largest row count sent to the K-split tiled GEMM (llm.WIDE_MAX_ROWS is what the kernel takes)
+    WIDE_ROWS = 256      # largest row count an 8B-class model sends to the K-split tiled GEMM (see lib_projections)
 
     """`tp`: a parallel.tp group. With more than one rank this instance holds ONE shard (Megatron layout: q/k/v
     heads, gate/up rows and vocabulary rows split by rank; wo and w_down split along their input, their partial
@@ -186,6 +186,7 @@ class LlamaModel:
         self.skinny_limit: Optional[int] = None                    # overrides skinny_rows() (benchmarks)
         self.mid_limit: Optional[int] = None                       # overrides mid_spans(): rows 1 .. mid_limit
         self.wide_from: Optional[int] = None                       # rows from which the tiled GEMM also replaces the mid-batch kernel
+        self.lib_proj: Optional[frozenset] = None                 # overrides lib_projections() (benchmarks)
         self.wide = True                                           # 129 - 256 rows on the K-split tiled GEMM (else hipBLASLt)
         self.fused_rope = True                                     # skinny decode path: RoPE + cache write inside the attention kernel
         self.lm_head8: Optional[torch.Tensor] = None
@@ -294,8 +295,13 @@ class LlamaModel:
                 return llm.mid_linear(y, L[name + "8"], weight_scale=L[name + "_s"], eps=cfg.eps, **kw)
             return llm.mid_linear(y, L[name], eps=cfg.eps, wide=tiled, **kw)
 
+        lib = self.lib_projections(tokens.shape[0]) if tiled or tokens.shape[0] > llm.MID_MAX_ROWS else frozenset()
+
         def close(y, L, name):
             """residual += y @ W^T (summed over the tensor-parallel ranks); -> its norm"""
+            if name in lib:
+                h = tp.all_reduce(torch.matmul(y, L[name].t()))
+                return llm.rmsnorm(h, self.unit_gain, cfg.eps, residual=residual)
             if tp.world == 1:
                 return lin(y, L, name, kind="res_rms", residual=residual)
             h = tp.all_reduce(lin(y, L, name))
@@ -310,7 +316,7 @@ class LlamaModel:
             qkv = llm.mid_qkv_rope(x, L["wqkv8"] if f8 else L["wqkv"], self.cos_sin, positions, slots, cache.k[li], cache.v[li],
                                    cfg.n_q, cfg.n_kv, weight_scale=L["wqkv_s"] if f8 else None, wide=tiled)
             x = close(attend(qkv, cache.k[li], cache.v[li]), L, "wo")
-            if wide_lib:
+            if wide_lib or "w_gate_up" in lib:
                 act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
             else:
                 act = lin(x, L, "w_gate_up", kind="swiglu")
@@ -322,9 +328,9 @@ class LlamaModel:
         kernel up to 128 rows, the K-split tiled GEMM above, both with fused epilogues; everything else is hipBLASLt +
         separate norm / rope / SwiGLU kernels. Measured per model class on one MI355X, whole decode step at ctx 1024:
 
-        hidden <= 4096 (Llama-3-8B): ahead at every row count up to 208 (15 - 23 % per layer at 24 - 128 rows,
-            scripts/gpu_mid_bench.py; 9.9 vs 10.2 ms at 136 rows, 11.8 vs 13.4 at 192), behind from 224 on (14.2 vs 13.9 ms
-            at 256), where the library's 256-row tile is full too (scripts/exp/ab_wide.py);
+        hidden <= 4096 (Llama-3-8B): ahead at every row count (15 - 23 % per layer at 24 - 128 rows,
+            scripts/gpu_mid_bench.py; 9.9 vs 10.2 ms at 136 rows, 11.4 vs 13.4 at 192, 13.6 vs 13.9 at 256 with the
+            projections of lib_projections() left on the library; scripts/exp/ab_wide.py, ab_wide_mix.py);
         hidden <= 8192 (Llama-3-70B): level up to 32 rows (31.8 vs 30.7 ms), ahead beyond: 31.0 vs 35.2 ms at 40 rows,
             36.8 vs 45.0 at 80, 43.5 vs 49.1 at 128, 45.1 vs 58.1 at 136, 58.2 vs 74.7 at 256 (scripts/exp/ab_wide_70b.py);
         wider (a llama3-405b / tp8 shard: narrow, deep projections): the library wins up to 96 rows (34.7 vs 36.7 ms at 64)
@@ -343,6 +349,19 @@ class LlamaModel:
         if h <= 8192:
             return [(33, llm.MID_MAX_ROWS)] + above
         return [(97, llm.MID_MAX_ROWS)] + above
+
+    def lib_projections(self, rows: int) -> frozenset:
+        """Projections that stay on hipBLASLt inside the tiled-GEMM range (129 - 256 rows). Llama-3-8B, whole decode step
+        (scripts/exp/ab_wide_mix.py): with gate_up (28672 x 4096: 112 tiles, two K splits, 59 MB of partial sums) on the
+        library 12.06 -> 11.40 ms at 192 rows; with wo there as well 13.01 -> 12.50 ms at 224 and 14.25 -> 13.63 at 256
+        (all library: 13.37 / 12.76 / 13.94)."""
+        if self.lib_proj is not None:
+            return self.lib_proj
+        if self.cfg.hidden <= 4096:
+            return frozenset(("w_gate_up", "wo")) if rows > 208 else frozenset(("w_gate_up",))
+        if self.cfg.hidden <= 8192:          # Llama-3-70B: 49.7 -> 48.3 ms at 192 rows, 56.7 -> 56.3 at 256 (w_down is where
+            return frozenset(("w_gate_up",))  # the library loses: 72.5 ms at 256 rows with it there too)
+        return frozenset()
 
     def mid(self, rows: int) -> bool:
         c = self.lcfg

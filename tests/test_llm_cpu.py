@@ -385,3 +385,25 @@ def test_decode_buckets_are_powers_of_two_and_their_midpoints():
     for lim in (1, 3, 16, 17, 100, 256):
         b = _buckets(lim)
         assert b == sorted(set(b)) and b[-1] == lim                       # every batch up to the limit has a bucket
+
+
+def test_kernel_path_policy_per_model_class(model):
+    """mid_spans / lib_projections are tables of measurements (docs/KERNELS.md): pin them, by model width."""
+    from dataclasses import replace
+    m = LlamaModel(TINY, "cpu", seed=1, dtype=torch.float32)
+    assert m.mid_spans() == [(1, 128), (129, 256)]                              # 8B class
+    assert m.lib_projections(192) == {"w_gate_up"} and m.lib_projections(230) == {"w_gate_up", "wo"}
+    m.cfg = replace(m.cfg, hidden=8192)                                         # 70B class
+    assert m.mid_spans() == [(33, 128), (129, 256)] and m.lib_projections(256) == {"w_gate_up"}
+    m.cfg = replace(m.cfg, hidden=16384)                                        # a 405B / tp8 shard
+    assert m.mid_spans() == [(97, 128), (193, 256)] and m.lib_projections(256) == frozenset()
+    m.fp8_decode = True
+    assert m.mid_spans() == [(1, 128), (193, 256)]                              # e4m3 copies up to 128 rows, bf16 tiles above
+    m.wide = False
+    assert m.mid_spans() == [(1, 128)]
+    m.mid_limit = 40
+    assert m.mid_spans() == [(1, 40)]
+    assert not m.mid(20)                                                        # and never on the CPU
+    eng = _engine(model)
+    d = eng.describe()["kernel_paths"]
+    assert d["skinny_rows"] == 16 and d["mid_spans"] == [[1, 128], [129, 256]] and d["fused_rope_attention"] is False

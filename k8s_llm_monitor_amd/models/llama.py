@@ -333,15 +333,16 @@ class LlamaModel:
             projections of lib_projections() left on the library; scripts/exp/ab_wide.py, ab_wide_mix.py);
         hidden <= 8192 (Llama-3-70B): level up to 32 rows (31.8 vs 30.7 ms), ahead beyond: 31.0 vs 35.2 ms at 40 rows,
             36.8 vs 45.0 at 80, 43.5 vs 49.1 at 128, 45.1 vs 58.1 at 136, 58.2 vs 74.7 at 256 (scripts/exp/ab_wide_70b.py);
-        wider (a llama3-405b / tp8 shard: narrow, deep projections): the library wins up to 96 rows (34.7 vs 36.7 ms at 64)
-            and ties at 136 - 192; ahead at 128 (45.9 vs 47.8) and at 256 (59.1 vs 66.4) (scripts/exp/ab_wide_405b_shard.py);
+        wider (a llama3-405b / tp8 shard: narrow, deep projections): the library wins up to 96 rows (34.7 vs 36.7 ms at 64);
+            ahead at 128 (45.9 vs 47.8), by 1 % at 136 - 192 and by 16 % at 256 (57.2 vs 66.3 ms) with wo left on the
+            library (scripts/exp/ab_wide_405b_shard.py);
         fp8 decode weights: the weight-streaming kernel reads the e4m3 copies, up to its 128 rows."""
         if self.mid_limit is not None:
             return [(1, self.mid_limit)]
         h = self.cfg.hidden
         # past 128 rows the tiled GEMM reads the bf16 weights, whatever the decode weight format
         above = [] if not self.wide else [(129, self.WIDE_ROWS)] if h <= 4096 else [(129, llm.WIDE_MAX_ROWS)] if h <= 8192 \
-            else [(193, llm.WIDE_MAX_ROWS)]
+            else [(129, llm.WIDE_MAX_ROWS)]
         if self.fp8_decode:
             return [(1, llm.MID_MAX_ROWS)] + above
         if h <= 4096:
@@ -361,7 +362,9 @@ class LlamaModel:
             return frozenset(("w_gate_up", "wo")) if rows > 208 else frozenset(("w_gate_up",))
         if self.cfg.hidden <= 8192:          # Llama-3-70B: 49.7 -> 48.3 ms at 192 rows, 56.7 -> 56.3 at 256 (w_down is where
             return frozenset(("w_gate_up",))  # the library loses: 72.5 ms at 256 rows with it there too)
-        return frozenset()
+        # a llama3-405b / tp8 shard (scripts/exp/ab_wide_405b_shard.py mix): wo (16384 x 2048) is the library's, gate_up is
+        # not (68.6 ms at 256 rows with it there): 48.5 / 53.2 / 57.2 ms at 136 / 192 / 256 rows, all library 49.2 / 53.6 / 66.3
+        return frozenset(("wo",))
 
     def mid(self, rows: int) -> bool:
         c = self.lcfg

@@ -17,9 +17,17 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 model = LlamaModel(PRESETS["llama3-405b"], dev, tp=AbsentPeers(8, dev))
 eng = Engine(EngineConfig(model="llama3-405b", device="cuda:0", max_num_seqs=256, max_model_len=4096, kv_blocks=18000), model=model)
-eng.buckets = [48, 64, 96, 128, 136, 192, 256]
-for name, limit, wide_from in (("tiled gemm", 256, 1), ("mid kernel (<= 128)", 256, None), ("library", 0, None)):
-    model.mid_limit, model.wide_from = limit, wide_from
+MIX = len(sys.argv) > 1 and sys.argv[1] == "mix"
+if MIX:          # which projections of the shard should the tiled GEMM take?
+    eng.buckets = [136, 192, 256]
+    cases = [("all tiled", 256, 1, ()), ("gate_up on library", 256, 1, ("w_gate_up",)), ("wo on library", 256, 1, ("wo",)),
+             ("qkv-side only tiled (wo + gate_up + w_down on library)", 256, 1, ("wo", "w_gate_up", "w_down")),
+             ("w_down on library", 256, 1, ("w_down",)), ("all library", 0, None, ())]
+else:
+    eng.buckets = [48, 64, 96, 128, 136, 192, 256]
+    cases = [("tiled gemm", 256, 1, ()), ("mid kernel (<= 128)", 256, None, ()), ("library", 0, None, ())]
+for name, limit, wide_from, lib in cases:
+    model.mid_limit, model.wide_from, model.lib_proj = limit, wide_from, frozenset(lib)
     eng._graphs.clear()
     row = {"path": name}
     for b in eng.buckets:

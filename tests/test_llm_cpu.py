@@ -396,9 +396,9 @@ def test_kernel_path_policy_per_model_class(model):
     m.cfg = replace(m.cfg, hidden=8192)                                         # 70B class
     assert m.mid_spans() == [(33, 128), (129, 256)] and m.lib_projections(256) == {"w_gate_up"}
     m.cfg = replace(m.cfg, hidden=16384)                                        # a 405B / tp8 shard
-    assert m.mid_spans() == [(97, 128), (193, 256)] and m.lib_projections(256) == frozenset()
+    assert m.mid_spans() == [(97, 128), (129, 256)] and m.lib_projections(256) == {"wo"}
     m.fp8_decode = True
-    assert m.mid_spans() == [(1, 128), (193, 256)]                              # e4m3 copies up to 128 rows, bf16 tiles above
+    assert m.mid_spans() == [(1, 128), (129, 256)]                              # e4m3 copies up to 128 rows, bf16 tiles above
     m.wide = False
     assert m.mid_spans() == [(1, 128)]
     m.mid_limit = 40

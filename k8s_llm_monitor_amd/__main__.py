@@ -131,9 +131,11 @@ def _cmd_serve_llm_tp_launch(a, argv: Sequence[str]) -> int:
     """--tp N: start N rank processes of this same command (one per GPU) and wait for them."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = a.port
+    while port == a.port:                      # the rendezvous port must not be the one rank 0 will serve HTTP on
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
     procs = []
     for r in range(a.tp):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.tp), MASTER_ADDR="127.0.0.1",

@@ -17,23 +17,35 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def run_ranks(world, args=(), timeout=240):
-    port = free_port()
-    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "tp_worker.py"), *args], cwd=ROOT,
-                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                                       PYTHONPATH=ROOT, OMP_NUM_THREADS="2"),
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    res = []
-    try:
-        for p in procs:
-            so, se = p.communicate(timeout=timeout)
-            assert p.returncode == 0, so[-1500:] + se[-3000:]
-            res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    return res
+RENDEZVOUS_ERRORS = ("Address already in use", "errno: 98", "Connection refused", "Connection reset by peer", "Broken pipe")
+
+
+def run_ranks(world, args=(), timeout=240, attempts=2):
+    """Runs tests/tp_worker.py as `world` processes. The rendezvous port is found by binding and releasing it, which another
+    process can win in between: such a start-up failure (and only that) gets a second attempt on a new port."""
+    for attempt in range(attempts):
+        port = free_port()
+        procs = [subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "tp_worker.py"), *args], cwd=ROOT,
+                                  env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                           PYTHONPATH=ROOT, OMP_NUM_THREADS="2"),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+        res, errs = [], []
+        try:
+            for p in procs:
+                so, se = p.communicate(timeout=timeout)
+                if p.returncode != 0:
+                    errs.append(so[-1500:] + se[-3000:])
+                    continue
+                res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        if not errs:
+            return res
+        if attempt + 1 < attempts and any(m in e for e in errs for m in RENDEZVOUS_ERRORS) and not any("RESULT " in e for e in errs):
+            continue
+        raise AssertionError("\n".join(errs))
 
 
 def test_config_shards():

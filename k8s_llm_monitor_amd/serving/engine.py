@@ -103,12 +103,15 @@ class Request:
 
 
 def _buckets(limit: int) -> List[int]:
-    """Decode batch sizes that get a hipGraph: powers of two, and from 16 on the midpoints (24, 48, 96, ...): a step
-    costs what its bucket costs (Llama-3-8B: 5.6 ms at 48, 6.2 ms at 64), so 40 running sequences should not pay for 64."""
+    """Decode batch sizes that get a hipGraph: powers of two, from 16 on the midpoints (24, 48, 96, ...) and from 128 on the
+    quarter points (160, 224, ...): a step costs what its bucket costs (Llama-3-8B: 5.6 ms at 48, 6.2 ms at 64; 10.5 ms at
+    160, 11.4 ms at 192), so 40 running sequences should not pay for 64, nor 150 for 192."""
     out, b = [], 1
     while b < limit:
         out.append(b)
-        if b >= 16 and b + b // 2 < limit:
+        if b >= 128:
+            out.extend(x for x in (b + b // 4, b + b // 2, b + 3 * b // 4) if x < limit)
+        elif b >= 16 and b + b // 2 < limit:
             out.append(b + b // 2)
         b *= 2
     out.append(limit)

@@ -378,9 +378,10 @@ def test_mid_batch_stack_computes_what_the_library_stack_computes():
     assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
 
 
-def test_decode_buckets_are_powers_of_two_and_their_midpoints():
+def test_decode_buckets_are_powers_of_two_their_midpoints_and_quarter_points_from_128():
     from k8s_llm_monitor_amd.serving.engine import _buckets
-    assert _buckets(256) == [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256]
+    assert _buckets(256) == [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 224, 256]
+    assert _buckets(200) == [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 200] and _buckets(512)[-5:] == [256, 320, 384, 448, 512]
     assert _buckets(8) == [1, 2, 4, 8] and _buckets(1) == [1] and _buckets(40) == [1, 2, 4, 8, 16, 24, 32, 40]
     for lim in (1, 3, 16, 17, 100, 256):
         b = _buckets(lim)

@@ -360,8 +360,11 @@ class LlamaModel:
             return self.lib_proj
         if self.cfg.hidden <= 4096:
             return frozenset(("w_gate_up", "wo")) if rows > 208 else frozenset(("w_gate_up",))
-        if self.cfg.hidden <= 8192:          # Llama-3-70B: 49.7 -> 48.3 ms at 192 rows, 56.7 -> 56.3 at 256 (w_down is where
-            return frozenset(("w_gate_up",))  # the library loses: 72.5 ms at 256 rows with it there too)
+        if self.cfg.hidden <= 8192:
+            # Llama-3-70B: gate_up on the library is worth 1 - 3 % up to 224 rows (49.7 -> 48.3 ms at 192); at 256 the tiled
+            # GEMM with SwiGLU in its tile epilogue (224 tiles, no K split) is ahead (57.1 vs 58.2 ms). w_down is where the
+            # library loses: 72.9 ms at 256 rows with it there too
+            return frozenset(("w_gate_up",)) if rows <= 224 else frozenset()
         # a llama3-405b / tp8 shard (scripts/exp/ab_wide_405b_shard.py mix): wo (16384 x 2048) is the library's, gate_up is
         # not (68.6 ms at 256 rows with it there): 48.5 / 53.2 / 57.2 ms at 136 / 192 / 256 rows, all library 49.2 / 53.6 / 66.3
         return frozenset(("wo",))

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const uint16_t* __restrict_
 // goes out as fp32 partial sums P[split][M][N] (what the mid-batch epilogues and the RoPE kernel consume), A may have
 // any number of rows <= 256 * tiles (rows past M re-read row M-1 and are not stored) and both operands a row stride.
 // The burner instantiation (SPLIT = false) compiles to the code it had before the template existed.
-template <bool SPLIT>
+template <bool SPLIT, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm_bf16_256_t(const uint16_t* __restrict__ A,
                                                        const uint16_t* __restrict__ B,
                                                        void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int Kc) {
@@ -340,7 +340,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_t(const uint16_t* __restric
         for (int ni = 0; ni < 2; ++ni) {
           const int m = brow + wr * 128 + ah * 64 + mi * 16 + fr;
           const int n = bcol + wc * 64 + bh * 32 + ni * 16 + fq * 4;
-          if (SPLIT) {
+          if (SWIGLU) {
+            // gate / up rows of B are interleaved by 8: in a 16-column tile lanes fq 0,1 hold gate, fq 2,3 the matching up
+            // columns (lane ^ 32). One K range only: the activation goes out in bf16, no partial sums, no epilogue launch.
+            f32x4 v = acc[ah][bh][mi][ni], o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = __shfl_xor(v[i], 32);
+            if (fq < 2 && m < M) {
+              f32x4 y;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) y[i] = v[i] / (1.f + __expf(-v[i])) * o[i];
+              store_c4(C, (size_t)m * (N >> 1) + ((n - fq * 4) >> 1) + fq * 4, y);
+            }
+          } else if (SPLIT) {
             float* const P = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.y * M * N;
             if (m < M) *reinterpret_cast<f32x4*>(P + (size_t)m * N + n) = acc[ah][bh][mi][ni];
           } else {
@@ -414,5 +426,24 @@ extern "C" int klm_gemm_bf16_splitk(const void* A, int lda, const void* B, int l
   const int tiles = ((M + 255) >> 8) * (N >> 8);
   hipLaunchKernelGGL(gemm_bf16_256_t<true>, dim3(tiles, ks), dim3(512), 131072, (hipStream_t)stream, (const uint16_t*)A,
                      (const uint16_t*)B, (void*)part, M, N, K, lda, ldb, K / ks);
+  return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+}
+
+// act[M][N/2] = silu(gate) * up of A . B^T with B's gate / up rows interleaved by 8 (ops.llm.interleave_gate_up), for shapes
+// whose tiles fill the chip without a K split (Llama-3-70B gate_up: 224 tiles): SwiGLU in the tile epilogue, bf16 out.
+extern "C" int klm_gemm_bf16_swiglu(const void* A, int lda, const void* B, int ldb, void* act, int M, int N, int K, void* stream) {
+  if (!A || !B || !act) return KLM_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)act) & 15) return KLM_ERR_ALIGN;
+  if (M <= 0 || N <= 0 || (N & 255) || K < 128 || (K & 63) || lda < K || ldb < K || (lda & 7) || (ldb & 7)) return KLM_ERR_SHAPE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_256_t<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) !=
+        hipSuccess)
+      return KLM_ERR_HIP;
+    attr_set = true;
+  }
+  const int tiles = ((M + 255) >> 8) * (N >> 8);
+  hipLaunchKernelGGL((gemm_bf16_256_t<true, true>), dim3(tiles, 1), dim3(512), 131072, (hipStream_t)stream, (const uint16_t*)A,
+                     (const uint16_t*)B, act, M, N, K, lda, ldb, K);
   return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
 }

@@ -85,6 +85,8 @@ int klm_rope_cache(void* qkv, const float* cos_sin, const int32_t* positions, co
 int klm_gemm_bf16_splitk_plan(int M, int N, int K, int* ksplit);
 int klm_gemm_bf16_splitk(const void* A, int lda, const void* B, int ldb, float* part, int M, int N, int K, int ksplit,
                          void* stream);
+// The same GEMM without a K split and with SwiGLU in the tile epilogue: act[M][N/2] bf16 (B's gate / up rows interleaved by 8).
+int klm_gemm_bf16_swiglu(const void* A, int lda, const void* B, int ldb, void* act, int M, int N, int K, void* stream);
 // Decode attention: q (row b at q + b*q_stride elements, n_q heads of 128), block_tables[B][max_blocks],
 // ctx_lens[B] -> out[B][n_q][128]. q_stride lets q be a view of the fused qkv activation.
 // num_splits > 1 splits each context over that many blocks (flash decoding); then

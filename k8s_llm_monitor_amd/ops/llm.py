@@ -51,6 +51,8 @@ def _lib():
         lib.klm_gemm_bf16_splitk_plan.argtypes = [i, i, i, ip]
         lib.klm_gemm_bf16_splitk.argtypes = [vp, i, vp, i, vp, i, i, i, i, vp]
         lib.klm_gemm_bf16_splitk_plan.restype = lib.klm_gemm_bf16_splitk.restype = i
+        lib.klm_gemm_bf16_swiglu.argtypes = [vp, i, vp, i, vp, i, i, i, vp]
+        lib.klm_gemm_bf16_swiglu.restype = i
         for n in ("klm_mid_linear_plan", "klm_mid_linear", "klm_mid_linear_w8", "klm_mid_epilogue", "klm_rope_cache_from_partials",
                   "klm_mid_linear_swiglu"):
             getattr(lib, n).restype = i
@@ -368,6 +370,11 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, kind: str = "none", residu
     elif tuple(out.shape) != (M, n_out) or not out.is_contiguous() or out.dtype != x.dtype:
         raise KlmOpsError("mid_linear: bad out")
     st = _stream(x)
+    if k == 1 and _wide(M, N, K, w8, wide) and ksplit in (0, 1) and wide_plan(M, N, K, ksplit) == 1:
+        # enough tiles without a K split (70B gate_up): SwiGLU in the tile epilogue, no partial sums
+        _check(_lib().klm_gemm_bf16_swiglu(x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), out.data_ptr(), M, N, K, st),
+               f"klm_gemm_bf16_swiglu(M={M},N={N},K={K})")
+        return out
     if k == 1 and not _wide(M, N, K, w8, wide):
         ks, nw, rt = mid_plan(M, N, K, ksplit, waves, row_tiles)
         if ks == 1:                       # no K split: the activation is applied inside the main kernel, no epilogue launch

@@ -386,6 +386,21 @@ def test_mid_linear_matches_reference(M, N, K):
     _close(got, hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5), 3e-2, 2e-2)
 
 
+def test_tiled_gemm_with_swiglu_in_the_tile_epilogue():
+    """Shapes with enough tiles for the chip without a K split (Llama-3-70B gate_up): no partial sums, the activation leaves
+    the GEMM in bf16."""
+    torch.manual_seed(35)
+    for M, N, K in ((256, 57344, 1024), (150, 65536, 512), (129, 57344, 512)):
+        assert llm.wide_plan(M, N, K) == 1
+        x, w = _rand(M, K), _rand(N, K, scale=0.05)
+        want = ref.silu_mul(x.float() @ w.float().t())
+        guard = torch.full((M + 1, N // 2), 7.0, device=DEV, dtype=torch.bfloat16)
+        got = llm.mid_linear(x, w, kind="swiglu", out=guard[:M])
+        _close(got, want, 5e-2, 2e-2)
+        assert bool((guard[M] == 7.0).all())
+        _close(got, llm.mid_linear(x, w, kind="swiglu", ksplit=2), 2e-2, 2e-2)     # the partial-sum route
+
+
 @pytest.mark.parametrize("M", [129, 200, 256])
 @pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (28672, 4096), (256, 512)])
 def test_mid_linear_from_129_rows_runs_the_k_split_tiled_gemm(M, N, K):

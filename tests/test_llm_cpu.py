@@ -395,7 +395,7 @@ def test_kernel_path_policy_per_model_class(model):
     assert m.mid_spans() == [(1, 128), (129, 256)]                              # 8B class
     assert m.lib_projections(192) == {"w_gate_up"} and m.lib_projections(230) == {"w_gate_up", "wo"}
     m.cfg = replace(m.cfg, hidden=8192)                                         # 70B class
-    assert m.mid_spans() == [(33, 128), (129, 256)] and m.lib_projections(256) == {"w_gate_up"}
+    assert m.mid_spans() == [(33, 128), (129, 256)] and m.lib_projections(192) == {"w_gate_up"} and m.lib_projections(256) == frozenset()
     m.cfg = replace(m.cfg, hidden=16384)                                        # a 405B / tp8 shard
     assert m.mid_spans() == [(97, 128), (129, 256)] and m.lib_projections(256) == {"wo"}
     m.fp8_decode = True

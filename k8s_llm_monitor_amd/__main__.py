@@ -139,7 +139,8 @@ def _cmd_serve_llm_tp_launch(a, argv: Sequence[str]) -> int:
     procs = []
     for r in range(a.tp):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.tp), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), KLM_TP_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+                   MASTER_PORT=str(port), KLM_TP_RANK=str(r), KLM_CHILD_OF=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   PYTHONUNBUFFERED="1")
         procs.append(subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", *argv], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     for sig in (signal.SIGINT, signal.SIGTERM):
@@ -169,6 +170,18 @@ def _cmd_serve_llm_tp_launch(a, argv: Sequence[str]) -> int:
     return rc
 
 
+def _die_with_parent() -> None:
+    """A rank / replica process must not outlive its launcher (a killed launcher would otherwise leave ranks waiting in a
+    collective for ever): ask the kernel for SIGKILL when the parent dies. Linux only, best effort."""
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)          # PR_SET_PDEATHSIG
+        if os.getppid() != int(os.environ["KLM_CHILD_OF"]):                         # the launcher was gone before the call
+            os._exit(1)
+    except (OSError, AttributeError, KeyError, ValueError):
+        pass
+
+
 def _tp_group(a):
     """This process is rank KLM_TP_RANK of a --tp job: join the process group, pick the device, build the TP group."""
     import torch
@@ -195,6 +208,8 @@ def _cmd_serve_llm(a) -> int:
         return _cmd_serve_llm_replicas(a)
     if a.tp > 1 and "KLM_TP_RANK" not in os.environ:
         return _cmd_serve_llm_tp_launch(a, a.argv)
+    if "KLM_CHILD_OF" in os.environ:             # a rank of --tp or a replica of --gpus: never outlive the launcher
+        _die_with_parent()
     from .serving import Engine, EngineConfig
     from .serving.loadclient import OpenLoopLoad
     from .serving.server import LlmServer

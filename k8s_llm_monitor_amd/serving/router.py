@@ -206,7 +206,7 @@ class ReplicaSet:
 
     def start(self) -> "ReplicaSet":
         for i, d in enumerate(self.devices):
-            env = dict(self.env, PYTHONUNBUFFERED="1")
+            env = dict(self.env, PYTHONUNBUFFERED="1", KLM_CHILD_OF=str(os.getpid()))   # the replica dies with this process
             if self.device_kind == "cuda":
                 env["HIP_VISIBLE_DEVICES"] = str(d)          # the child sees exactly one GPU, as cuda:0
             cmd = [sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--host", self.host, "--port",

@@ -143,3 +143,44 @@ def test_tp_launcher_stops_the_job_when_a_rank_dies():
     finally:
         if p.poll() is None:
             p.kill()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_do_not_outlive_a_killed_launcher():
+    """SIGKILL at the launcher (it cannot clean up): the kernel delivers the ranks' parent-death signal."""
+    import signal
+    import time
+    import urllib.request
+    port = free_port()
+    p = subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--model", "tiny", "--device", "cpu", "--tp", "2",
+                          "--host", "127.0.0.1", "--port", str(port), "--max-num-seqs", "4", "--max-model-len", "128", "--kv-blocks", "32"],
+                         cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2"), stdout=subprocess.DEVNULL,
+                         stderr=subprocess.DEVNULL)
+    kids = []
+    try:
+        t_end = time.time() + 120
+        while True:
+            try:
+                urllib.request.urlopen(f"http://127.0.0.1:{port}/health", timeout=1).read()
+                break
+            except OSError:
+                assert p.poll() is None and time.time() < t_end, "server did not come up"
+                time.sleep(0.3)
+        kids = [int(k) for k in subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()]
+        assert len(kids) == 2
+        p.kill()
+        p.wait(timeout=30)
+        t_end = time.time() + 30
+        while time.time() < t_end and any(os.path.exists(f"/proc/{k}") and "Z" not in open(f"/proc/{k}/stat").read().split(")")[-1].split()[0]
+                                          for k in kids):
+            time.sleep(0.2)
+        alive = [k for k in kids if os.path.exists(f"/proc/{k}") and open(f"/proc/{k}/stat").read().split(")")[-1].split()[0] != "Z"]
+        assert not alive, f"ranks {alive} survived their launcher"
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for k in kids:
+            try:
+                os.kill(k, signal.SIGKILL)
+            except OSError:
+                pass

@@ -34,10 +34,13 @@ def test_all_targets_exist_and_carry_gfx950_code(built):
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if os.path.exists(objdump):
         import tempfile
-        with tempfile.TemporaryDirectory() as td:      # --offloading extracts the code objects into the cwd
+        import shutil
+        with tempfile.TemporaryDirectory() as td:      # --offloading writes the code objects next to its input: work on a copy
             for lib in ("klm_ops", "klm_xgmi"):
-                r = subprocess.run([objdump, "--offloading", str(built[lib])], capture_output=True, text=True, cwd=td)
+                copy = shutil.copy(built[lib], td)
+                r = subprocess.run([objdump, "--offloading", copy], capture_output=True, text=True, cwd=td)
                 assert "gfx950" in r.stdout + r.stderr, lib
+        assert not [f for f in os.listdir(built["klm_ops"].parent) if "hipv4" in f or ".host-" in f]
 
 
 def test_executables_fail_with_json_when_no_gpu(built):

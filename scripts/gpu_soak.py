@@ -14,6 +14,21 @@ cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"},
                                      "sources": {"gpu": "amdsmi", "kube": "none", "vllm": "none", "history": "local"}})
 mon = Monitor(cfg).start(); srv = MonitorServer(mon, cfg).start()
 get = lambda p: json.loads(urllib.request.urlopen(srv.url + p, timeout=5).read())
+# a dashboard tab would hold /api/events open: count what is pushed to it (one `realtime` event per sampler tick)
+import socket, threading
+pushed = {"bytes": 0, "buf": b""}
+def sse():
+    c = socket.create_connection(("127.0.0.1", srv.port), timeout=60)
+    c.sendall(b"GET /api/events HTTP/1.1\r\nHost: x\r\n\r\n")
+    try:
+        while True:
+            chunk = c.recv(65536)
+            if not chunk:
+                break
+            pushed["bytes"] += len(chunk); pushed["buf"] += chunk
+    except OSError:
+        pass
+threading.Thread(target=sse, daemon=True).start()
 timeline = []
 def poll(tag):
     g = get("/api/gpu/metrics")[0]; a = get("/api/alerts")
@@ -35,11 +50,15 @@ doc = {"device": torch.cuda.get_device_name(0), "burner": burn, "timeline": time
        "history_points": {k: len(v["data"]) for k, v in hist.items() if isinstance(v, dict) and "data" in v},
        "sampler": stats["tasks"]["realtime"], "collectors_ms": stats["collectors"], "metrics_series": len(parse_exposition(metrics)),
        "alert_events": get("/api/alerts/history")}
+events = {k: pushed["buf"].count(b"event: " + k.encode()) for k in ("realtime", "alerts", "pods", "vllm")}
+doc["sse"] = {"events": events, "bytes": pushed["bytes"], "seconds": round(time.time() - t0, 1)}
 srv.stop(); mon.stop()
 mid = [r for r in timeline if r["phase"] == "burner50"][3:]
 doc["checks"] = {"gfx_mean_during_burner": sum(r["gfx"] for r in mid) / len(mid), "duty_achieved": burn["duty_achieved"],
                  "hbm_alert_seen": any("gpu/0/hbm" in sum(r["alerts"].values(), []) for r in timeline if r["phase"] == "burner50+hbm72"),
-                 "hbm_alert_cleared": not any("gpu/0/hbm" in sum(r["alerts"].values(), []) for r in timeline[-2:])}
+                 "hbm_alert_cleared": not any("gpu/0/hbm" in sum(r["alerts"].values(), []) for r in timeline[-2:]),
+                 "sse_realtime_events": events["realtime"], "sse_alert_events": events["alerts"]}
 json.dump(doc, open(out_path, "w"), indent=1)
 print(json.dumps(doc["checks"])); print(json.dumps(timeline[-1])); print("saved", out_path)
 assert abs(doc["checks"]["gfx_mean_during_burner"] - burn["duty_achieved"]) < 3.0 and doc["checks"]["hbm_alert_seen"] and doc["checks"]["hbm_alert_cleared"]
+assert events["realtime"] >= 15 and events["alerts"] >= 2, events          # a tick per second for ~21 s; first paint + the HBM alert

@@ -178,7 +178,12 @@ def test_sse_stream_pushes_every_panel(server):
         buf += s.recv(65536)
     first = dict(events(buf.split(b"\r\n\r\n", 1)[1]))
     assert set(first) == {"alerts", "realtime", "pods", "vllm"}
-    assert first["realtime"]["gpus"] == get_json(server, "/api/gpu/metrics") and first["pods"] == get_json(server, "/api/k8s/pods")
+    # the same documents as the polled endpoints (compared by shape: the sampler may tick between the two reads)
+    polled = get_json(server, "/api/gpu/metrics")
+    assert [g["index"] for g in first["realtime"]["gpus"]] == [g["index"] for g in polled] and len(polled) == 8
+    assert set(first["realtime"]["gpus"][0]) == set(polled[0]) and set(first["realtime"]["host"]) == {"cpu", "memory", "disk"}
+    assert [p["name"] for p in first["pods"]] == [p["name"] for p in get_json(server, "/api/k8s/pods")]
+    assert set(first["alerts"]) == {"minor", "serious", "critical"} and "available" in first["vllm"]
     mon = server.monitor
     n0 = len(events(buf.split(b"\r\n\r\n", 1)[1]))
     mon.tick_all()

@@ -152,8 +152,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             from ..serving import bench as sb
             eng = Engine(EngineConfig(model="llama3-8b", device=str(dev), max_num_seqs=256, max_model_len=4096,
                                       kv_blocks=20000))
-            eng.warmup([1, 16, 64, 256])
-            dec = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64, 256)]
+            eng.warmup([1, 16, 64, 192, 256])
+            dec = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64, 192, 256)]   # skinny / skinny / mid / tiled GEMM paths
             pre = sb.prefill_ms(eng, 4, 1024, iters=2)
             extras["llm_serving"] = {
                 "model": "llama3-8b (random weights, bf16)", "ctx": 1024,

@@ -35,25 +35,27 @@ def _sync(torch, dev) -> None:
         torch.cuda.synchronize(dev)
 
 
-def run_op(dist, op: str, x, y, world: int):
+def run_op(dist, op: str, x, y, world: int, group=None):
     if op == "allreduce":
-        dist.all_reduce(x)
+        dist.all_reduce(x, group=group)
     elif op == "allgather":
-        dist.all_gather_into_tensor(y, x[: x.numel() // world])
+        dist.all_gather_into_tensor(y, x[: x.numel() // world], group=group)
     elif op == "reducescatter":
-        dist.reduce_scatter_tensor(y[: x.numel() // world], x)
+        dist.reduce_scatter_tensor(y[: x.numel() // world], x, group=group)
     elif op == "alltoall":
-        dist.all_to_all_single(y, x)
+        dist.all_to_all_single(y, x, group=group)
     else:
         raise ValueError(op)
 
 
 def sweep(dev, sizes: Optional[Sequence[int]] = None, dtype: str = "bf16", op: str = "allreduce",
-          warmup: int = 5, iters: int = 20, check: bool = True) -> Optional[Dict[str, Any]]:
-    """Run the size sweep on the default process group. Returns the curve on rank 0, None elsewhere."""
+          warmup: int = 5, iters: int = 20, check: bool = True, group=None) -> Optional[Dict[str, Any]]:
+    """Run the size sweep on `group` (default: the default process group); every member of the group
+    calls it. Returns the curve on the group's rank 0, None elsewhere. The buffer is reduced IN PLACE
+     and the data check covers every element."""
     import torch
     import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     esz = probe.DTYPE_BYTES[dtype]
     sizes = list(sizes) if sizes is not None else probe.sweep_sizes()
     tdt = _dtype(torch, dtype)
@@ -72,33 +74,55 @@ def sweep(dev, sizes: Optional[Sequence[int]] = None, dtype: str = "bf16", op: s
         verdict = None
         if check and op == "allreduce":
             xv.fill_(float(rank + 1))
-            dist.all_reduce(xv)
+            dist.all_reduce(xv, group=group)
             _sync(torch, dev)
-            want = world * (world + 1) / 2.0
-            probe_idx = torch.tensor([0, n // 2, n - 1], device=dev)
-            verdict = "ok" if bool((xv[probe_idx].float() == want).all().item()) else "MISMATCH"
+            want = world * (world + 1) / 2.0            # exact in bf16 up to 22 ranks
+            verdict = "ok" if bool((xv == want).all().item()) else "MISMATCH"
         xv.fill_(1.0 / world if op == "allreduce" else 1.0)      # keeps repeated sums finite
         for _ in range(warmup):
-            run_op(dist, op, xv, yv, world)
+            run_op(dist, op, xv, yv, world, group)
             if op == "allreduce":
                 xv.mul_(1.0 / world)
         _sync(torch, dev)
-        dist.barrier()
+        dist.barrier(group=group)
         _sync(torch, dev)
         t0 = time.perf_counter()
         for _ in range(iters):
-            run_op(dist, op, xv, yv, world)
+            run_op(dist, op, xv, yv, world, group)
         _sync(torch, dev)
         dt = (time.perf_counter() - t0) / iters
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         pts.append(probe.point(world, nbytes, float(t.item()), dtype, op, verdict))
     if rank != 0:
         return None
     ok = all(p["check"] in (None, "ok") for p in pts)
-    c = probe.curve(world, pts, dtype, verified=ok, executor="torch.distributed/" + dist.get_backend())
+    c = probe.curve(world, pts, dtype, verified=ok, executor="torch.distributed/" + dist.get_backend(group))
     c["op"] = op
+    c["ranks_seen"] = world                              # what the communicator itself reports
     return c
+
+
+def sweep_subgroups(dev, counts: Sequence[int] = (1, 2, 4, 8), sizes: Optional[Sequence[int]] = None,
+                    dtype: str = "bf16", warmup: int = 5, iters: int = 20, ctrl=None) -> List[Dict[str, Any]]:
+    """The whole 1/2/4/8 curve from ONE launch: for every n <= world the first n ranks form their own
+    communicator (``dist.new_group``; RCCL builds it over just those GPUs' xGMI links) and sweep it while
+    the others wait on `ctrl` (a gloo group: waiting there submits nothing to the GPU, whereas an RCCL
+    barrier would park a spinning kernel on the idle devices). Every rank of the default group calls
+    this; rank 0 gets the list of curves, the others []."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    curves: List[Dict[str, Any]] = []
+    for n in sorted({int(c) for c in counts if 1 <= int(c) <= world}):
+        g = dist.new_group(ranks=list(range(n))) if n < world else None     # collective over the default group
+        if rank < n:
+            c = sweep(dev, sizes, dtype, "allreduce", warmup, iters, group=g)
+            if c is not None:
+                curves.append(c)
+        dist.barrier(group=ctrl)
+        if g is not None:
+            dist.destroy_process_group(g)
+    return curves
 
 
 def main(argv: Optional[Sequence[str]] = None) -> int:

@@ -84,6 +84,22 @@ def curve(n: int, points: Sequence[Mapping[str, Any]], dtype: str = "bf16", veri
     return out
 
 
+def brief(c: Mapping[str, Any]) -> Dict[str, Any]:
+    """One curve as bench.py's JSON line carries it: peak, ceilings, [[bytes, busBW], ...] (algBW at n = 1)."""
+    n = c["n_gpus"]
+    key = "busbw_GBps" if n > 1 else "algbw_GBps"
+    rnd = lambda v: None if v is None else round(v, 2)
+    out = {"peak_busbw_GBps": rnd(c.get("peak_busbw_GBps")), "peak_algbw_GBps": rnd(c.get("peak_algbw_GBps")),
+           "peak_bytes": c.get("peak_bytes"), "ceiling_mesh_GBps": c.get("ceiling_mesh_GBps"),
+           "ceiling_ring_GBps": c.get("ceiling_ring_GBps"), "verified": c.get("verified"),
+           "executor": c.get("executor"), "ranks_seen": c.get("ranks_seen", (c.get("header") or {}).get("n_gpus")),
+           "curve_key": key, "curve": [[p["bytes"], round(p[key], 4)] for p in c.get("points", [])]}
+    for k in ("mesh_efficiency", "single_ring_suspected"):
+        if k in c:
+            out[k] = c[k] if isinstance(c[k], bool) else round(c[k], 3)
+    return out
+
+
 def results_doc(curves: Iterable[Mapping[str, Any]], note: str = "") -> Dict[str, Any]:
     cs = sorted((dict(c) for c in curves), key=lambda c: (c["n_gpus"], c["dtype"]))
     return {"timestamp": time.time(), "link_GBps": XGMI_LINK_GBPS, "note": note, "curves": cs,

@@ -100,23 +100,34 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         extras["sampler_stats"] = sampler.stats()
 
     t_sec = time.perf_counter()
-    if dd and not getattr(a, "no_probe", False):
-        # the RCCL all-reduce curve at this GPU count (outside the timed region)
+    if not getattr(a, "no_probe", False):
+        # the RCCL all-reduce curve at EVERY n in {1, 2, 4, 8} <= world from this one launch (outside the
+        # timed region): the first n ranks form their own communicator and sweep it in place
         try:
             from ..parallel import dist_probe, probe
-            c = dist_probe.sweep(dev, probe.sweep_sizes(1024, getattr(a, "probe_max_bytes", 1 << 28), 4), "bf16",
-                                 warmup=3, iters=10)
-            if c is not None:
-                extras["rccl_allreduce"] = {"peak_busbw_GBps": round(c["peak_busbw_GBps"], 2), "peak_bytes": c["peak_bytes"],
-                                            "ceiling_mesh_GBps": c["ceiling_mesh_GBps"], "ceiling_ring_GBps": c["ceiling_ring_GBps"],
-                                            "verified": c["verified"],
-                                            "curve": [[p["bytes"], round(p["busbw_GBps"], 2)] for p in c["points"]]}
+            sizes = probe.sweep_sizes(1024, getattr(a, "probe_max_bytes", 1 << 28), 4)
+            if dd:
+                curves = dist_probe.sweep_subgroups(dev, (1, 2, 4, 8), sizes, "bf16", warmup=3, iters=10,
+                                                    ctrl=getattr(a, "ctrl_group", None))
+                extras["rccl_ranks_seen"] = {"process_group_world_size": dist.get_world_size(),
+                                             "communicators": [c.get("ranks_seen") for c in curves]}
+            elif dev.type == "cuda":
+                # one rank and no process group: the native probe (a child process) gives the n = 1 point
+                curves = [probe.run_native(1, "bf16", max_bytes=sizes[-1], warmup=3, iters=10, timeout=120.0)]
+                extras["rccl_ranks_seen"] = {"process_group_world_size": 1,
+                                             "communicators": [c.get("header", {}).get("n_gpus") for c in curves]}
+            else:
+                curves = []
+            if rank == 0 and curves:
+                extras["rccl_curves"] = {str(c["n_gpus"]): probe.brief(c) for c in curves}
+                top = curves[-1]
+                extras["rccl_allreduce"] = dict(probe.brief(top), n_gpus=top["n_gpus"])
                 try:
-                    probe.save_results(probe.merge_results(probe.load_results(), probe.results_doc([c], note="bench.py")))
+                    probe.save_results(probe.merge_results(probe.load_results(), probe.results_doc(curves, note="bench.py")))
                 except OSError:
                     pass
         except Exception as e:
-            extras["rccl_allreduce"] = {"error": f"{type(e).__name__}: {e}"}
+            extras["rccl_curves"] = {"error": f"{type(e).__name__}: {e}"}
 
     which = getattr(a, "validation_phases", "all") or "all"
     if dd and not a.no_validation and (which == "all" or "xgmi" in which.split(",")):

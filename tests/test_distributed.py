@@ -86,6 +86,45 @@ def test_bench_contract_two_ranks_rehearsal():
     assert d["allreduce_bytes_per_step"] == 256 * 256 * 2 and d["allreduce_busbw_GBps_overlapped"] > 0
 
 
+@pytest.mark.timeout(240)
+def test_bench_launches_its_own_ranks():
+    """Plain ``python bench.py --gpus 2`` (no torchrun): the parent starts the ranks as a child, relays ONE JSON line,
+    and the line proves two ranks ran and carries the curve at n = 1 AND n = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-rehearsal", "--size", "256",
+                        "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=220)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = check_bench_line(r.stdout, 2, 3, 1)
+    assert d["launcher"].startswith("bench.py self-launch")
+    assert d["rccl_ranks_seen"] == {"process_group_world_size": 2, "communicators": [1, 2]}
+    assert sorted(d["rccl_curves"]) == ["1", "2"]
+    c1, c2 = d["rccl_curves"]["1"], d["rccl_curves"]["2"]
+    assert c1["verified"] and c2["verified"] and c1["ranks_seen"] == 1 and c2["ranks_seen"] == 2
+    assert c1["curve_key"] == "algbw_GBps" and c2["curve_key"] == "busbw_GBps" and c2["ceiling_mesh_GBps"] == 153.0
+    assert [b for b, _ in c2["curve"]] == [1024, 4096, 16384, 65536] and c2["curve"][-1][1] > 0
+    assert "rccl_curves_native" not in d                                 # the C++ probe needs GPUs
+
+
+@pytest.mark.timeout(240)
+def test_bench_four_ranks_give_the_1_2_4_curve():
+    r = torchrun(4, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--cpu-rehearsal", "--size", "128", "--steps", "2", "--warmup", "1",
+                     "--probe-max-bytes", "4096"])
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = check_bench_line(r.stdout, 4, 2, 1)
+    assert d["launcher"] == "torch.distributed.run"
+    assert sorted(d["rccl_curves"]) == ["1", "2", "4"] and d["rccl_ranks_seen"]["communicators"] == [1, 2, 4]
+    assert d["rccl_curves"]["4"]["ceiling_mesh_GBps"] == 3 * 153.0 and d["rccl_allreduce"]["n_gpus"] == 4
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """WORLD_SIZE=1 with --gpus 2 used to run one rank and report n_gpus 1 with rc 0."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-rehearsal", "--size", "64", "--steps", "1",
+                        "--warmup", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and '{"metric"' not in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_bench_one_rank_rccl_takes_the_multi_gpu_path():
@@ -100,4 +139,5 @@ def test_bench_one_rank_rccl_takes_the_multi_gpu_path():
     assert d["n_gpus"] == 1 and d["distributed_backend"] == "nccl" and d["allreduce_bytes_per_step"] == 8192 * 8192 * 2
     assert d["value"] > 500, d["value"]                                  # the GEMMs ran at speed next to the collective
     assert "error" not in d["rccl_allreduce"] and d["rccl_allreduce"]["verified"], d["rccl_allreduce"]
+    assert d["rccl_curves"]["1"]["executor"] == "torch.distributed/nccl" and d["rccl_ranks_seen"]["communicators"] == [1]
     assert d["xgmi_fidelity"]["world"] == 1 and d["xgmi_fidelity"]["expected_bytes_per_gpu"] == 0, d["xgmi_fidelity"]

@@ -136,6 +136,8 @@ class GpuNormalizer:
         rd, wr = raw.get("xgmi_read_kib") or [], raw.get("xgmi_write_kib") or []
         st = raw.get("xgmi_link_status") or []
         peers = raw.get("xgmi_peers") or []
+        peer_idx, peer_src = raw.get("xgmi_peer_index") or [], raw.get("xgmi_peer_source") or []
+        max_gbps = raw.get("xgmi_link_max_gbps") or []
         rx_total = tx_total = 0.0
         any_rate = False
         for i in range(max(len(rd), len(wr), len(st))):
@@ -154,7 +156,11 @@ class GpuNormalizer:
                 tx_total += tx_gbps
             if state == "n/a" and r_kib in (None, 0) and w_kib in (None, 0):
                 continue  # link slot not populated (the GPU's own position in the hive)
+            cap = _num(max_gbps[i]) if i < len(max_gbps) else None
             links.append({"link": i, "state": state, "peer": peers[i] if i < len(peers) else None,
+                          "peerIndex": peer_idx[i] if i < len(peer_idx) else None,
+                          "peerSource": peer_src[i] if i < len(peer_src) else None,
+                          "maxGBps": None if cap is None else cap / 8.0,       # amdsmi: Gb/s, one direction
                           "rxBytes": None if r_kib is None else r_kib * 1024,
                           "txBytes": None if w_kib is None else w_kib * 1024,
                           "rxGBps": rx_gbps, "txGBps": tx_gbps})
@@ -196,7 +202,13 @@ class GpuNormalizer:
                      "rxGBps": rx_total if any_rate else None,
                      "txGBps": tx_total if any_rate else None,
                      "linkWidth": _int(raw.get("xgmi_link_width")),
-                     "linkSpeedGbps": _int(raw.get("xgmi_link_speed"))},
+                     "linkSpeedGbps": _int(raw.get("xgmi_link_speed")),
+                     "hiveId": None if raw.get("xgmi_hive_id") is None else str(raw.get("xgmi_hive_id")),   # 64-bit: a string for JS
+                     "nodeId": _int(raw.get("xgmi_node_id")),
+                     "peersKnown": any(l.get("peerIndex") is not None or l.get("peer") for l in links),
+                     "nearest": raw.get("xgmi_nearest"),
+                     "topologyNote": raw.get("xgmi_topology_note"),
+                     "errorStatus": raw.get("xgmi_error_status")},
             # amdsmi's pcie_bandwidth_inst is megabits per second (amd-smi prints it as Mb/s; 700 under launch traffic)
             "pcieGBps": None if _num(raw.get("pcie_bandwidth_inst")) is None else _num(raw.get("pcie_bandwidth_inst")) / 8000.0,
             "pcie": {"GBps": None if _num(raw.get("pcie_bandwidth_inst")) is None else _num(raw.get("pcie_bandwidth_inst")) / 8000.0,
@@ -211,6 +223,80 @@ class GpuNormalizer:
             "timestamp": raw.get("wall", time.time()),
         }
         return out
+
+
+# --------------------------------------------------------------------------------------
+# xGMI topology ("the link-to-peer mapping comes from topology calls")
+# --------------------------------------------------------------------------------------
+def _valid_bdf(bdf: Any) -> bool:
+    """amdsmi names a link's far end by PCI address; a GPU the process cannot see (another container's
+    device) comes back as the all-ones address ``ffffffffffff:ff:1f.7`` (profiles/r2_amdsmi_topo_mi355x.json)."""
+    return isinstance(bdf, str) and bool(bdf) and not bdf.lower().startswith("ffff") and bdf != "N/A"
+
+
+def read_xgmi_topology(smi, handles: Sequence[Any], bdfs: Sequence[Optional[str]]) -> List[Dict[str, Any]]:
+    """One record per GPU, read once at start-up:
+
+      ``links[slot]`` = {peer_bdf, peer_index, source, bit_rate_gbps, max_gbps, link_type} for every slot of
+      ``amdsmi_get_link_metrics`` (same slot order as ``xgmi_read_data_acc`` in the metrics table: the two
+      carry identical counters on MI355X), ``hive_id`` / ``node_id`` from ``amdsmi_get_xgmi_info``,
+      ``nearest`` = indices from ``amdsmi_get_link_topology_nearest(XGMI)``, ``pair_type[j]`` from
+      ``amdsmi_topo_get_link_type``, and ``note`` saying why peers are unnamed when they are.
+
+    Peer naming, in order: the far-end PCI address of the link slot when it is one of the visible GPUs
+    (``source = "link_metrics"``); else, inside one hive, the GPU whose ``xgmi_node_id`` equals the slot
+    number (the GPU's own slot is the one its own node id names: status ``X``) (``source = "xgmi_node_id"``);
+    else None. Every call is guarded: a failing one leaves its field empty and its reason in ``note``."""
+    by_bdf = {str(b).lower(): i for i, b in enumerate(bdfs) if b}
+    infos: List[Dict[str, Any]] = []
+    for h in handles:
+        rec: Dict[str, Any] = {"links": [], "hive_id": None, "node_id": None, "nearest": None, "pair_type": {}, "notes": []}
+        try:
+            xi = smi.amdsmi_get_xgmi_info(h)
+            rec["hive_id"], rec["node_id"] = _int(xi.get("xgmi_hive_id")), _int(xi.get("xgmi_node_id"))
+        except Exception as e:
+            rec["notes"].append(f"xgmi_info: {type(e).__name__}")
+        try:
+            lm = smi.amdsmi_get_link_metrics(h)
+            for slot, l in enumerate(lm.get("links") or []):
+                rec["links"].append({"slot": slot, "peer_bdf": l.get("bdf") if _valid_bdf(l.get("bdf")) else None, "peer_index": None,
+                                     "source": None, "bit_rate_gbps": _num(l.get("bit_rate")), "max_gbps": _num(l.get("max_bandwidth")),
+                                     "link_type": _int(l.get("link_type"))})
+        except Exception as e:
+            rec["notes"].append(f"link_metrics: {type(e).__name__}")
+        infos.append(rec)
+    LT = getattr(smi, "AmdSmiLinkType", None)
+    for i, (h, rec) in enumerate(zip(handles, infos)):
+        for l in rec["links"]:
+            j = by_bdf.get(str(l["peer_bdf"]).lower()) if l["peer_bdf"] else None
+            if j is not None and j != i:
+                l["peer_index"], l["source"] = j, "link_metrics"
+        if not any(l["peer_index"] is not None for l in rec["links"]) and len(handles) > 1 and rec["hive_id"] is not None:
+            # far ends unnamed by the link table: same-hive GPUs by xgmi node id = slot number
+            for l in rec["links"]:
+                for j, other in enumerate(infos):
+                    if j != i and other["hive_id"] == rec["hive_id"] and other["node_id"] == l["slot"] and rec["node_id"] != l["slot"]:
+                        l["peer_index"], l["peer_bdf"], l["source"] = j, bdfs[j], "xgmi_node_id"
+        if LT is not None and len(handles) > 1:
+            try:
+                near = smi.amdsmi_get_link_topology_nearest(h, LT.AMDSMI_LINK_TYPE_XGMI)
+                got = {getattr(x, "value", x) for x in (near.get("processor_list") or [])}
+                rec["nearest"] = sorted(k for k, h2 in enumerate(handles) if k != i and getattr(h2, "value", h2) in got)
+            except Exception as e:
+                rec["notes"].append(f"topology_nearest: {type(e).__name__}")
+            for j, h2 in enumerate(handles):
+                if j == i:
+                    continue
+                try:
+                    t = smi.amdsmi_topo_get_link_type(h, h2)
+                    rec["pair_type"][j] = {"hops": _int(t.get("hops")), "type": _int(t.get("type"))} if isinstance(t, dict) else t
+                except Exception:
+                    pass
+        if rec["links"] and not any(l["peer_index"] is not None for l in rec["links"]):
+            rec["notes"].append("peers not visible to this process (1 GPU visible of the hive)" if len(handles) == 1
+                                else "no link slot names a visible GPU")
+        rec["note"] = "; ".join(rec.pop("notes")) or None
+    return infos
 
 
 # --------------------------------------------------------------------------------------
@@ -257,6 +343,12 @@ class AmdSmiReader(GpuReader):
                 except Exception:
                     st[key] = None
             self._static.append(st)
+        try:
+            self.topology = read_xgmi_topology(amdsmi, self._handles, [st.get("bdf") for st in self._static])
+        except Exception as e:                      # telemetry must come up even when the topology calls do not
+            self.topology = [{"links": [], "hive_id": None, "node_id": None, "nearest": None, "pair_type": {},
+                              "note": f"topology unavailable: {type(e).__name__}: {e}"} for _ in self._handles]
+        self._xgmi_err_supported = [True] * len(self._handles)
         self._slow_every = 12       # ECC and process list change rarely: read every Nth sample
         self._n = 0
         self._slow_cache: Dict[int, Dict[str, Any]] = {}
@@ -303,8 +395,19 @@ class AmdSmiReader(GpuReader):
                 except Exception:
                     m = {}
                 raw.update(metrics_to_raw(m))
+                raw.update(topology_to_raw(self.topology[i]))
                 if slow or i not in self._slow_cache:
                     sc: Dict[str, Any] = {}
+                    if self._xgmi_err_supported[i]:
+                        try:
+                            est = smi.amdsmi_gpu_xgmi_error_status(h)
+                            sc["xgmi_error_status"] = getattr(est, "name", str(est)).replace("AMDSMI_XGMI_STATUS_", "").lower()
+                        except Exception as e:
+                            # MI355X / amdsmi 26.2 answers NOT_SUPPORTED (profiles/r2_amdsmi_topo_mi355x.json): ask once
+                            self._xgmi_err_supported[i] = False
+                            sc["xgmi_error_status"] = "not_supported" if "NOT_SUPPORTED" in str(e) else f"error: {type(e).__name__}"
+                    else:
+                        sc["xgmi_error_status"] = (self._slow_cache.get(i) or {}).get("xgmi_error_status", "not_supported")
                     try:
                         e = smi.amdsmi_get_gpu_total_ecc_count(h)
                         sc.update(ecc_correctable=e.get("correctable_count"),
@@ -331,6 +434,17 @@ class AmdSmiReader(GpuReader):
             self._smi.amdsmi_shut_down()
         except Exception:
             pass
+
+
+def topology_to_raw(topo: Dict[str, Any]) -> Dict[str, Any]:
+    """One GPU's start-up topology record -> raw-reading keys (per link slot)."""
+    links = topo.get("links") or []
+    return {"xgmi_peers": [l.get("peer_bdf") for l in links],
+            "xgmi_peer_index": [l.get("peer_index") for l in links],
+            "xgmi_peer_source": [l.get("source") for l in links],
+            "xgmi_link_max_gbps": [l.get("max_gbps") for l in links],
+            "xgmi_hive_id": topo.get("hive_id"), "xgmi_node_id": topo.get("node_id"),
+            "xgmi_nearest": topo.get("nearest"), "xgmi_topology_note": topo.get("note")}
 
 
 def metrics_to_raw(m: Dict[str, Any]) -> Dict[str, Any]:

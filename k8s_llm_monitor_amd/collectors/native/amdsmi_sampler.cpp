@@ -100,9 +100,22 @@ struct Gauge {
   void reset() { *this = Gauge(); }
 };
 
+// What the topology calls said about one xGMI link slot at start-up (slot order = xgmi_read_data_acc order).
+struct LinkTopo {
+  std::string peer_bdf;      // "" = the far end is not a GPU this process can see
+  int peer_index = -1;
+  const char* source = nullptr;   // "link_metrics" | "xgmi_node_id"
+  uint32_t max_gbps = 0;     // Gb/s, one direction
+};
+
 struct Gpu {
   amdsmi_processor_handle h;
   std::string name, uuid, bdf;
+  std::vector<LinkTopo> links;
+  bool have_xgmi_info = false;
+  uint64_t hive_id = 0, node_id = 0;
+  std::string topo_note, xgmi_err = "unknown";
+  bool xgmi_err_supported = true;
   double cap_w = NAN, energy_res_uj = NAN;
   Gauge gfx, umc, power, temp, temp_mem, clk;
   amdsmi_gpu_metrics_t m;
@@ -148,6 +161,29 @@ static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, d
       r.u64("ecc_uncorrectable", g.ecc.uncorrectable_count);
       r.u64("ecc_deferred", g.ecc.deferred_count);
     }
+    if (!g.links.empty()) {
+      auto arr = [&](const char* k, auto&& item) {
+        r.key(k);
+        r.s += '[';
+        for (size_t l = 0; l < g.links.size(); ++l) {
+          if (l) r.s += ',';
+          item(g.links[l]);
+        }
+        r.s += ']';
+      };
+      auto quoted = [&](const std::string& v) { r.s += v.empty() ? std::string("null") : "\"" + v + "\""; };
+      arr("xgmi_peers", [&](const LinkTopo& l) { quoted(l.peer_bdf); });
+      arr("xgmi_peer_index", [&](const LinkTopo& l) { r.s += l.peer_index < 0 ? std::string("null") : std::to_string(l.peer_index); });
+      arr("xgmi_peer_source", [&](const LinkTopo& l) { quoted(l.source ? l.source : ""); });
+      arr("xgmi_link_max_gbps", [&](const LinkTopo& l) { r.s += std::to_string(l.max_gbps); });
+    }
+    if (g.have_xgmi_info) {
+      r.u64("xgmi_hive_id", g.hive_id);
+      r.u64("xgmi_node_id", g.node_id);
+    }
+    if (g.topo_note.empty()) r.null("xgmi_topology_note");
+    else r.str("xgmi_topology_note", g.topo_note.c_str());
+    r.str("xgmi_error_status", g.xgmi_err.c_str());
     if (g.have_m) {
       const amdsmi_gpu_metrics_t& m = g.m;
       r.num("gfx_activity", g.gfx.mean());
@@ -213,6 +249,87 @@ static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, d
   return j.s;
 }
 
+static std::string bdf_str(const amdsmi_bdf_t& bdf) {
+  char b[40];
+  snprintf(b, sizeof b, "%04llx:%02x:%02x.%x", (unsigned long long)bdf.domain_number, (unsigned)bdf.bus_number,
+           (unsigned)bdf.device_number, (unsigned)bdf.function_number);
+  return b;
+}
+
+// Name each link slot's far end: by the slot's PCI address when that is one of the GPUs we enumerate, else (same
+// hive) by xgmi node id == slot number, else leave it unnamed and say why (collectors/gpu.py read_xgmi_topology
+// is the same resolution for the in-process reader).
+static void resolve_peers(std::vector<Gpu>& gpus) {
+  for (size_t i = 0; i < gpus.size(); ++i) {
+    Gpu& g = gpus[i];
+    bool any = false;
+    for (auto& l : g.links) {
+      if (l.peer_bdf.empty()) continue;
+      for (size_t j = 0; j < gpus.size(); ++j)
+        if (j != i && gpus[j].bdf == l.peer_bdf) {
+          l.peer_index = (int)j;
+          l.source = "link_metrics";
+          any = true;
+        }
+      if (l.peer_index < 0) l.peer_bdf.clear();
+    }
+    if (!any && gpus.size() > 1 && g.have_xgmi_info) {
+      for (size_t slot = 0; slot < g.links.size(); ++slot)
+        for (size_t j = 0; j < gpus.size(); ++j)
+          if (j != i && gpus[j].have_xgmi_info && gpus[j].hive_id == g.hive_id && gpus[j].node_id == slot && g.node_id != slot) {
+            g.links[slot].peer_index = (int)j;
+            g.links[slot].peer_bdf = gpus[j].bdf;
+            g.links[slot].source = "xgmi_node_id";
+            any = true;
+          }
+    }
+    if (!g.links.empty() && !any) {
+      if (!g.topo_note.empty()) g.topo_note += "; ";
+      g.topo_note += gpus.size() == 1 ? "peers not visible to this process (1 GPU visible of the hive)" : "no link slot names a visible GPU";
+    }
+  }
+}
+
+static void read_topology(Gpu& g) {
+  amdsmi_xgmi_info_t xi;
+  if (amdsmi_get_xgmi_info(g.h, &xi) == AMDSMI_STATUS_SUCCESS) {
+    g.have_xgmi_info = true;
+    g.hive_id = xi.xgmi_hive_id;
+    g.node_id = xi.xgmi_node_id;
+  } else {
+    g.topo_note = "xgmi_info: unavailable";
+  }
+  static amdsmi_link_metrics_t lm;   // 5 KiB: keep it off the stack
+  memset(&lm, 0, sizeof lm);
+  if (amdsmi_get_link_metrics(g.h, &lm) == AMDSMI_STATUS_SUCCESS) {
+    // MI355X / amdsmi 26.2 fills 8 slots and leaves num_links at 0 (profiles/r2_amdsmi_topo_mi355x.json)
+    const uint32_t n = std::min<uint32_t>(std::max<uint32_t>(lm.num_links, AMDSMI_MAX_NUM_XGMI_LINKS), AMDSMI_MAX_NUM_XGMI_LINKS);
+    for (uint32_t l = 0; l < n; ++l) {
+      LinkTopo t;
+      const amdsmi_bdf_t& b = lm.links[l].bdf;
+      const bool unseen = b.bus_number == 0xff && b.device_number == 0x1f;   // all-ones address: not one of our devices
+      if (!unseen) t.peer_bdf = bdf_str(b);
+      t.max_gbps = lm.links[l].max_bandwidth;
+      g.links.push_back(t);
+    }
+  } else {
+    if (!g.topo_note.empty()) g.topo_note += "; ";
+    g.topo_note += "link_metrics: unavailable";
+  }
+}
+
+static void read_xgmi_error(Gpu& g) {
+  if (!g.xgmi_err_supported) return;
+  amdsmi_xgmi_status_t st;
+  const amdsmi_status_t rc = amdsmi_gpu_xgmi_error_status(g.h, &st);
+  if (rc == AMDSMI_STATUS_SUCCESS) {
+    g.xgmi_err = st == AMDSMI_XGMI_STATUS_NO_ERRORS ? "no_errors" : st == AMDSMI_XGMI_STATUS_ERROR ? "error" : "multiple_errors";
+  } else {
+    g.xgmi_err_supported = false;      // MI355X answers NOT_SUPPORTED: ask once
+    g.xgmi_err = rc == AMDSMI_STATUS_NOT_SUPPORTED ? "not_supported" : "error: call failed";
+  }
+}
+
 // --selftest: render one line from synthetic metrics (no driver needed), including
 // unsupported-field sentinels and a 32-bit activity accumulator near its wrap. Lets the JSON
 // writer run under host sanitizers and feeds the Python reader in CPU tests.
@@ -248,6 +365,16 @@ static int selftest() {
       g.m.xgmi_write_data_acc[l] = self ? 0 : 43520298ull + l;
       g.m.xgmi_link_status[l] = self ? 0xFFFF : 1;
     }
+    g.have_xgmi_info = true;
+    g.hive_id = 6319504153631384352ull;
+    g.node_id = i;
+    g.xgmi_err = "not_supported";
+    for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
+      LinkTopo t;
+      t.max_gbps = 608;
+      if (l < 2 && (size_t)l != i) t.peer_bdf = l ? "0000:75:00.0" : "0000:72:00.0";   // the other selftest GPU; slots 2..7 unseen
+      g.links.push_back(t);
+    }
     for (double v : {10.0, 30.0}) g.gfx.add(v);
     g.umc.add(5);
     for (double v : {300.0, 900.0}) g.power.add(v);
@@ -262,6 +389,7 @@ static int selftest() {
     g.ecc.deferred_count = 0;
     g.have_ecc = true;
   }
+  resolve_peers(gpus);
   puts(render_line(gpus, 1234.5, 20, 6000.0).c_str());
   return 0;
 }
@@ -318,12 +446,8 @@ int main(int argc, char** argv) {
       unsigned int ul = AMDSMI_GPU_UUID_SIZE;
       if (amdsmi_get_gpu_device_uuid(g.h, &ul, uuid) == AMDSMI_STATUS_SUCCESS) g.uuid = uuid;
       amdsmi_bdf_t bdf;
-      if (amdsmi_get_gpu_device_bdf(g.h, &bdf) == AMDSMI_STATUS_SUCCESS) {
-        char b[32];
-        snprintf(b, sizeof b, "%04llx:%02x:%02x.%x", (unsigned long long)bdf.domain_number, (unsigned)bdf.bus_number,
-                 (unsigned)bdf.device_number, (unsigned)bdf.function_number);
-        g.bdf = b;
-      }
+      if (amdsmi_get_gpu_device_bdf(g.h, &bdf) == AMDSMI_STATUS_SUCCESS) g.bdf = bdf_str(bdf);
+      read_topology(g);
       amdsmi_power_cap_info_t cap;
       if (amdsmi_get_power_cap_info(g.h, 0, &cap) == AMDSMI_STATUS_SUCCESS && cap.power_cap)
         g.cap_w = cap.power_cap > 100000 ? cap.power_cap / 1e6 : (double)cap.power_cap;
@@ -338,6 +462,7 @@ int main(int argc, char** argv) {
     amdsmi_shut_down();
     return 3;
   }
+  resolve_peers(gpus);
 
   const double dt_poll = 1.0 / hz;
   double next_emit = mono_s() + (once ? 0.0 : period);
@@ -366,7 +491,10 @@ int main(int argc, char** argv) {
       // VRAM and ECC once per line: they are separate driver calls and change slowly
       for (auto& g : gpus) {
         g.have_vram = amdsmi_get_gpu_vram_usage(g.h, &g.vram) == AMDSMI_STATUS_SUCCESS;
-        if (slow % 10 == 0 || !g.have_ecc) g.have_ecc = amdsmi_get_gpu_total_ecc_count(g.h, &g.ecc) == AMDSMI_STATUS_SUCCESS;
+        if (slow % 10 == 0 || !g.have_ecc) {
+          g.have_ecc = amdsmi_get_gpu_total_ecc_count(g.h, &g.ecc) == AMDSMI_STATUS_SUCCESS;
+          read_xgmi_error(g);
+        }
       }
       ++slow;
       const std::string line = render_line(gpus, now, polls, poll_us);

@@ -215,7 +215,12 @@ class FakeGpuReader:
                 "res_vr_thm_acc": 0, "res_hbm_thm_acc": 0,
                 "xgmi_read_kib": [int(x) for x in a["rd"]], "xgmi_write_kib": [int(x) for x in a["wr"]],
                 "xgmi_link_status": status, "xgmi_link_width": 16, "xgmi_link_speed": 38,
-                "xgmi_peers": [None if l == i % 8 else f"0000:{0x10 + l:02x}:00.0" for l in range(8)],
+                # a full mesh as amdsmi reports it on an 8-GPU hive: link slot l of GPU i ends at the GPU whose xgmi node id is l
+                "xgmi_peers": [None if (l == i % 8 or l >= self.n) else f"0000:{0x10 + l:02x}:00.0" for l in range(8)],
+                "xgmi_peer_index": [None if (l == i % 8 or l >= self.n) else l for l in range(8)],
+                "xgmi_peer_source": [None if (l == i % 8 or l >= self.n) else "link_metrics" for l in range(8)],
+                "xgmi_link_max_gbps": [608] * 8, "xgmi_hive_id": 0x57b3c0de57b3c0de, "xgmi_node_id": i % 8,
+                "xgmi_nearest": [j for j in range(self.n) if j != i], "xgmi_topology_note": None, "xgmi_error_status": "no_errors",
                 "processes": 1,
                 "process_list": [{"pid": 40000 + i, "name": "python3 (vllm worker)", "vramBytes": int(HBM_TOTAL_MIB * s.hbm_frac) << 20}],
             })

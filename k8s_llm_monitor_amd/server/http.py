@@ -54,15 +54,35 @@ def _clean(o: Any) -> Any:
 
 
 def xgmi_matrix(gpus) -> Dict[str, Any]:
-    """Per-GPU, per-link table for the xGMI panel."""
+    """Per-GPU, per-link table for the xGMI panel, plus the GPU x GPU traffic matrix the topology calls make
+    possible: ``matrix[i][j]`` = {tx, rx, state} of the link from GPU i to GPU j (None where amdsmi names no
+    link between them). A down link or a link carrying far less than its siblings shows up as one cell."""
     rows = []
-    for g in gpus:
+    index_of = {g.get("index"): n for n, g in enumerate(gpus)}
+    matrix = [[None] * len(gpus) for _ in gpus]
+    notes = []
+    for n, g in enumerate(gpus):
         x = g.get("xgmi") or {}
         rows.append({"gpu": g.get("index"), "bdf": g.get("bdf"), "rxGBps": x.get("rxGBps"), "txGBps": x.get("txGBps"),
                      "linkSpeedGbps": x.get("linkSpeedGbps"), "linkWidth": x.get("linkWidth"),
+                     "hiveId": x.get("hiveId"), "nodeId": x.get("nodeId"), "peersKnown": x.get("peersKnown"),
+                     "errorStatus": x.get("errorStatus"), "topologyNote": x.get("topologyNote"),
                      "links": x.get("links") or []})
+        if x.get("topologyNote"):
+            notes.append(f"GPU{g.get('index')}: {x['topologyNote']}")
+        for l in x.get("links") or []:
+            j = index_of.get(l.get("peerIndex"))
+            if j is not None and j != n:
+                matrix[n][j] = {"link": l.get("link"), "state": l.get("state"), "txGBps": l.get("txGBps"), "rxGBps": l.get("rxGBps"),
+                                "source": l.get("peerSource")}
     total = sum(((r["rxGBps"] or 0.0) + (r["txGBps"] or 0.0)) for r in rows)
-    return {"gpus": rows, "totalGBps": total, "linkPeakGBps": rccl_probe.XGMI_LINK_GBPS}
+    # imbalance over the named, up links that carry traffic: busiest / mean (1.0 = even; a ring reads >> 1)
+    tx = [c["txGBps"] for row in matrix for c in row if c and c.get("state") == "up" and c.get("txGBps") is not None]
+    mean = sum(tx) / len(tx) if tx else 0.0
+    return {"gpus": rows, "totalGBps": total, "linkPeakGBps": rccl_probe.XGMI_LINK_GBPS,
+            "indices": [g.get("index") for g in gpus], "matrix": matrix,
+            "peersKnown": any(r.get("peersKnown") for r in rows), "notes": notes,
+            "linkImbalance": (max(tx) / mean) if mean > 1e-9 else None}
 
 
 # Paths whose body depends only on the sampler's snapshot: serialised once per snapshot

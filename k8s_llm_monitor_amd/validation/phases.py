@@ -242,7 +242,22 @@ def xgmi_expected_bytes(world: int, nbytes: int, iters: int) -> float:
 def xgmi_link_totals(sample: Dict[str, Any]) -> Dict[str, float]:
     links = (sample.get("xgmi") or {}).get("links") or []
     return {"tx": float(sum(l.get("txBytes") or 0 for l in links)), "rx": float(sum(l.get("rxBytes") or 0 for l in links)),
-            "per_link_tx": [float(l.get("txBytes") or 0) for l in links], "links_up": sum(1 for l in links if l.get("state") == "up")}
+            "per_link_tx": [float(l.get("txBytes") or 0) for l in links], "links_up": sum(1 for l in links if l.get("state") == "up"),
+            "peers": [l.get("peerIndex") for l in links], "peer_sources": sorted({l.get("peerSource") for l in links if l.get("peerSource")})}
+
+
+def xgmi_unit_check(counter_bytes_1024: float, want: float) -> Dict[str, Any]:
+    """The counters (`xgmi_read_data_acc`, = amdsmi_link_metrics_t.read/write) are documented as "KB". The dashboard
+    multiplies by 1024; this says which of 1024 / 1000 bytes per count the known traffic supports, and whether the
+    counter sees the algorithm's volume once (ratio ~1), per direction pair (~2) or not at all."""
+    if not want or not counter_bytes_1024:
+        return {"verdict": "no traffic to judge by"}
+    r1024 = counter_bytes_1024 / want
+    r1000 = r1024 * 1000.0 / 1024.0
+    best = min((abs(r1024 - 1.0), "KiB (x1024)"), (abs(r1000 - 1.0), "KB (x1000)"))
+    return {"ratio_if_1024": r1024, "ratio_if_1000": r1000, "error_pct_if_1024": abs(r1024 - 1.0) * 100.0,
+            "error_pct_if_1000": abs(r1000 - 1.0) * 100.0,
+            "verdict": best[1] if best[0] < 0.05 else f"neither unit explains the traffic (counter/expected = {r1024:.3f})"}
 
 
 def xgmi_fidelity(torch, dist, dev, rank: int, world: int, nbytes: int = 1 << 28, iters: int = 40,
@@ -293,7 +308,9 @@ def xgmi_fidelity(torch, dist, dev, rank: int, world: int, nbytes: int = 1 << 28
     after = xgmi_link_totals(s1) if s1 else before
     tx, rx = after["tx"] - before["tx"], after["rx"] - before["rx"]
     per_link = [a - b for a, b in zip(after["per_link_tx"], before["per_link_tx"])]
-    out.update({"counter_tx_bytes": tx, "counter_rx_bytes": rx, "links_up": after["links_up"],
+    out.update({"unit_check_tx": xgmi_unit_check(tx, want), "unit_check_rx": xgmi_unit_check(rx, want),
+                "peers": after.get("peers"), "peer_sources": after.get("peer_sources"),
+                "counter_tx_bytes": tx, "counter_rx_bytes": rx, "links_up": after["links_up"],
                 "tx_error_pct": abs(tx - want) / want * 100.0 if want else None,
                 "rx_error_pct": abs(rx - want) / want * 100.0 if want else None,
                 "per_link_tx_GB": [round(v / 1e9, 3) for v in per_link],

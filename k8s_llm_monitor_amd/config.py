@@ -38,6 +38,7 @@ class PeriodsConfig:
     history_step: float = 30.0       # monitor_server.js:119 ('30s')
     history_window: str = "30m"      # monitor_server.js:119 ('30m')
     alert_hold: float = 30.0         # how long an edge-triggered pod alert stays visible
+    page_alert_poll: float = 5.0     # the page's /api/alerts poll; the reference polls every 10 s (monitor.html:608)
     probe: float = 0.0               # RCCL probe re-run period, 0 = only on demand
     peers: float = 5.0               # cluster view: peer poll period
 
@@ -152,6 +153,24 @@ class CompatConfig:
     gpu0_only_alerts: bool = False   # reference alerts on GPU 0 only (:178)
     first_sight_alerts: bool = False # reference fires "Pod 刚恢复" for unseen pods (:194-207)
     language: str = "zh"             # alert text language: zh (reference) | en
+    reference_text: bool = False     # the reference's exact title / desc / fix strings (:163-230) for its own rules
+    reference_rules_only: bool = False   # evaluate only the rules the reference has (:162-232)
+    alert_extra_fields: bool = True  # /api/alerts items carry key / since / signal beside {title, desc, fix}
+    alerts_per_request: bool = False # evaluate on every GET /api/alerts against a state the request replaces (:282-288, :235):
+                                     # edge alerts appear in exactly one response, to whichever client polls first
+    reference_defaults: bool = False # ONE switch for a side-by-side run: everything below set to the reference's behaviour
+
+
+#: what ``compat.reference_defaults`` sets (explicit values in the same file / env still win where listed after it)
+REFERENCE_PRESET = {
+    "compat": {"cpu_percent": "load", "cpu_cores": 8,                     # load_1min / 8 (monitor_server.js:76)
+               "gpu0_only_alerts": True,                                  # :178
+               "first_sight_alerts": True,                                # :194-207
+               "language": "zh", "reference_text": True, "reference_rules_only": True, "alert_extra_fields": False,
+               "alerts_per_request": True},
+    "thresholds": {"gpu_temp": [-1.0, 75.0, 85.0]},                       # :183-184
+    "periods": {"page_alert_poll": 10.0},                                 # monitor.html:608
+}
 
 
 @dataclass
@@ -277,6 +296,8 @@ def load_config(path: Optional[str] = None, env: Optional[Mapping[str, str]] = N
     _apply_env(cfg, env)
     if overrides:
         _apply(cfg, overrides, "overrides")
+    if cfg.compat.reference_defaults:
+        _apply(cfg, REFERENCE_PRESET, "compat.reference_defaults")
     validate(cfg)
     return cfg
 

@@ -87,6 +87,13 @@ def _stream(t) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _on_device(t):
+    """The launchers act on the CURRENT HIP device (per-device kernel attributes, the launch itself): make that the
+    tensor's device for the duration of the call, so `--device 1` in a process whose current device is 0 works."""
+    import torch
+    return torch.cuda.device(t.device)
+
+
 def _require_cuda(*ts) -> None:
     for t in ts:
         if not t.is_cuda:
@@ -102,7 +109,8 @@ def version() -> str:
 def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
 
-    variant None picks the 256x256 ring kernel when the shape allows, else the 128x128 one.
+    variant None picks the 256x256 ring kernel when the shape allows, else the 128x128 one
+    (0: 128x128; 1: ring, schedule 0; 2: ring, one half-tile per phase -- see gemm_ring256.h).
     """
     import torch
     _require_cuda(a, b)
@@ -120,7 +128,8 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
         _require_cuda(out)
         if out.shape != (M, N) or out.dtype != torch.bfloat16:
             raise KlmOpsError("gemm_bf16: bad `out`")
-    rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+    with _on_device(a):
+        rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
     _check(rc, f"klm_gemm_bf16(M={M},N={N},K={K},variant={variant})")
     return out
 
@@ -140,7 +149,8 @@ def gemm_fp8(a, b, out=None, variant: int = 0):
     lib = load()
     if not hasattr(lib, "klm_gemm_fp8"):
         raise KlmOpsError("libklm_ops.so was built without the fp8 kernel")
-    rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+    with _on_device(a):
+        rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
     _check(rc, f"klm_gemm_fp8(M={M},N={N},K={K})")
     return out
 
@@ -158,7 +168,7 @@ def fp4_decode(packed):
     return torch.stack((lo, hi), dim=-1).reshape(*packed.shape[:-1], packed.shape[-1] * 2)
 
 
-def gemm_fp4(a, b, out=None):
+def gemm_fp4(a, b, out=None, variant: int = 0):
     """``out[M,N] (bf16) = A[M,K] @ B[N,K].T`` with e2m1 (fp4) inputs packed two per byte:
     `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2]."""
     import torch
@@ -175,7 +185,8 @@ def gemm_fp4(a, b, out=None):
     lib = load()
     if not hasattr(lib, "klm_gemm_fp4"):
         raise KlmOpsError("libklm_ops.so was built without the fp4 kernel")
-    rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, 0, _stream(a))
+    with _on_device(a):
+        rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, variant, _stream(a))
     _check(rc, f"klm_gemm_fp4(M={M},N={N},K={Kb * 2})")
     return out
 

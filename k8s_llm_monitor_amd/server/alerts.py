@@ -185,6 +185,35 @@ _MSG["en"] = {
     "ttft_desc": "TTFT p99 {v}s",
 }
 
+# The reference's own strings, byte for byte (monitor_server.js:163-184 host and GPU, :203-230 pods): an API output
+# table that clients may key on, selected by ``compat.reference_text`` (part of ``compat.reference_defaults``).
+# GPU titles carry no index there because only GPU 0 is checked (:178).
+_MSG["ref"] = dict(_MSG["zh"], **{
+    "cpu": {"critical": ("CPU 使用率过高", "建议：1. 检查是否有异常进程 2. 考虑扩容 CPU 核心数 3. 优化占用高的服务"),
+            "serious": ("CPU 使用率偏高", "建议：1. 查看占用最高的进程 2. 考虑升级 CPU 或增加实例 3. 检查是否有DDOS攻击"),
+            "minor": ("CPU 使用率轻度偏高", "建议：持续监控，必要时考虑扩容")},
+    "cpu_desc": "当前 CPU 使用率 {v}%",
+    "memory": {"critical": ("内存使用率过高", "建议：立即释放缓存 echo 3 > /proc/sys/vm/drop_caches 2. 重启占用内存大的服务 3. 扩容内存"),
+               "serious": ("内存使用率偏高", "建议：1. 检查内存泄漏 2. 增加 Swap 3. 考虑扩容内存"),
+               "minor": ("内存使用率轻度偏高", "建议：关注内存趋势，必要时扩容")},
+    "memory_desc": "当前内存使用率 {v}%",
+    "disk": {"critical": ("磁盘空间不足", "建议：1. 立即清理日志文件 2. 删除不必要的镜像/容器 3. 扩容磁盘"),
+             "serious": ("磁盘空间紧张", "建议：1. 清理旧日志 2. 删除临时文件 3. 计划扩容"),
+             "minor": ("磁盘使用率偏高", "建议：关注磁盘增长趋势，定期清理")},
+    "disk_desc": "磁盘使用率 {v}%",
+    "hbm": {"critical": ("GPU 显存不足", "建议：1. 减少 batch_size 2. 使用模型量化 3. 扩容 GPU 或使用多卡"),
+            "serious": ("GPU 显存使用偏高", "建议：监控模型推理性能，考虑优化显存使用"),
+            "minor": ("GPU 显存使用偏高", "建议：持续监控 GPU 显存使用情况")},
+    "hbm_desc": "GPU 显存使用 {u}/{t} MB ({p}%)",
+    "gpu_temp": {"critical": ("GPU 温度过高", "建议：1. 检查 GPU 散热风扇 2. 降低计算负载 3. 增加机房空调"),
+                 "serious": ("GPU 温度偏高", "建议：关注温度趋势，检查散热系统")},
+    "gpu_temp_desc": "GPU 温度 {v}°C",
+    "pod_failed": ("Pod 异常: {name}", "命名空间: {ns}, 状态: {st}", "建议：kubectl describe pod {name} -n {ns}"),
+    "pod_pending": ("Pod 等待调度: {name}", "命名空间: {ns}", "建议：kubectl describe pod {name} -n {ns}"),
+    "pod_recovered": ("Pod 刚恢复: {name}", "命名空间: {ns}, 之前状态: {prev}", "建议：检查之前故障原因 kubectl describe pod {name} -n {ns}"),
+    "pod_restart": ("Pod 重启: {name}", "命名空间: {ns}, 重启次数: {n}次 (增加了{d}次)", "建议：kubectl logs {name} -n {ns} --previous 查看重启前日志"),
+})
+
 #: container waiting reasons -> tier
 WAITING_REASONS = {"CrashLoopBackOff": "critical", "ImagePullBackOff": "serious", "ErrImagePull": "serious",
                    "CreateContainerConfigError": "serious", "CreateContainerError": "serious",
@@ -215,7 +244,8 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
     from ..config import Config
     cfg = cfg or Config()
     th, compat = cfg.thresholds, cfg.compat
-    msgs = _MSG.get(compat.language, _MSG["zh"])
+    msgs = _MSG["ref"] if getattr(compat, "reference_text", False) else _MSG.get(compat.language, _MSG["zh"])
+    ref_only = bool(getattr(compat, "reference_rules_only", False))     # only the rules of monitor_server.js:162-232
     state = state or AlertState()
     alerts = empty_alerts()
 
@@ -245,6 +275,8 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
         if isinstance(temp, (int, float)):
             _tiered(alerts, msgs, "gpu_temp", f"{k}/temp", float(temp), th.gpu_temp,
                     msgs["gpu_temp_desc"].format(v=_js_num(temp)), g)
+        if ref_only:
+            continue
         thbm = gpu.get("temperatureHbm")
         if isinstance(thbm, (int, float)):
             _tiered(alerts, msgs, "hbm_temp", f"{k}/hbm_temp", float(thbm), th.hbm_temp,
@@ -289,7 +321,7 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
         if isinstance(ppt, (int, float)) and ppt > 50.0:
             t, d, f = msgs["throttle_ppt"]
             _add(alerts, "minor", f"{k}/throttle_ppt", t.format(g=g), d.format(p=_fmt(ppt)), f, signal="throttle")
-    if state.gpu_count is not None and len(gpus) < state.gpu_count:
+    if not ref_only and state.gpu_count is not None and len(gpus) < state.gpu_count:
         t, d, f = msgs["gpu_lost"]
         _add(alerts, "critical", "gpu/lost", t, d.format(n=len(gpus), m=state.gpu_count), f, signal="gpu_lost")
     # the count only ever ratchets up, so the alert stays level-triggered until the GPU is back
@@ -323,7 +355,7 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
             t, d, f = msgs["pod_pending"]
             _add(alerts, "serious", f"pod/{key}/pending", t.format(**fmt), d.format(**fmt), f.format(**fmt), signal="pod")
         reason = pod.get("reason")
-        if reason in WAITING_REASONS and status not in ("Failed", "Error"):
+        if not ref_only and reason in WAITING_REASONS and status not in ("Failed", "Error"):
             t, d, f = msgs["pod_waiting"]
             _add(alerts, WAITING_REASONS[reason], f"pod/{key}/waiting", t.format(**fmt),
                  d.format(reason=reason, **fmt), f.format(**fmt), signal="pod")
@@ -331,11 +363,13 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
     # ---- vLLM serving metrics (no reference rule)
     # an endpoint that answered once and no longer does is an outage, not "no data": level-triggered,
     # critical when nothing answers, serious when some replicas are gone (direct scraping counts them)
+    if ref_only:
+        vllm = None
     n_ep = 0
     if vllm:
         e = vllm.get("endpoints")
         n_ep = int(e) if isinstance(e, (int, float)) and e > 0 else 1
-    if state.vllm_endpoints and n_ep < state.vllm_endpoints:
+    if not ref_only and state.vllm_endpoints and n_ep < state.vllm_endpoints:
         t, d, f = msgs["vllm_down"]
         _add(alerts, "critical" if n_ep == 0 else "serious", "vllm/down", t, d.format(n=n_ep, m=state.vllm_endpoints), f,
              signal="vllm_down")

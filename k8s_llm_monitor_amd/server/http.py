@@ -114,6 +114,8 @@ class MonitorServer:
         self.static_dir = static
         # like the reference, the page is read once at start-up and a missing file is fatal (:241)
         self.html = (static / "monitor.html").read_bytes()
+        # the page's alert poll period is configuration (reference: 10 s, monitor.html:608; default here 5 s)
+        self.html = self.html.replace(b"/*ALERT_POLL_MS*/5000", b"%d" % int(self.cfg.periods.page_alert_poll * 1000))
         self._cache: Dict[str, Tuple[int, Tuple[int, str, bytes]]] = {}
         self._head_cors = ("Access-Control-Allow-Origin: %s\r\nAccess-Control-Allow-Methods: GET, OPTIONS\r\n"
                            % self.cfg.server.cors_origin).encode("latin-1")
@@ -154,7 +156,7 @@ class MonitorServer:
     # ---- routing -------------------------------------------------------------------------
     def route(self, path: str) -> Optional[Tuple[int, str, bytes]]:
         """(status, content type, body) for a GET, None for an unknown path."""
-        if path in _SNAPSHOT_PATHS:
+        if path in _SNAPSHOT_PATHS and not (path == "/api/alerts" and self.cfg.compat.alerts_per_request):
             ver = self.monitor.version
             hit = self._cache.get(path)
             if hit is not None and hit[0] == ver:

@@ -168,6 +168,7 @@ class Monitor:
                                       "vllm": {"available": False}, "alerts": empty_alerts(),
                                       "t_host": 0.0, "t_gpu": 0.0, "t_pods": 0.0, "t_vllm": 0.0, "t_alerts": 0.0}
         self._alert_state = AlertState()
+        self._request_alert_state = AlertState()      # compat.alerts_per_request: the reference's lastPodStates (:157)
         self.version = 0            # bumped whenever the snapshot changes (HTTP body cache key)
         self.book = AlertBook(hold_s=c.periods.alert_hold, debounce_s=c.notify.debounce_s)
         self.notifier = None
@@ -338,11 +339,20 @@ class Monitor:
             return dict(self._snap)
 
     def alerts_public(self) -> Dict[str, List[Dict[str, Any]]]:
-        """The reference's shape: three lists of ``{title, desc, fix}`` (+ ``since``, ``key``)."""
+        """The reference's shape: three lists of ``{title, desc, fix}`` (+ ``since``, ``key``, ``signal`` unless
+        ``compat.alert_extra_fields`` is off). With ``compat.alerts_per_request`` the rules are evaluated here, per
+        call, on the current snapshot against a state this call replaces: the reference's semantics exactly
+        (monitor_server.js:282-288 and :235), including its first-sight and alert-stealing behaviour. The
+        collectors still do not run per request."""
+        keep = ("title", "desc", "fix", "since", "key", "signal") if self.cfg.compat.alert_extra_fields else ("title", "desc", "fix")
         with self._lock:
-            a = self._snap["alerts"]
-            return {tier: [{k: v for k, v in x.items() if k in ("title", "desc", "fix", "since", "key", "signal")}
-                           for x in a[tier]] for tier in ("minor", "serious", "critical")}
+            if self.cfg.compat.alerts_per_request:
+                s = self._snap
+                a, self._request_alert_state = check_alerts(s["host"], s["gpus"], s["pods"], self._request_alert_state, self.cfg,
+                                                            s["vllm"] if s["vllm"].get("available") else None)
+            else:
+                a = self._snap["alerts"]
+            return {tier: [{k: x[k] for k in keep if k in x} for x in a[tier]] for tier in ("minor", "serious", "critical")}
 
     def prometheus_available(self) -> bool:
         now = time.monotonic()

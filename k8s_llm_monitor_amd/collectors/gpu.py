@@ -43,6 +43,8 @@ def _num(x: Any) -> Optional[float]:
 
 
 def _int(x: Any) -> Optional[int]:
+    if isinstance(x, int) and not isinstance(x, bool):
+        return x                      # 64-bit ids and accumulators must not pass through a float
     v = _num(x)
     return None if v is None else int(v)
 

@@ -31,7 +31,7 @@ class LinearLayerStep:
         dd = self.distributed = (world > 1) if distributed is None else bool(distributed)
         # `gemm(a, b, out)` computes out = a @ b.T; the default is the hand-written MFMA kernel.
         # CPU tests of the stream/event/all-reduce logic pass a torch.matmul stand-in.
-        self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out, variant=1))
+        self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out))
         self.gpu = dev.type == "cuda"
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + (dist.get_rank() if dd else 0))

@@ -109,8 +109,9 @@ def version() -> str:
 def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
 
-    variant None picks the 256x256 ring kernel when the shape allows, else the 128x128 one
-    (0: 128x128; 1: ring, schedule 0; 2: ring, one half-tile per phase -- see gemm_ring256.h).
+    variant None picks the 256x256 ring kernel on its fastest schedule when the shape allows, else the 128x128 one
+    (0: 128x128; 1: ring, schedule 0; 2: ring, one half-tile per phase -- see gemm_ring256.h; 3: experimental
+    4-wave 128x128-per-wave kernel, gemm_quad128.h).
     """
     import torch
     _require_cuda(a, b)
@@ -121,7 +122,10 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     M, K = a.shape
     N = b.shape[0]
     if variant is None:
-        variant = 1 if (M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128) else 0
+        if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
+            variant = 2 if (K % 128 == 0 and K >= 256) else 1      # schedule 1 needs an even number of K tiles >= 4
+        else:
+            variant = 0
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     else:
@@ -134,8 +138,9 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     return out
 
 
-def gemm_fp8(a, b, out=None, variant: int = 0):
-    """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the MX-scaled MFMA."""
+def gemm_fp8(a, b, out=None, variant: int = 1):
+    """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the MX-scaled MFMA.
+    variant 1 (default): ring schedule 1 when the K tile count allows, else schedule 0; variant 0: schedule 0."""
     import torch
     _require_cuda(a, b)
     if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
@@ -168,7 +173,7 @@ def fp4_decode(packed):
     return torch.stack((lo, hi), dim=-1).reshape(*packed.shape[:-1], packed.shape[-1] * 2)
 
 
-def gemm_fp4(a, b, out=None, variant: int = 0):
+def gemm_fp4(a, b, out=None, variant: int = 1):
     """``out[M,N] (bf16) = A[M,K] @ B[N,K].T`` with e2m1 (fp4) inputs packed two per byte:
     `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2]."""
     import torch

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemm_quad128.h"
 #include "gemm_ring256.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -245,6 +246,76 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_t(const uint16_t* __restric
         }
 }
 
+// ------------------------------------------------------------------------------------
+// 256x256x64 on 4 waves of 128x128 (gemm_quad128.h): bf16 operand policy. A part is a k step of 32.
+// ------------------------------------------------------------------------------------
+struct klm_op_quad_bf16 {
+  f32x4 acc[8][8];                 // [m tile][n tile]: 256 accumulator registers
+  bf16x8 fa[2][8], fb[2][8];       // [fragment set][tile]
+  int a_off[2], b_off[2];          // per k step
+
+  __device__ __forceinline__ void init(int lane, int wr, int wc) {
+    const int fr = lane & 15, fq = lane >> 4, key = lane & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ((ks * 4 + fq) ^ key) << 4;
+      a_off[ks] = (wr * 128 + fr) * 128 + ch;
+      b_off[ks] = KLM_QUAD_B_OFFSET + (wc * 128 + fr) * 128 + ch;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // fragment read R of 16 in the order the m-tile-major MFMA sequence needs them: A0, B0..B7, A1..A7
+  template <int SET, int PART, int R>
+  __device__ __forceinline__ void read1(const char* stage) {
+    if constexpr (R == 0) fa[SET][0] = *reinterpret_cast<const bf16x8*>(stage + a_off[PART]);
+    else if constexpr (R <= 8) fb[SET][R - 1] = *reinterpret_cast<const bf16x8*>(stage + b_off[PART] + (R - 1) * 2048);
+    else fa[SET][R - 8] = *reinterpret_cast<const bf16x8*>(stage + a_off[PART] + (R - 8) * 2048);
+  }
+  template <int SET, int PART>
+  __device__ __forceinline__ void read_all(const char* stage) {
+    read1<SET, PART, 0>(stage); read1<SET, PART, 1>(stage); read1<SET, PART, 2>(stage); read1<SET, PART, 3>(stage);
+    read1<SET, PART, 4>(stage); read1<SET, PART, 5>(stage); read1<SET, PART, 6>(stage); read1<SET, PART, 7>(stage);
+    read1<SET, PART, 8>(stage); read1<SET, PART, 9>(stage); read1<SET, PART, 10>(stage); read1<SET, PART, 11>(stage);
+    read1<SET, PART, 12>(stage); read1<SET, PART, 13>(stage); read1<SET, PART, 14>(stage); read1<SET, PART, 15>(stage);
+  }
+  // MFMAs 4G .. 4G+3 of the 64 (m tile major): X = B rows (n), Y = A rows (m): D[n][m], a lane holds 4 consecutive n of one m
+  template <int SET, int PART, int G>
+  __device__ __forceinline__ void mfma4() {
+    constexpr int mi = G >> 1, n0 = (G & 1) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mi][n0 + j]) : "v"(fb[SET][n0 + j]), "v"(fa[SET][mi]));
+  }
+};
+
+__global__ __launch_bounds__(256) void gemm_bf16_quad(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                      uint16_t* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  int tm, tn;
+  tile_of_block<8>(blockIdx.x, M >> 8, N >> 8, tm, tn);
+  const int brow = tm << 8, bcol = tn << 8;
+  klm_stage_quad st;
+  st.init(A, B, brow, bcol, (unsigned)K * 2, (unsigned)K * 2, lane, wid, smem);
+  klm_op_quad_bf16 op;
+  op.init(lane, wr, wc);
+  klm_quad_mainloop(op, st, smem, K >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const int m = brow + wr * 128 + mi * 16 + fr;
+      const int n = bcol + wc * 128 + ni * 16 + fq * 4;
+      store_c4(C, (size_t)m * N + n, op.acc[mi][ni]);
+    }
+}
+
 extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                              void* stream) {
   if (!A || !B || !C) return KLM_ERR_ARG;
@@ -256,6 +327,12 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     if ((M & 127) || (N & 127) || (K & 63)) return KLM_ERR_SHAPE;
     const int grid = (M >> 7) * (N >> 7);
     hipLaunchKernelGGL(gemm_bf16_128, dim3(grid), dim3(256), 32768, s, (const uint16_t*)A,
+                       (const uint16_t*)B, (uint16_t*)C, M, N, K);
+  } else if (variant == 3) {
+    // 4 waves of 128x128; an even number of K tiles >= 4
+    if ((M & 255) || (N & 255) || (K & 127) || K < 256) return KLM_ERR_SHAPE;
+    if (int e = klm_ensure_dyn_lds<gemm_bf16_quad>(KLM_QUAD_LDS_BYTES)) return e;
+    hipLaunchKernelGGL(gemm_bf16_quad, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, (const uint16_t*)A,
                        (const uint16_t*)B, (uint16_t*)C, M, N, K);
   } else if (variant == 1 || variant == 2) {
     if ((M & 255) || (N & 255) || (K & 63) || K < 128) return KLM_ERR_SHAPE;

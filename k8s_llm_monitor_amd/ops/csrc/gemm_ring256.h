@@ -29,6 +29,7 @@
 //            half-tile gets the same three phases of flight time. B0 of the NEXT tile is read in phase 3 into the
 //            operand registers the (a1,b1) quadrant has just released, so the b0 / b1 register sets swap roles
 //            every tile (the loop is unrolled by two tiles; no extra registers). Needs an even number of K tiles >= 4.
+// Measured and dropped (docs/KERNELS.md): two phases of 32 MFMAs per K tile (half the barriers): 0.98x of schedule 1.
 //
 // Hazards (same rules for both schedules; cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait
 // that retires it"): a half-tile is read one phase after the phase whose counted wait (placed before that phase's
@@ -204,7 +205,7 @@ __device__ __forceinline__ void klm_ring256_mainloop(OP& op, const STAGE& st, co
       KLM_BAR();
     }
     if (wr == 0) KLM_BAR();  // matches group 1's extra barrier in the prologue
-  } else {
+  } else if constexpr (SCHED == 1) {
     const char* const s0 = smem;
     const char* const s1 = smem + KLM_STAGE_BYTES;
     // ---- prologue: h0..h4 = B0(0) A0(0) B1(0) A1(0) B0(1); B0(0) goes to register set 0 ("phase -1" read)

@@ -29,7 +29,9 @@ def check_small():
         a32, b32 = rnd(M, K), rnd(Nn, K)
         a, b = a32.bfloat16(), b32.bfloat16()
         ref = a.float() @ b.float().t()
-        for v in (1, 2):
+        for v in (1, 2, 3):
+            if v == 3 and (K % 128 or K < 256):
+                continue
             c = ops.gemm_bf16(a, b, variant=v).float()
             err = (c - ref).abs().max().item() / ref.abs().max().item()
             out[f"bf16_v{v}_{M}x{Nn}x{K}"] = err
@@ -82,6 +84,7 @@ def main():
     ref = torch.matmul(a, bt)
     big = {}
     for name, fn in (("bf16_v1", lambda: ops.gemm_bf16(a, b, out=c, variant=1)), ("bf16_v2", lambda: ops.gemm_bf16(a, b, out=c, variant=2)),
+                     ("bf16_v3", lambda: ops.gemm_bf16(a, b, out=c, variant=3)),
                      ("fp8_v0", lambda: ops.gemm_fp8(a8, b8, out=c, variant=0)), ("fp8_v1", lambda: ops.gemm_fp8(a8, b8, out=c, variant=1)),
                      ("fp4_v0", lambda: ops.gemm_fp4(a4, b4, out=c, variant=0)), ("fp4_v1", lambda: ops.gemm_fp4(a4, b4, out=c, variant=1))):
         fn()
@@ -97,14 +100,16 @@ def main():
     big["fp8_v1_equals_v0"] = bool(torch.equal(ops.gemm_fp8(a8, b8, variant=0), ops.gemm_fp8(a8, b8, variant=1)))
     big["fp4_v1_equals_v0"] = bool(torch.equal(ops.gemm_fp4(a4, b4, variant=0), ops.gemm_fp4(a4, b4, variant=1)))
     big["bf16_v2_equals_v1"] = bool(torch.equal(ops.gemm_bf16(a, b, variant=1), ops.gemm_bf16(a, b, variant=2)))
+    big["bf16_v3_equals_v1"] = bool(torch.equal(ops.gemm_bf16(a, b, variant=1), ops.gemm_bf16(a, b, variant=3)))
     res["big_checks"] = big
     log("big checks", json.dumps(big))
     assert all(v["bit_identical_13_runs"] for k, v in big.items() if isinstance(v, dict)), big
-    assert big["fp8_v1_equals_v0"] and big["fp4_v1_equals_v0"] and big["bf16_v2_equals_v1"], big
+    assert big["fp8_v1_equals_v0"] and big["fp4_v1_equals_v0"] and big["bf16_v2_equals_v1"] and big["bf16_v3_equals_v1"], big
 
     arms = {
         "bf16_v1": (lambda: ops.gemm_bf16(a, b, out=c, variant=1), 2.0 * N ** 3),
         "bf16_v2": (lambda: ops.gemm_bf16(a, b, out=c, variant=2), 2.0 * N ** 3),
+        "bf16_v3": (lambda: ops.gemm_bf16(a, b, out=c, variant=3), 2.0 * N ** 3),
         "bf16_hipblaslt": (lambda: torch.matmul(a, bt, out=c), 2.0 * N ** 3),
         "fp8_v0": (lambda: ops.gemm_fp8(a8, b8, out=c, variant=0), 2.0 * N ** 3),
         "fp8_v1": (lambda: ops.gemm_fp8(a8, b8, out=c, variant=1), 2.0 * N ** 3),
@@ -125,7 +130,9 @@ def main():
         log(f"round {r} ({time.time() - t0:.0f}s):", {k: round(v[-1], 1) for k, v in runs.items()})
     res["tflops"] = {k: {"median": sorted(v)[len(v) // 2], "min": min(v), "max": max(v), "runs": [round(x, 1) for x in v]} for k, v in runs.items()}
     med = lambda k: res["tflops"][k]["median"] if k in res["tflops"] else None
-    res["ratios"] = {"bf16_v2_over_v1": med("bf16_v2") / med("bf16_v1") if med("bf16_v2") and med("bf16_v1") else None,
+    res["ratios"] = {"bf16_v3_over_hipblaslt": med("bf16_v3") / med("bf16_hipblaslt") if med("bf16_v3") and med("bf16_hipblaslt") else None,
+                     "bf16_v3_over_v2": med("bf16_v3") / med("bf16_v2") if med("bf16_v3") and med("bf16_v2") else None,
+                     "bf16_v2_over_v1": med("bf16_v2") / med("bf16_v1") if med("bf16_v2") and med("bf16_v1") else None,
                      "bf16_v2_over_hipblaslt": med("bf16_v2") / med("bf16_hipblaslt") if med("bf16_v2") and med("bf16_hipblaslt") else None,
                      "bf16_v1_over_hipblaslt": med("bf16_v1") / med("bf16_hipblaslt") if med("bf16_v1") and med("bf16_hipblaslt") else None,
                      "fp8_v1_over_v0": med("fp8_v1") / med("fp8_v0") if med("fp8_v1") and med("fp8_v0") else None,

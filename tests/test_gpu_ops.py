@@ -17,6 +17,8 @@ def env():
 
 @pytest.mark.parametrize("variant,shape", [(0, (128, 128, 64)), (0, (256, 384, 192)), (0, (1024, 512, 2048)),
                                            (1, (256, 256, 128)), (1, (512, 768, 320)), (1, (2048, 1024, 4096)),
+                                           (2, (256, 256, 256)), (2, (512, 768, 384)), (2, (2048, 1024, 4096)), (2, (256, 512, 4224)),
+                                           (3, (256, 256, 256)), (3, (512, 768, 384)), (3, (1024, 512, 4096)),
                                            (None, (1024, 1024, 1024)), (None, (384, 128, 64))])
 def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch, ops, dev = env
@@ -30,10 +32,10 @@ def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=1e-2 * K ** 0.5)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_gemm_bf16_exact_on_small_integers_with_asymmetric_operands(env, variant):
     torch, ops, dev = env
-    M, N, K = 512, 256, 192
+    M, N, K = 512, 256, (192 if variant < 2 else 384)
     g = torch.Generator(device=dev).manual_seed(7)
     a = torch.randint(-3, 4, (M, K), device=dev, generator=g).to(torch.bfloat16)
     b = torch.randint(-3, 4, (N, K), device=dev, generator=g).to(torch.bfloat16)
@@ -48,7 +50,7 @@ def test_gemm_bf16_identity_picks_rows_not_columns(env):
     n = 256
     eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
     b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)      # asymmetric
-    for v in (0, 1):
+    for v in (0, 1, 2, 3):
         assert torch.equal(ops.gemm_bf16(eye, b, variant=v), b.t().contiguous())      # C = I @ B^T
 
 
@@ -57,8 +59,9 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
     a = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     b = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     c0 = ops.gemm_bf16(a, b, variant=1).clone()
-    for _ in range(20):
-        assert torch.equal(ops.gemm_bf16(a, b, variant=1), c0)       # a ring-buffer race would show as a rare diff
+    for v in (1, 2, 3):                                               # every pipeline gives the same bits, every run
+        for _ in range(20):
+            assert torch.equal(ops.gemm_bf16(a, b, variant=v), c0)   # a ring-buffer race would show as a rare diff
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096)])
@@ -71,6 +74,7 @@ def test_gemm_fp8_matches_fp32_reference(env, shape):
     c = ops.gemm_fp8(a, b)
     ref = a.float() @ b.float().t()                      # the fp8 VALUES are exact in fp32
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=2e-3 * K ** 0.5)
+    assert torch.equal(c, ops.gemm_fp8(a, b, variant=0))   # both ring schedules: same order of accumulation, same bits
 
 
 def test_gemm_fp8_exact_on_small_integers(env):
@@ -97,6 +101,7 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     a[:, 3] = (torch.arange(M, device=dev) % 251).to(torch.uint8)            # position- and row-dependent bytes
     b[:, K // 2 - 5] = (torch.arange(N, device=dev) % 239).to(torch.uint8)
     c = ops.gemm_fp4(a, b)
+    assert torch.equal(c, ops.gemm_fp4(a, b, variant=0))
     ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
     assert torch.equal(c, ref.float().to(torch.bfloat16))
     if hasattr(torch, "float4_e2m1fn_x2"):

@@ -27,6 +27,7 @@ class ServerConfig:
     static_dir: str = ""             # "" = the package's web/ directory
     state_dir: str = ""              # checkpoint/resume of history + alert state; "" = keep nothing on disk
     persist_period: float = 60.0     # seconds between checkpoints
+    expose_config: bool = False      # GET /api/config (the running configuration: URLs, paths, peers); off: 404
 
 
 @dataclass

@@ -456,6 +456,17 @@ class AlertBook:
             out[a["tier"]].append(a)
         return out
 
+    # ---- checkpoint / resume: a restart must not re-announce what was already announced (webhook, history, `since`)
+    def to_state(self) -> Dict[str, Any]:
+        return {"announced": dict(self._announced), "since": dict(self._since),
+                "held": {k: [until, a] for k, (until, a) in self._held.items()}, "history": list(self.history)}
+
+    def load_state(self, d: Mapping[str, Any]) -> None:
+        self._announced = {str(k): str(v) for k, v in (d.get("announced") or {}).items()}
+        self._since = {str(k): float(v) for k, v in (d.get("since") or {}).items()}
+        self._held = {str(k): (float(v[0]), dict(v[1])) for k, v in (d.get("held") or {}).items()}
+        self.history = [dict(e) for e in (d.get("history") or [])][-self.max_history:]
+
     def _log(self, what: str, a: Mapping[str, Any], now: float) -> None:
         ev = {"t": now, "event": what, "key": a.get("key"), "tier": a.get("tier"), "title": a.get("title"),
               "desc": a.get("desc"), "fix": a.get("fix")}

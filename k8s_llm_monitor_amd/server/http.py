@@ -18,7 +18,7 @@ Added (additive only): ``/api/vllm/metrics``, ``/api/xgmi``, ``/api/rccl/probe``
 ``/api/alerts/history``, ``/api/cluster`` (this node plus its configured peers), ``/api/summary`` (everything the page needs in one request),
 ``/api/events`` (server-sent events, so an alert reaches an open page without waiting for
 its next poll), ``/api/monitor/stats``, ``/api/validation``, ``/metrics`` (Prometheus text),
-``/healthz``. Handlers read the sampler's snapshot and never run a collector.
+``/healthz``, and ``/api/config`` (only with ``server.expose_config``; credentials redacted). Handlers read the sampler's snapshot and never run a collector.
 """
 from __future__ import annotations
 
@@ -205,7 +205,8 @@ class MonitorServer:
             st = m.stats()
             st["http_requests"] = self.requests
             return 200, JSON_CT, _dumps(st)
-        if path == "/api/config":
+        if path == "/api/config" and self.cfg.server.expose_config:
+            # off by default: CORS is "*" like the reference's, so any page the operator's browser visits could read it
             return 200, JSON_CT, _dumps(redacted_config(self.cfg))
         if path == "/metrics":
             return 200, "text/plain; version=0.0.4; charset=utf-8", exporter.render(m.snapshot(), m.stats()).encode("utf-8")
@@ -380,8 +381,10 @@ class MonitorServer:
 
 
 def redacted_config(cfg: Config) -> Dict[str, Any]:
-    """The running configuration without anything that can carry a credential."""
+    """The running configuration without anything that can carry a credential: the webhook URL is cut to its
+    origin and the service-account token path is dropped."""
     d = cfg.to_dict()
+    d.get("sources", {}).pop("kube_token_file", None)
     url = d.get("notify", {}).get("webhook_url") or ""
     if url:
         from urllib.parse import urlsplit

@@ -190,7 +190,7 @@ class Monitor:
         if c.periods.probe > 0:
             self.tasks["probe"] = PeriodicTask("probe", self.run_probe, c.periods.probe)
         self.state_dir = c.server.state_dir
-        self.restored: Dict[str, Any] = {"history": False, "alert_state": False}
+        self.restored: Dict[str, Any] = {"history": False, "alert_state": False, "alert_book": False}
         if self.state_dir:
             self.tasks["persist"] = PeriodicTask("persist", self.checkpoint, max(1.0, c.server.persist_period))
             self.restore()
@@ -212,7 +212,8 @@ class Monitor:
             st = self._alert_state
             doc = {"saved": self.clock(), "pods": st.pods, "gpu_count": st.gpu_count,
                    "ecc_correctable": {str(k): v for k, v in st.ecc_correctable.items()},
-                   "vllm_endpoints": st.vllm_endpoints, "evaluations": st.evaluations}
+                   "vllm_endpoints": st.vllm_endpoints, "evaluations": st.evaluations,
+                   "book": self.book.to_state()}
         tmp = self._state_path(f"alert_state.json.tmp.{os.getpid()}")
         with open(tmp, "w", encoding="utf-8") as f:
             json.dump(doc, f)
@@ -230,6 +231,10 @@ class Monitor:
                                                vllm_endpoints=int(d.get("vllm_endpoints", 0)),
                                                evaluations=int(d.get("evaluations", 0)))
                 self.restored["alert_state"] = True
+                if isinstance(d.get("book"), dict):
+                    # alerts that were live before the restart keep their `since`, log no second "begin" and post no second webhook
+                    self.book.load_state(d["book"])
+                    self.restored["alert_book"] = True
         except (OSError, ValueError, KeyError, TypeError, AttributeError):
             pass
 
@@ -277,6 +282,10 @@ class Monitor:
     def _evaluate(self, now: float) -> None:
         with self._lock:
             s = self._snap
+            if not (s["t_host"] and s["t_pods"]):
+                # not every source has reported yet (start-up, or right after a restart): an evaluation on half a
+                # snapshot would "end" every restored alert of the missing half and announce it again a moment later
+                return
             alerts, self._alert_state = check_alerts(s["host"], s["gpus"], s["pods"], self._alert_state, self.cfg,
                                                      s["vllm"] if s["vllm"].get("available") else None)
             shown = self.book.update(alerts, now)
@@ -370,12 +379,25 @@ class Monitor:
             # a few seconds (the data has a 30 s step; the page asks every 30 s)
             ttl = min(5.0, self.cfg.periods.history_step / 2)
             now = time.monotonic()
-            with self._hist_lock:
-                if self._hist_cache is not None and now - self._hist_cache[0] < ttl:
-                    return self._hist_cache[1]
+            cache = self._hist_cache
+            if cache is not None and now - cache[0] < ttl:
+                return cache[1]
+            # ONE refresh at a time, and nobody waits for it with a result in hand: with Prometheus slow (six queries
+            # of up to `timeout` each) every other request gets the previous result instead of queueing on a lock
+            # inside the executor, where a handful of dashboards used to occupy every thread
+            if cache is not None and not self._hist_lock.acquire(blocking=False):
+                return cache[1]
+            if cache is None:
+                self._hist_lock.acquire()
+            try:
+                cache = self._hist_cache
+                if cache is not None and time.monotonic() - cache[0] < ttl:
+                    return cache[1]
                 out = self._history_from_prometheus()
                 self._hist_cache = (time.monotonic(), out)
                 return out
+            finally:
+                self._hist_lock.release()
         out = self.local_history.payload()
         out["source"] = "local"
         return out

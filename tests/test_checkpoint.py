@@ -26,7 +26,7 @@ def test_history_and_alert_state_survive_a_restart(tmp_path, clock):
     assert os.path.exists(tmp_path / "history.json") and os.path.exists(tmp_path / "alert_state.json")
 
     m2 = make(clock, tmp_path, kube="steady")                     # the pending pod is now gone, the others still run
-    assert m2.restored == {"history": True, "alert_state": True}
+    assert m2.restored == {"history": True, "alert_state": True, "alert_book": True}
     assert len(m2.history()["cpu"]["data"]) == 4                  # charts keep their window
     assert "llm/vllm-llama3-8b-7f9c6d5b8-2xkzv" in m2._alert_state.pods
     m2.tick_all()
@@ -63,7 +63,7 @@ def test_stale_or_corrupt_state_is_ignored(tmp_path, clock):
     (tmp_path / "alert_state.json").write_text("{broken")
     (tmp_path / "history.json").write_text("[]")
     m3 = make(clock, tmp_path)
-    assert m3.restored == {"history": False, "alert_state": False}
+    assert m3.restored == {"history": False, "alert_state": False, "alert_book": False}
     m3.tick_all()
     m3.stop()
     json.loads((tmp_path / "alert_state.json").read_text())       # rewritten cleanly
@@ -76,3 +76,50 @@ def test_no_state_dir_writes_nothing(tmp_path, clock, monkeypatch):
     m.tick_all()
     m.stop()
     assert "persist" not in m.tasks and os.listdir(tmp_path) == []
+
+
+def test_live_alert_is_not_announced_twice_across_a_restart(tmp_path, clock):
+    """a restart used to log a fresh `begin` for every level-triggered alert (a second webhook
+    post), reset `since` to the restart time and lose /api/alerts/history."""
+    from k8s_llm_monitor_amd.fakes.gpu import GpuState
+
+    def hot(t, i):
+        return GpuState(hbm_frac=0.97 if i == 0 else 0.30)
+
+    def mk():
+        cfg = demo_config(server={"state_dir": str(tmp_path)}, periods={"history_step": 5.0})
+        m = Monitor(cfg, gpu=GpuSource(FakeGpuReader(2, scenario=hot, clock=clock)), kube=FakeKube("steady", clock=clock), clock=clock)
+        posted = []
+        m.book.on_event = posted.append                    # what WebhookNotifier would be handed
+        return m, posted
+
+    m1, posted1 = mk()
+    t_begin = clock()
+    m1.tick_all()
+    clock.advance(5)
+    m1.tick_all()
+    crit = m1.alerts_public()["critical"]
+    assert [a["key"] for a in crit] == ["gpu/0/hbm"] and crit[0]["since"] == t_begin
+    assert [(e["event"], e["key"]) for e in posted1] == [("begin", "gpu/0/hbm")]
+    m1.stop()
+
+    clock.advance(30)                                       # down for half a minute, the GPU is still full
+    m2, posted2 = mk()
+    assert m2.restored["alert_book"] is True
+    m2.tick_all()
+    clock.advance(5)
+    m2.tick_all()
+    crit = m2.alerts_public()["critical"]
+    assert [a["key"] for a in crit] == ["gpu/0/hbm"] and crit[0]["since"] == t_begin     # began before the restart
+    assert posted2 == []                                    # no second begin, no second webhook post
+    assert [(e["event"], e["key"]) for e in m2.book.history] == [("begin", "gpu/0/hbm")]  # history survived
+    m2.stop()
+
+    # and an alert that ended while the monitor was down is closed on the first evaluation
+    def cool(t, i):
+        return GpuState(hbm_frac=0.30)
+    cfg = demo_config(server={"state_dir": str(tmp_path)}, periods={"history_step": 5.0})
+    m3 = Monitor(cfg, gpu=GpuSource(FakeGpuReader(2, scenario=cool, clock=clock)), kube=FakeKube("steady", clock=clock), clock=clock)
+    m3.tick_all()
+    assert m3.alerts_public()["critical"] == [] and [e["event"] for e in m3.book.history] == ["begin", "end"]
+    m3.stop()

@@ -133,7 +133,7 @@ def test_additions(server):
     assert {"host", "gpus", "pods", "vllm", "alerts", "ages"} <= set(s)
     st = get_json(server, "/api/monitor/stats")
     assert st["tasks"]["realtime"]["calls"] >= 2 and st["sources"]["gpu"].startswith("fake(")
-    assert get_json(server, "/api/config")["server"]["cors_origin"] == "*"
+    assert get(server, "/api/config")[0] == 404                              # off unless server.expose_config
     status, hd, body = get(server, "/metrics")
     assert status == 200 and hd["Content-Type"].startswith("text/plain") and b'klm_gpu_hbm_used_bytes{gpu="7"' in body
     from k8s_llm_monitor_amd.collectors.vllm import parse_exposition
@@ -295,3 +295,56 @@ def test_config_endpoint_redacts_the_webhook():
     cfg = demo_config(notify={"webhook_url": "https://hooks.example.com:8443/services/T000/B000/secret-token?x=1"})
     d = redacted_config(cfg)
     assert d["notify"]["webhook_url"] == "https://hooks.example.com:8443/..." and "secret-token" not in json.dumps(d)
+
+
+def test_config_endpoint_is_opt_in_and_redacted():
+    cfg = demo_config(server={"expose_config": True}, notify={"webhook_url": "https://hooks.example.com/T000/B000/secret"})
+    mon = Monitor(cfg)
+    srv = MonitorServer(mon, cfg).start()
+    try:
+        d = get_json(srv, "/api/config")
+        assert d["server"]["cors_origin"] == "*" and d["notify"]["webhook_url"] == "https://hooks.example.com/..."
+        assert "kube_token_file" not in d["sources"]
+    finally:
+        srv.stop()
+        mon.stop()
+
+
+def test_slow_prometheus_does_not_starve_other_routes():
+    """/api/history held a lock across six network calls, so concurrent requests queued inside the
+    executor and stalled the other blocking routes. Now one refresh runs and everybody else gets the previous result."""
+    import threading
+    from k8s_llm_monitor_amd.fakes.prometheus import FakePrometheus
+    prom = FakePrometheus().start()
+    cfg = demo_config(sources={"history": "prometheus"}, prometheus={"url": prom.url, "timeout": 3.0},
+                      periods={"history_step": 1.0, "history_window": "1m"})  # result ttl 0.5 s
+    mon = Monitor(cfg)
+    mon.tick_all()
+    srv = MonitorServer(mon, cfg).start()
+    try:
+        first = get_json(srv, "/api/history")
+        assert first["source"] == "prometheus" and len(first["cpu"]["data"]) > 10
+        prom.delay_s = 0.4                                                 # six queries, an 8-way pool: a refresh now takes >= 0.4 s
+        time.sleep(0.6)                                                    # the cached result is stale when the burst arrives
+        out, lat = [], []
+
+        def hit(path):
+            t0 = time.perf_counter()
+            out.append((path, get(srv, path)[0]))
+            lat.append((path, time.perf_counter() - t0))
+
+        th = [threading.Thread(target=hit, args=("/api/history",)) for _ in range(12)]
+        [t.start() for t in th]
+        time.sleep(0.05)
+        t0 = time.perf_counter()
+        st, _, body = get(srv, "/api/cluster")
+        dt = time.perf_counter() - t0
+        [t.join() for t in th]
+        assert st == 200 and dt < 0.1, dt                                  # not queued behind the history refreshes
+        assert all(code == 200 for _, code in out)
+        fast = [d for _, d in lat if d < 0.2]
+        assert len(fast) >= 10, sorted(d for _, d in lat)                  # at most a refresher or two paid for Prometheus
+    finally:
+        srv.stop()
+        mon.stop()
+        prom.stop()

@@ -1,0 +1,152 @@
+"""The dashboard's script is EXECUTED (Node, a small DOM / canvas / fetch stub: tests/js/run_page.js) against the payloads the
+demo server really serves, and against hostile and degenerate ones (reference behaviour:
+monitor.html:488-592). Skipped without node."""
+import json
+import os
+import shutil
+import subprocess
+import time
+import urllib.request
+
+import pytest
+
+from k8s_llm_monitor_amd.config import demo_config
+from k8s_llm_monitor_amd.parallel import probe
+from k8s_llm_monitor_amd.server.http import MonitorServer
+from k8s_llm_monitor_amd.server.sampler import Monitor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAGE = os.path.join(ROOT, "k8s_llm_monitor_amd", "web", "monitor.html")
+RUNNER = os.path.join(ROOT, "tests", "js", "run_page.js")
+ROUTES = ("/api/host/metrics", "/api/gpu/metrics", "/api/k8s/pods", "/api/history", "/api/alerts", "/api/vllm/metrics",
+          "/api/rccl/probe", "/api/cluster", "/api/validation")
+
+pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+
+DUMP = {"text": ["cpuValue", "cpuLabel", "memValue", "diskValue", "gpuValue", "gpuLabel", "minorCount", "seriousCount", "criticalCount",
+                 "alertModalTitle", "rcclNote", "vTps", "vModel", "srcInfo", "xgmiMatrixNote"],
+        "rows": ["gpuTableBody", "podTableBody", "xgmiMatrixBody", "alertList", "vReplicaBody"],
+        "style": ["xgmiMatrixCard", "gpuStatus", "podStatus", "validationCard"], "cls": ["alertModal"],
+        "eval": {"rccl_data": "charts.rccl.data", "rccl_labels": "charts.rccl.labels", "cpu_points": "charts.cpu.data[0].length",
+                 "gpu_series": "charts.gpu.data.map(d => d.length)"}}
+
+
+def run_page(tmp_path, routes, actions=(), dump=DUMP):
+    f = tmp_path / "scenario.json"
+    f.write_text(json.dumps({"routes": routes, "actions": list(actions), "dump": dump}))
+    r = subprocess.run(["node", RUNNER, PAGE, str(f)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout)
+
+
+@pytest.fixture(scope="module")
+def demo_payloads(tmp_path_factory):
+    """What the demo server (8 fake MI355X, fake pods, fake vLLM) really answers."""
+    state = tmp_path_factory.mktemp("klm")
+    pts = lambda n, alg: [probe.point(n, b, b / (alg * 1e9)) for b in (1024, 1 << 20, 1 << 28)]      # algBW given; busBW = algBW * 2(n-1)/n
+    doc = probe.results_doc([probe.curve(1, pts(1, 3000.0)), probe.curve(2, pts(2, 120.0)), probe.curve(8, pts(8, 600.0)),
+                             probe.curve(4, [], verified=False, executor="none")])
+    probe.save_results(doc, str(state / "probe.json"))
+    cfg = demo_config(periods={"realtime": 0.1, "pods": 0.1, "vllm": 0.1, "history_step": 1.0}, sources={"probe_results": str(state / "probe.json")})
+    mon = Monitor(cfg).start()
+    srv = MonitorServer(mon, cfg).start()
+    time.sleep(0.6)
+    out = {}
+    for p in ROUTES:
+        out[p] = json.loads(urllib.request.urlopen(srv.url + p, timeout=5).read())
+    srv.stop()
+    mon.stop()
+    return out
+
+
+def test_real_demo_payloads_render_every_panel(tmp_path, demo_payloads):
+    o = run_page(tmp_path, demo_payloads)
+    assert o["errors"] == [], o["errors"]
+    assert set(ROUTES) <= set(o["fetched"])
+    assert sorted(o["intervals"]) == sorted([5000, 30000, 10000, 5000, 5000, 60000, 10000, 60000, 1000])     # reference loops 5/30/10 s + additions
+    host, gpus = demo_payloads["/api/host/metrics"], demo_payloads["/api/gpu/metrics"]
+    assert o["text"]["cpuValue"] == host["cpu"]["percent"] + "%" and o["text"]["memValue"] == host["memory"]["percent"] + "%"
+    assert o["text"]["gpuLabel"].startswith("8 卡 · ") and o["text"]["gpuLabel"].endswith(" MB")
+    assert len(o["rows"]["gpuTableBody"]) == 8 and all(len(r) == 17 for r in o["rows"]["gpuTableBody"])
+    assert [r[0] for r in o["rows"]["gpuTableBody"]] == [str(i) for i in range(8)]
+    assert o["rows"]["gpuTableBody"][3][1] == gpus[3]["name"]
+    pods = demo_payloads["/api/k8s/pods"]
+    assert [r[1] for r in o["rows"]["podTableBody"]] == [p["name"] for p in pods]
+    a = demo_payloads["/api/alerts"]
+    assert o["text"]["minorCount"] == str(len(a["minor"])) and o["text"]["criticalCount"] == str(len(a["critical"]))
+    # the xGMI matrix: 8 x 8 with an empty diagonal, every other cell a number
+    m = o["rows"]["xgmiMatrixBody"]
+    assert len(m) == 8 and all(len(r) == 9 for r in m) and all(m[i][i + 1] == "·" for i in range(8))
+    assert all(float(m[i][j + 1]) >= 0 for i in range(8) for j in range(8) if i != j) and o["style"]["xgmiMatrixCard"].get("display") == ""
+    # RCCL chart: the 1/2/4/8 curves land on series 0..3 in that order; 1 GPU plots algBW, the others busBW; 4 GPUs not measured
+    d = o["evals"]["rccl_data"]
+    assert len(d) == 4 and len(d[0]) == 3 and len(d[1]) == 3 and d[2] == [None, None, None] and len(d[3]) == 3
+    assert d[0][2] == pytest.approx(3000.0, rel=1e-6) and d[1][2] == pytest.approx(120.0, rel=1e-6) and d[3][2] == pytest.approx(600.0 * 1.75, rel=1e-6)
+    assert o["evals"]["rccl_labels"] == ["1.0K", "1.0M", "256M"] and "4 GPU: 未测量" in o["text"]["rcclNote"] and "8 GPU: 1050" in o["text"]["rcclNote"]
+    assert o["evals"]["cpu_points"] >= 1 and o["ctxCalls"].get("stroke", 0) > 0
+    assert o["text"]["vModel"] != "未连接" and float(o["text"]["vTps"]) > 0
+
+
+def test_hostile_names_never_reach_innerhtml_unescaped(tmp_path, demo_payloads):
+    evil = '<img src=x onerror="alert(1)">\'"<script>alert(2)</script>'
+    routes = dict(demo_payloads)
+    routes["/api/k8s/pods"] = [{"namespace": evil, "name": evil, "status": "Pending", "restarts": 1, "age": "1m", "reason": evil, "node": evil}]
+    routes["/api/alerts"] = {"minor": [], "serious": [], "critical": [{"title": evil, "desc": evil, "fix": evil, "since": 1700000000}]}
+    g = json.loads(json.dumps(demo_payloads["/api/gpu/metrics"]))
+    g[0]["name"] = evil
+    g[0]["podsHbm"] = [{"owner": evil, "vramBytes": 1 << 30}]
+    routes["/api/gpu/metrics"] = g
+    o = run_page(tmp_path, routes, actions=[["click", "critical"], ["mousemove", "cpuChart", 100]])
+    assert o["errors"] == [], o["errors"]
+    assert o["rows"]["podTableBody"][0][0] == evil and o["rows"]["podTableBody"][0][2] == evil       # as TEXT nodes, verbatim
+    assert o["rows"]["gpuTableBody"][0][1] == evil
+    assert o["cls"]["alertModal"].split().count("active") == 1 and o["text"]["alertModalTitle"] == "🔥 紧急告警"
+    writes = [w["html"] for w in o["htmlWrites"]]
+    assert writes, "the modal and the tooltip write innerHTML"
+    for h in writes:
+        assert "<img" not in h and "<script" not in h and 'onerror="' not in h, h
+    assert any("&lt;img src=x onerror=&quot;alert(1)&quot;&gt;" in h for h in writes)                  # escaped, three times per alert
+    assert "firing" in " ".join(o["badgeClasses"])
+
+
+def test_no_gpu_empty_history_and_failing_routes(tmp_path, demo_payloads):
+    empty = {"labels": [], "data": []}
+    routes = {"/api/host/metrics": {"cpu": {}, "memory": {}, "disk": {}},            # the reference's failure shape (monitor_server.js:80)
+              "/api/gpu/metrics": [], "/api/k8s/pods": [],
+              "/api/history": {k: empty for k in ("cpu", "memory", "disk", "gpuUtil", "gpuMem", "gpuTemp")},
+              "/api/alerts": {"minor": [], "serious": [], "critical": []},
+              "/api/vllm/metrics": {"available": False}, "/api/rccl/probe": {"curves": [], "scaling": [], "note": "no probe result yet"},
+              "/api/cluster": {"__status": 500}}                                      # /api/validation missing altogether: 404
+    o = run_page(tmp_path, routes, actions=[["click", "minor"]])
+    assert [e for e in o["errors"] if "Cluster error" not in e and "Validation error" not in e] == [], o["errors"]
+    assert o["text"]["cpuValue"] == "-%" and o["text"]["gpuValue"] == "-" and o["text"]["gpuLabel"] == "未检测到 GPU"
+    assert o["rows"]["gpuTableBody"] == [["未检测到 AMD GPU (amdsmi)"]] and o["rows"]["podTableBody"] == []
+    assert o["style"]["xgmiMatrixCard"].get("display") == "none" and o["text"]["vModel"] == "未连接"
+    assert o["rows"]["alertList"] == [[]] or o["text"]["alertModalTitle"] == "⚠️ 轻微告警"           # "暂无告警" placeholder
+    assert o["evals"]["rccl_data"] == [[], [], [], []] and o["text"]["rcclNote"] == "no probe result yet"
+
+
+def test_linechart_tolerates_null_and_single_point_series(tmp_path, demo_payloads):
+    routes = dict(demo_payloads)
+    routes["/api/history"] = {"cpu": {"labels": ["10:00"], "data": ["5.0"]},
+                              "memory": {"labels": ["10:00", "10:01", "10:02"], "data": [None, "3.5", None]},
+                              "disk": {"labels": ["a", "b"], "data": ["NaN", "x"]}, "gpuUtil": {"labels": [], "data": []},
+                              "gpuMem": None, "gpuTemp": {"labels": [], "data": []}, "source": "local"}
+    o = run_page(tmp_path, routes, actions=[["mousemove", "memChart", 200], ["eval", "charts.cpu.set(null, [null]); charts.cpu.set(['x'], [[7]], null);"]],
+                 dump=dict(DUMP, eval={"mem": "charts.mem.data[0]", "disk": "charts.disk.data[0].map(v => v === null ? null : (isNaN(v) ? 'nan' : v))",
+                                        "cpu": "charts.cpu.data[0]", "gpu": "charts.gpu.data.map(d => d.length)"}))
+    assert o["errors"] == [], o["errors"]
+    assert o["evals"]["mem"] == [None, 3.5, None] and o["evals"]["disk"] == ["nan", "nan"] and o["evals"]["cpu"] == [7]
+    assert o["evals"]["gpu"] == [0, 0, 0] and o["text"]["srcInfo"] == "历史数据源: local"
+
+
+def test_single_gpu_without_named_peers_shows_the_reason(tmp_path, demo_payloads):
+    """What the one-GPU box returns: live counters, no peer names (profiles/r2_amdsmi_topo_mi355x.json)."""
+    g = json.loads(json.dumps(demo_payloads["/api/gpu/metrics"][:1]))
+    for l in g[0]["xgmi"]["links"]:
+        l["peer"] = l["peerIndex"] = l["peerSource"] = None
+    g[0]["xgmi"]["peersKnown"] = False
+    g[0]["xgmi"]["topologyNote"] = "peers not visible to this process (1 GPU visible of the hive)"
+    o = run_page(tmp_path, dict(demo_payloads, **{"/api/gpu/metrics": g}))
+    assert o["errors"] == [] and o["rows"]["xgmiMatrixBody"] == []
+    assert "not visible" in o["text"]["xgmiMatrixNote"] and o["text"]["gpuValue"].endswith("%") and " 卡" not in o["text"]["gpuLabel"]

@@ -279,6 +279,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p.add_argument("--hbm-gib", type=float, default=0.0, help="also hold this much HBM (fill injector)")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--json", action="store_true")
+    p.add_argument("--monitored", action="store_true", help="run the whole monitor (sampler, server, SSE + polling clients) beside the load")
+    p.add_argument("--monitor-period", type=float, default=1.0)
     p = sub.add_parser("probe")
     p.add_argument("--gpus", default="1,2,4,8")
     p.add_argument("--dtypes", default="bf16")

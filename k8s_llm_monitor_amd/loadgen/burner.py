@@ -317,10 +317,18 @@ def main_from_args(a) -> int:
             last[0] = time.time()
             print(json.dumps({"t": last[0], "kernels": st["kernels"], "busy_s": round(st["busy_s"], 4)}), flush=True)
 
+    product = None
+    if getattr(a, "monitored", False):
+        # the whole monitor beside the load (validation/phases.py::Product): what rocprofv3 compares kernel times under
+        from ..validation.phases import Product
+        product = Product(a.monitor_period, pollers=4)
     try:
         out = b.run(a.seconds, on_period=tick)
     finally:
         if hold is not None:
             hold.release()
+        if product is not None:
+            out_m = product.stop()
+            print(json.dumps({"monitor": out_m}), flush=True)
     print(json.dumps(out), flush=True)
     return 0

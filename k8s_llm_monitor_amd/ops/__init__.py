@@ -203,7 +203,8 @@ def _nbytes(t) -> int:
 def hbm_fill(t, pattern: int = 0xA5A5A5A5):
     """Write `pattern` (32-bit) over the whole tensor with streaming 16-byte stores."""
     _require_cuda(t)
-    _check(load().klm_hbm_fill(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, _stream(t)), "klm_hbm_fill")
+    with _on_device(t):
+        _check(load().klm_hbm_fill(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, _stream(t)), "klm_hbm_fill")
     return t
 
 
@@ -211,7 +212,8 @@ def hbm_copy(dst, src):
     _require_cuda(dst, src)
     if _nbytes(dst) != _nbytes(src):
         raise KlmOpsError("hbm_copy: size mismatch")
-    _check(load().klm_hbm_copy(dst.data_ptr(), src.data_ptr(), _nbytes(src), _stream(src)), "klm_hbm_copy")
+    with _on_device(src):
+        _check(load().klm_hbm_copy(dst.data_ptr(), src.data_ptr(), _nbytes(src), _stream(src)), "klm_hbm_copy")
     return dst
 
 
@@ -220,19 +222,22 @@ def hbm_copy_ex(dst, src, flags: int = 3, grid: int = 0):
     _require_cuda(dst, src)
     if _nbytes(dst) != _nbytes(src):
         raise KlmOpsError("hbm_copy_ex: size mismatch")
-    _check(load().klm_hbm_copy_ex(dst.data_ptr(), src.data_ptr(), _nbytes(src), flags, grid, _stream(src)), "klm_hbm_copy_ex")
+    with _on_device(src):
+        _check(load().klm_hbm_copy_ex(dst.data_ptr(), src.data_ptr(), _nbytes(src), flags, grid, _stream(src)), "klm_hbm_copy_ex")
     return dst
 
 
 def hbm_fill_ex(t, pattern: int = 0xA5A5A5A5, flags: int = 2, grid: int = 0):
     _require_cuda(t)
-    _check(load().klm_hbm_fill_ex(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, flags, grid, _stream(t)), "klm_hbm_fill_ex")
+    with _on_device(t):
+        _check(load().klm_hbm_fill_ex(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, flags, grid, _stream(t)), "klm_hbm_fill_ex")
     return t
 
 
 def hbm_read(src, sink):
     _require_cuda(src, sink)
-    _check(load().klm_hbm_read(src.data_ptr(), _nbytes(src), sink.data_ptr(), _stream(src)), "klm_hbm_read")
+    with _on_device(src):
+        _check(load().klm_hbm_read(src.data_ptr(), _nbytes(src), sink.data_ptr(), _stream(src)), "klm_hbm_read")
 
 
 def hbm_checksum(src) -> int:
@@ -240,12 +245,14 @@ def hbm_checksum(src) -> int:
     import torch
     _require_cuda(src)
     acc = torch.zeros(1, dtype=torch.int64, device=src.device)
-    _check(load().klm_hbm_checksum(src.data_ptr(), _nbytes(src), acc.data_ptr(), _stream(src)),
-           "klm_hbm_checksum")
+    with _on_device(src):
+        _check(load().klm_hbm_checksum(src.data_ptr(), _nbytes(src), acc.data_ptr(), _stream(src)),
+               "klm_hbm_checksum")
     return int(acc.item()) & 0xFFFFFFFFFFFFFFFF
 
 
 def spin(cycles: int, blocks: int = 256, device=None):
     import torch
     s = torch.cuda.current_stream(device).cuda_stream
-    _check(load().klm_spin(int(cycles), int(blocks), s), "klm_spin")
+    with torch.cuda.device(device):            # None keeps the current device
+        _check(load().klm_spin(int(cycles), int(blocks), s), "klm_spin")

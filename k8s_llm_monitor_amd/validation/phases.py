@@ -8,8 +8,12 @@ Each phase puts a KNOWN load on the GPU and compares what the monitor reports wi
   activity_fidelity  the MFMA burner at 25 / 50 / 75 / 100 % duty (measured with HIP events);
                      the monitor's GFX activity over the same window vs the achieved duty.
   mem_activity       the HBM copy burner at full duty: achieved TB/s next to amdsmi's UMC activity.
-  overhead           burner throughput with the sampler off, on at the dashboard period, and on
-                     at a 20 Hz stress rate; overhead = throughput lost.
+  power_temperature  the burner at 100 % duty: the power gauge vs the energy accumulator over the same
+                     window (two independent sources that must agree), and the junction temperature's
+                     shape (rises under load without falling back, drops when the load stops).
+  overhead           burner throughput alone, next to the whole product (Monitor + HTTP server + one
+                     SSE stream + polling clients), and next to a 20 Hz bare poller; interleaved repeats,
+                     overhead = mean paired difference with its 95 % confidence interval.
   alert_latency      the full stack (amdsmi -> sampler thread -> alert engine -> HTTP): HBM is
                      pushed across 70 / 85 / 95 % of the card and /api/alerts is polled like
                      the page does; latency = crossing -> alert visible.
@@ -158,34 +162,227 @@ def mem_activity(torch, dev, src, smi_idx: int, seconds: float = 4.0) -> Dict[st
     return {"rows": rows}
 
 
-def overhead(torch, dev, seconds: float = 5.0, size: int = 8192, period_s: float = 5.0, stress_hz: float = 20.0,
-             repeats: int = 2) -> Dict[str, Any]:
-    """Burner throughput with the telemetry sampler off / on. Runs are interleaved
-    (off, on, stress, off, on, stress ...) so clock drift does not masquerade as overhead."""
+# two-sided 95 % Student-t quantiles by degrees of freedom (n - 1); beyond the table the normal value
+_T95 = {1: 12.706, 2: 4.303, 3: 3.182, 4: 2.776, 5: 2.571, 6: 2.447, 7: 2.365, 8: 2.306, 9: 2.262, 10: 2.228}
+
+
+def mean_ci95(xs: List[float]) -> Dict[str, Any]:
+    """Mean and the half-width of its 95 % confidence interval (Student t, sample standard deviation)."""
+    xs = [float(x) for x in xs if x is not None]
+    n = len(xs)
+    if n == 0:
+        return {"n": 0, "mean": None, "ci95": None}
+    m = sum(xs) / n
+    if n < 2:
+        return {"n": n, "mean": m, "ci95": None}
+    sd = (sum((x - m) ** 2 for x in xs) / (n - 1)) ** 0.5
+    return {"n": n, "mean": m, "ci95": _T95.get(n - 1, 1.96) * sd / n ** 0.5, "sd": sd}
+
+
+class DashboardClients:
+    """What one open dashboard tab plus a few scripted pollers put on the server: one ``/api/events`` stream
+    held open and `pollers` threads that walk the page's routes (monitor.html's fetch loop) every `poll_s`."""
+
+    ROUTES = ("/api/gpu/metrics", "/api/host/metrics", "/api/alerts", "/api/k8s/pods", "/api/history", "/api/xgmi", "/metrics")
+
+    def __init__(self, url: str, pollers: int = 4, poll_s: float = 1.0):
+        import threading
+        self.url, self.poll_s = url, poll_s
+        self._stop = threading.Event()
+        self.requests = 0
+        self.errors = 0
+        self.sse_events = 0
+        self._threads = [threading.Thread(target=self._sse, name="klm-ovh-sse", daemon=True)]
+        self._threads += [threading.Thread(target=self._poll, args=(i,), name=f"klm-ovh-poll{i}", daemon=True) for i in range(pollers)]
+
+    def _sse(self) -> None:
+        try:
+            with urllib.request.urlopen(self.url + "/api/events", timeout=10) as r:
+                while not self._stop.is_set():
+                    line = r.readline()
+                    if not line:
+                        break
+                    if line.startswith(b"event:"):
+                        self.sse_events += 1
+        except Exception:
+            if not self._stop.is_set():
+                self.errors += 1
+
+    def _poll(self, i: int) -> None:
+        k = i
+        while not self._stop.wait(self.poll_s):
+            try:
+                urllib.request.urlopen(self.url + self.ROUTES[k % len(self.ROUTES)], timeout=3).read()
+                self.requests += 1
+            except Exception:
+                self.errors += 1
+            k += 1
+
+    def start(self) -> "DashboardClients":
+        for t in self._threads:
+            t.start()
+        return self
+
+    def stop(self) -> Dict[str, int]:
+        self._stop.set()
+        for t in self._threads[1:]:
+            t.join(timeout=3)
+        return {"requests": self.requests, "errors": self.errors, "sse_events": self.sse_events}
+
+
+class Product:
+    """The whole monitor next to a load: `Monitor` (amdsmi sampler thread, alert engine, history store) at
+    `period_s`, `MonitorServer`, one /api/events stream and `pollers` polling clients. stop() returns the
+    realtime task's statistics and the clients' request counts."""
+
+    def __init__(self, period_s: float = 1.0, pollers: int = 4, gpu_source: str = "amdsmi"):
+        from ..config import load_config
+        from ..server.http import MonitorServer
+        from ..server.sampler import Monitor
+        cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"},
+                                             "sources": {"gpu": gpu_source, "kube": "none", "vllm": "none", "history": "local"},
+                                             "periods": {"realtime": period_s}})
+        self.period_s, self.pollers = period_s, pollers
+        self.mon = Monitor(cfg).start()
+        self.srv = MonitorServer(self.mon, cfg).start()
+        self.clients = DashboardClients(self.srv.url, pollers=pollers, poll_s=min(1.0, period_s)).start()
+
+    def stop(self) -> Dict[str, Any]:
+        cl = self.clients.stop()
+        rt = (self.mon.stats().get("tasks") or {}).get("realtime") or {}
+        self.srv.stop()
+        self.mon.stop()
+        return dict(rt, clients=cl, pollers=self.pollers, sse_clients=1)
+
+
+def overhead(torch, dev, seconds: float = 5.0, size: int = 8192, period_s: float = 1.0, stress_hz: float = 20.0,
+             repeats: int = 5, pollers: int = 4) -> Dict[str, Any]:
+    """What monitoring costs the monitored load. Three legs, interleaved (off, product, stress, off, ...) so clock
+    and temperature drift cannot pass for overhead:
+
+      off      the bf16 burner alone;
+      product  the WHOLE monitor next to it: `Monitor` (amdsmi sampler thread, alert engine, history store) at a
+               `period_s` realtime period -- 1 s here, five times the dashboard's rate, so that a window holds
+               >= 4 samples -- plus `MonitorServer` with one /api/events stream and `pollers` polling clients;
+      stress   a bare amdsmi poller at `stress_hz`.
+
+    The cost is the PAIRED difference (off_i - leg_i) / off_i per repeat, reported as mean and 95 % confidence
+    half-width, for the wall-clock rate (`tflops_avg`: launch gaps included) and for the GPU-side rate
+    (`tflops_busy`: HIP-event time of the kernels only). An interval that contains 0 is "below the noise floor";
+    the pass criterion is its upper end < 1 %. scripts/overhead_rocprof.py repeats the product leg under
+    rocprofv3 --kernel-trace for the per-kernel durations."""
     from ..collectors.gpu import open_gpu_source
     from ..loadgen.burner import Burner
     from ..server.sampler import BackgroundPoller
     b = Burner("gemm_bf16", size=size, duty=100.0, device=dev.index or 0)
     b.run(2.0)                                             # warm the clocks
-    res: Dict[str, List[float]] = {"off": [], "on": [], "stress": []}
-    sampler_stats = {}
+    modes = ("off", "product", "stress")
+    avg: Dict[str, List[float]] = {m: [] for m in modes}
+    busy: Dict[str, List[float]] = {m: [] for m in modes}
+    stats: Dict[str, Any] = {}
     for _ in range(repeats):
-        for mode in ("off", "on", "stress"):
-            poller = None
-            if mode != "off":
-                poller = BackgroundPoller(open_gpu_source("amdsmi"), period=period_s if mode == "on" else 1.0 / stress_hz).start()
+        for mode in modes:
+            poller = product = None
+            if mode == "stress":
+                poller = BackgroundPoller(open_gpu_source("amdsmi"), period=1.0 / stress_hz).start()
+            elif mode == "product":
+                product = Product(period_s, pollers)
             out = b.run(seconds)
-            res[mode].append(out["tflops_avg"])
+            avg[mode].append(out["tflops_avg"])
+            busy[mode].append(out["tflops_busy"])
             if poller is not None:
-                sampler_stats[mode] = poller.stats()
+                stats["stress"] = poller.stats()
                 poller.stop()
                 poller.src.close()
-    off, on, stress = _mean(res["off"]), _mean(res["on"]), _mean(res["stress"])
-    return {"tflops_sampler_off": off, "tflops_sampler_on": on, "tflops_sampler_stress": stress, "runs": res,
-            "period_s": period_s, "stress_hz": stress_hz,
-            "overhead_pct": (off - on) / off * 100.0, "overhead_stress_pct": (off - stress) / off * 100.0,
-            "noise_pct": (max(res["off"]) - min(res["off"])) / off * 100.0,
-            "sampler_stats": sampler_stats}
+            if product is not None:
+                stats["on"] = product.stop()
+
+    def paired(kind: Dict[str, List[float]], leg: str) -> Dict[str, Any]:
+        d = mean_ci95([(o - x) / o * 100.0 for o, x in zip(kind["off"], kind[leg])])
+        lo, hi = (d["mean"] - (d["ci95"] or 0.0), d["mean"] + (d["ci95"] or 0.0)) if d["mean"] is not None else (None, None)
+        return {"mean_pct": d["mean"], "ci95_pct": d["ci95"], "low_pct": lo, "high_pct": hi, "n": d["n"],
+                "below_noise_floor": bool(lo is not None and lo <= 0.0 <= hi)}
+
+    wall_p, wall_s, gpu_p = paired(avg, "product"), paired(avg, "stress"), paired(busy, "product")
+    off = _mean(avg["off"])
+    return {"legs": {"off": "burner alone", "product": f"Monitor at {period_s} s + HTTP server + 1 SSE + {pollers} polling clients",
+                     "stress": f"bare amdsmi poller at {stress_hz} Hz"},
+            "window_s": seconds, "repeats": repeats, "period_s": period_s, "stress_hz": stress_hz,
+            "tflops_sampler_off": off, "tflops_sampler_on": _mean(avg["product"]), "tflops_sampler_stress": _mean(avg["stress"]),
+            "runs": avg, "runs_gpu_side": busy,
+            "overhead_pct": wall_p["mean_pct"], "overhead_ci95_pct": wall_p["ci95_pct"], "overhead": wall_p,
+            "overhead_stress_pct": wall_s["mean_pct"], "overhead_stress": wall_s,
+            "overhead_gpu_side_pct": gpu_p["mean_pct"], "overhead_gpu_side": gpu_p,
+            "noise_pct": (max(avg["off"]) - min(avg["off"])) / off * 100.0,
+            "sampler_stats": stats}
+
+
+def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s: float = 8.0, cool_s: float = 4.0,
+                      hz: float = 4.0, size: int = 8192) -> Dict[str, Any]:
+    """Power and junction temperature against what a known load must do to them (BASELINE.json config 2).
+
+    Power has two independent sources on this card: the firmware's socket-power gauge and the energy accumulator
+    (the monitor's `powerAvgW` = delta energy / delta time). Under a steady 100 % duty load they must agree:
+    `power_error_pct` = |mean gauge - accumulator mean| / accumulator mean over the same window (under duty
+    cycling they differ by design: the gauge is a moving average sampled at one instant, which is why the card
+    shows the accumulator figure then). Temperature has no second source, so it is checked for shape: it must
+    rise under the burner without falling back by more than the sensor's 1-2 degree jitter, exceed idle by a
+    clear margin, and fall again when the load stops."""
+    from ..loadgen.burner import Burner
+    b = Burner("gemm_bf16", size=size, duty=100.0, device=dev.index or 0)
+    step = 1.0 / hz
+    trace: List[Dict[str, Any]] = []
+
+    def watch(seconds: float, phase: str) -> None:
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            s = _gpu_sample(src, smi_idx) or {}
+            trace.append({"t": time.perf_counter(), "phase": phase, "power_w": s.get("powerW"), "power_avg_w": s.get("powerAvgW"),
+                          "temperature": s.get("temperature"), "hbm_temperature": s.get("temperatureHbm")})
+            time.sleep(step)
+
+    torch.cuda.synchronize(dev)
+    time.sleep(0.5)
+    watch(idle_s, "idle")
+    b.start(burn_s + 60.0)
+    time.sleep(1.5)                                        # clocks and the firmware's power average settle
+    watch(burn_s, "burn")
+    out = b.stop()
+    watch(cool_s, "cool")
+    del b
+    torch.cuda.empty_cache()
+
+    burn = [r for r in trace if r["phase"] == "burn"]
+    idle = [r for r in trace if r["phase"] == "idle"]
+    cool = [r for r in trace if r["phase"] == "cool"]
+    gauge = _mean([r["power_w"] for r in burn])
+    # accumulator mean over the burn window: each sample's powerAvgW is delta energy / delta time since the
+    # previous sample of this source, and the samples are evenly spaced
+    acc = _mean([r["power_avg_w"] for r in burn[1:]])
+    temps = [r["temperature"] for r in burn if r["temperature"] is not None]
+    t_idle = _mean([r["temperature"] for r in idle])
+    worst_drop, run_max = 0.0, None
+    for t in temps:
+        run_max = t if run_max is None else max(run_max, t)
+        worst_drop = max(worst_drop, run_max - t)
+    t_cool_min = min([r["temperature"] for r in cool if r["temperature"] is not None], default=None)
+    res: Dict[str, Any] = {
+        "burn_s": burn_s, "samples": len(trace), "sample_hz": hz, "tflops_busy": out.get("tflops_busy"), "duty_achieved": out.get("duty_achieved"),
+        "power_gauge_mean_w": gauge, "power_accumulator_mean_w": acc,
+        "power_idle_w": _mean([r["power_w"] for r in idle]),
+        "power_error_pct": abs(gauge - acc) / acc * 100.0 if gauge and acc else None,
+        "temperature_idle_c": t_idle, "temperature_burn_first_c": temps[0] if temps else None,
+        "temperature_burn_last_c": temps[-1] if temps else None, "temperature_burn_max_c": max(temps) if temps else None,
+        "temperature_worst_drop_under_load_c": worst_drop if temps else None, "temperature_cool_min_c": t_cool_min,
+        "hbm_temperature_burn_max_c": max([r["hbm_temperature"] for r in burn if r["hbm_temperature"] is not None], default=None),
+        "trace": [{"t": round(r["t"] - trace[0]["t"], 2), "phase": r["phase"], "power_w": r["power_w"], "temperature": r["temperature"]}
+                  for r in trace[::max(1, int(hz / 2))]]}
+    if temps and t_idle is not None:
+        rise = max(temps) - t_idle
+        res["temperature_rise_c"] = rise
+        res["temperature_monotonic"] = bool(worst_drop <= 2.0 and temps[-1] >= temps[0])
+        res["temperature_follows_load"] = bool(rise >= 3.0 and t_cool_min is not None and t_cool_min <= max(temps) - 2.0)
+    return res
 
 
 def alert_latency(torch, dev, realtime_period: float = 5.0, poll_s: float = 0.25, tiers=(("minor", 71.0), ("serious", 86.0), ("critical", 96.0)),
@@ -435,7 +632,8 @@ def llm_activity(torch, dev, src, smi_idx: int, seconds: float = 2.5, model: str
                  {"tokens_per_s": r["tokens_per_s"], "TBps": r["TBps"]})
         p = sb.prefill_ms(eng, 4, 1024, iters=1)
         hold("prefill 4 x 1024", lambda: sb.prefill_ms(eng, 4, 1024, iters=1, warmup=0),
-             {"tokens_per_s": p["tokens_per_s"], "TFLOPs": p["TFLOPs"]})
+             {"tokens_per_s": p["tokens_per_s"], "TFLOPs": p["TFLOPs"],
+              "gemm_backend": "hipBLASLt (torch.matmul), not this repo's GEMM kernels"})
     finally:
         del eng
         import gc
@@ -453,7 +651,7 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
         return {}
     from ..collectors.gpu import open_gpu_source
     out: Dict[str, Any] = {}
-    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "mem", "overhead", "latency", "llm", "vllm"}
+    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "power", "mem", "overhead", "latency", "llm", "vllm"}
     src = open_gpu_source("amdsmi")
     try:
         idx = _smi_index_for(torch, dev, src)
@@ -473,10 +671,12 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
             guard("hbm_fidelity", lambda: hbm_fidelity(torch, dev, src, idx, steps_gib=(16, 64) if quick else (16, 64, 128, 200)))
         if "activity" in want:
             guard("activity_fidelity", lambda: activity_fidelity(torch, dev, src, idx, seconds=4.0 if quick else 10.0))
+        if "power" in want:
+            guard("power_temperature", lambda: power_temperature(torch, dev, src, idx, burn_s=8.0 if quick else 20.0))
         if "mem" in want:
             guard("mem_activity", lambda: mem_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
         if "overhead" in want:
-            guard("overhead", lambda: overhead(torch, dev, seconds=3.0 if quick else 8.0, repeats=2 if quick else 3))
+            guard("overhead", lambda: overhead(torch, dev, seconds=5.0 if quick else 8.0, repeats=5 if quick else 7))
         if "latency" in want:
             guard("alert_latency", lambda: alert_latency(torch, dev))
         if "llm" in want:
@@ -492,20 +692,36 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
 
 def summarize(out: Dict[str, Any]) -> Dict[str, Any]:
     g = lambda d, k: (out.get(d) or {}).get(k)
+    ovh = g("overhead", "overhead") or {}
     s = {"hbm_error_pct": g("hbm_fidelity", "max_error_vs_driver_pct"),
          "hbm_error_vs_allocated_pct": g("hbm_fidelity", "max_error_vs_allocated_pct"),
          "gfx_activity_error_points": g("activity_fidelity", "max_error_points"),
+         "power_error_pct": g("power_temperature", "power_error_pct"),
+         "temperature_rise_c": g("power_temperature", "temperature_rise_c"),
+         "temperature_monotonic": g("power_temperature", "temperature_monotonic"),
+         "temperature_follows_load": g("power_temperature", "temperature_follows_load"),
+         # the whole product (Monitor + HTTP server + SSE and polling clients) next to the burner: mean of the
+         # paired differences and the 95 % half-width; `high` is what the pass criterion looks at
          "sampling_overhead_pct": g("overhead", "overhead_pct"),
+         "sampling_overhead_ci95_pct": g("overhead", "overhead_ci95_pct"),
+         "sampling_overhead_high_pct": ovh.get("high_pct"),
+         "sampling_overhead_below_noise_floor": ovh.get("below_noise_floor"),
+         "sampling_overhead_gpu_side_pct": g("overhead", "overhead_gpu_side_pct"),
          "sampling_overhead_20hz_pct": g("overhead", "overhead_stress_pct"),
+         "sampler_calls_per_window": ((g("overhead", "sampler_stats") or {}).get("on") or {}).get("calls"),
          "alert_latency_max_s": g("alert_latency", "max_latency_s"),
          "vllm_tokens_per_s_error_pct": g("vllm_fidelity", "max_tokens_per_s_error_pct"),
          "vllm_kv_cache_error_points": g("vllm_fidelity", "max_kv_error_points"),
          "vllm_ttft_p50_in_true_bucket": g("vllm_fidelity", "ttft_p50_in_true_bucket")}
-    s["targets"] = {"error_pct": 2.0, "overhead_pct": 1.0, "alert_latency_s": 10.0}
+    s["targets"] = {"error_pct": 2.0, "overhead_pct": 1.0, "alert_latency_s": 10.0, "temperature_rise_c": 3.0}
+    high = s["sampling_overhead_high_pct"] if s["sampling_overhead_high_pct"] is not None else s["sampling_overhead_pct"]
     s["pass"] = {"hbm": s["hbm_error_pct"] is not None and s["hbm_error_pct"] <= 2.0,
                  "activity": s["gfx_activity_error_points"] is not None and s["gfx_activity_error_points"] <= 2.0,
-                 "overhead": s["sampling_overhead_pct"] is not None and s["sampling_overhead_pct"] < 1.0,
+                 "overhead": high is not None and high < 1.0,
                  "latency": s["alert_latency_max_s"] is not None and s["alert_latency_max_s"] < 10.0}
+    if "power_temperature" in out:
+        s["pass"]["power"] = s["power_error_pct"] is not None and s["power_error_pct"] <= 2.0
+        s["pass"]["temperature"] = bool(s["temperature_monotonic"]) and bool(s["temperature_follows_load"])
     if "vllm_fidelity" in out:
         s["pass"]["vllm"] = (s["vllm_tokens_per_s_error_pct"] is not None and s["vllm_tokens_per_s_error_pct"] <= 2.0
                              and s["vllm_kv_cache_error_points"] is not None and s["vllm_kv_cache_error_points"] <= 2.0)

@@ -221,3 +221,33 @@ def cross_check_duty(outdir: str, duties: Sequence[float] = (25.0, 50.0, 75.0), 
         rows.append({"duty_target": d, "duty_rocprof": bf["busy_fraction"] * 100.0, "kernels": bf["kernels"],
                      "duty_burner_events": self_report.get("duty_achieved")})
     return rows
+
+
+def kernel_durations(rows: Iterable[Dict[str, Any]], name_contains: str, skip: int = 16) -> List[float]:
+    """Durations (us) of the matching dispatches in start order, without the first `skip` (calibration, cold clocks)."""
+    ks = sorted((r for r in rows if name_contains in r["name"]), key=lambda r: r["start"])
+    return [(r["end"] - r["start"]) / 1e3 for r in ks[skip:]]
+
+
+def overhead_kernel_trace(outdir: str, repeats: int = 3, seconds: float = 5.0, size: int = 8192,
+                          monitor_period: float = 1.0) -> Dict[str, Any]:
+    """GPU-side ground truth for the sampling overhead: the burner's per-kernel duration in rocprofv3's kernel
+    trace with the whole monitor running beside it vs alone, interleaved, as a paired difference per repeat."""
+    from .phases import mean_ci95
+    legs: Dict[str, List[Dict[str, Any]]] = {"off": [], "on": []}
+    for i in range(repeats):
+        for leg in ("off", "on"):
+            cmd = burner_cmd(duty=100.0, seconds=seconds, size=size) + (["--monitored", "--monitor-period", str(monitor_period)] if leg == "on" else [])
+            res = kernel_trace(cmd, os.path.join(outdir, f"{leg}{i}"))
+            d = kernel_durations(res["rows"], "gemm_bf16")
+            d.sort()
+            n = len(d)
+            legs[leg].append({"kernels": n, "mean_us": sum(d) / n if n else None, "median_us": d[n // 2] if n else None,
+                              "p99_us": d[min(n - 1, int(n * 0.99))] if n else None, "max_us": d[-1] if n else None,
+                              "monitor": "monitor" in res["stdout"]})
+    diffs = [(on["mean_us"] - off["mean_us"]) / off["mean_us"] * 100.0 for off, on in zip(legs["off"], legs["on"])
+             if off["mean_us"] and on["mean_us"]]
+    meds = [(on["median_us"] - off["median_us"]) / off["median_us"] * 100.0 for off, on in zip(legs["off"], legs["on"])
+            if off["median_us"] and on["median_us"]]
+    return {"kernel": "gemm_bf16 (8192^3 burner)", "window_s": seconds, "monitor_period_s": monitor_period, "legs": legs,
+            "kernel_time_increase_pct": mean_ci95(diffs), "kernel_median_increase_pct": mean_ci95(meds)}

@@ -58,6 +58,7 @@ class GpuNormalizer:
     def __init__(self):
         self._rates = RateTracker(bits=64)
         self._prev: Dict[int, Dict[str, Any]] = {}
+        self._held: Dict[Any, Any] = {}        # last period figures, shown again while the metrics table has not moved
 
     def reset(self) -> None:
         self.__init__()
@@ -67,6 +68,21 @@ class GpuNormalizer:
         t = float(raw.get("t", time.monotonic()))
         prev = self._prev.get(idx)
         self._prev[idx] = raw
+        # The driver refreshes the metrics table about once a second (measured on MI355X: 6 changes in 6 s at 20 Hz
+        # polling, profiles/r2_prof/energy_timebase.json), so its accumulators belong to the table's OWN clock
+        # (firmware_timestamp, 10 ns ticks: 100.6 M per host second), not to the host time of the read: against
+        # the host clock a rate is off by up to one refresh per period, and a table read twice gives a zero.
+        fw = _int(raw.get("firmware_timestamp"))
+        tt = fw * 1e-8 if fw else t
+        table_same = bool(prev is not None and fw and _int(prev.get("firmware_timestamp")) == fw)
+
+        def held(key, value):
+            """A period figure: remembered when it could be formed, repeated while the table is unchanged."""
+            k = (key, idx)
+            if value is not None:
+                self._held[k] = value
+                return value
+            return self._held.get(k) if table_same else None
 
         total_mib = _int(raw.get("vram_total_mib")) or 0
         used_mib = _int(raw.get("vram_used_mib")) or 0
@@ -95,7 +111,8 @@ class GpuNormalizer:
             gfx_avg = share(counter_delta(_int(prev.get("gfx_activity_acc")), _int(raw.get("gfx_activity_acc")), ACT_ACC_BITS), dacc, 1.0)
             umc_avg = share(counter_delta(_int(prev.get("mem_activity_acc")), _int(raw.get("mem_activity_acc")), ACT_ACC_BITS), dacc, 1.0)
             for k in RESIDENCY_KEYS:
-                residency[k] = share(counter_delta(_int(prev.get(f"res_{k}_acc")), _int(raw.get(f"res_{k}_acc"))), dacc, 100.0)
+                residency[k] = held(("res", k), share(counter_delta(_int(prev.get(f"res_{k}_acc")), _int(raw.get(f"res_{k}_acc"))), dacc, 100.0))
+            gfx_avg, umc_avg = held("gfx_avg", gfx_avg), held("umc_avg", umc_avg)
         # per-XCD busy share over the period (same tick base as the whole-GPU accumulator)
         xcd_inst = raw.get("xcd_busy_inst") if isinstance(raw.get("xcd_busy_inst"), list) else None
         xcd_avg: Optional[List[Optional[float]]] = None
@@ -105,6 +122,7 @@ class GpuNormalizer:
             for a0, a1 in zip(xa, xb):
                 v = share(counter_delta(_int(a0), _int(a1)), dacc, 1.0)
                 xcd_avg.append(None if v is None else min(100.0, max(0.0, v)))
+        xcd_avg = held("xcd_avg", xcd_avg)
         # PCIe link health: cumulative error counters and what they gained since the last reading
         pcie_err = {}
         for key, name in (("pcie_replay_acc", "replay"), ("pcie_l0_recovery_acc", "l0Recovery"),
@@ -124,9 +142,10 @@ class GpuNormalizer:
         power_w = _num(raw.get("power_w"))
         power_avg = None
         res_uj = _num(raw.get("energy_resolution_uj"))
-        e_rate = self._rates.update(("energy", idx), t, _int(raw.get("energy_acc")))
+        e_rate = self._rates.update(("energy", idx), tt, _int(raw.get("energy_acc")))
         if e_rate is not None and res_uj:
             power_avg = e_rate * res_uj * 1e-6
+        power_avg = held("power_avg", power_avg)
         cap_w = _num(raw.get("power_cap_w"))
 
         # throttle
@@ -147,8 +166,8 @@ class GpuNormalizer:
             w_kib = _int(wr[i]) if i < len(wr) else None
             s = st[i] if i < len(st) else None
             state = {1: "up", 0: "down", "U": "up", "D": "down", "X": "disabled"}.get(s, "n/a")
-            rx = self._rates.update(("xr", idx, i), t, r_kib)
-            tx = self._rates.update(("xw", idx, i), t, w_kib)
+            rx = held(("xr", i), self._rates.update(("xr", idx, i), tt, r_kib))
+            tx = held(("xw", i), self._rates.update(("xw", idx, i), tt, w_kib))
             rx_gbps = None if rx is None else rx * 1024 / 1e9
             tx_gbps = None if tx is None else tx * 1024 / 1e9
             if rx_gbps is not None:
@@ -188,6 +207,9 @@ class GpuNormalizer:
             "memActivityAvg": umc_avg,
             "powerW": power_w,
             "powerAvgW": power_avg,
+            # the accumulator itself, in joules: lets a reader form its own mean over any window (delta E / delta t)
+            "metricsTableTimeS": tt if fw else None,     # the table's firmware clock at its last refresh (pairs with energyJ)
+            "energyJ": (_int(raw.get("energy_acc")) * res_uj * 1e-6) if (_int(raw.get("energy_acc")) is not None and res_uj) else None,
             "powerCapW": cap_w,
             "powerPercent": (power_w / cap_w * 100.0) if (power_w is not None and cap_w) else None,
             "temperatureHbm": _num(raw.get("temp_mem")),

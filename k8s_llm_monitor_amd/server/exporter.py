@@ -63,6 +63,8 @@ def render(snapshot: Mapping[str, Any], stats: Mapping[str, Any]) -> str:
               g.get("memActivityAvg") if g.get("memActivityAvg") is not None else g.get("memActivity"), L)
         d.add("klm_gpu_power_watts", "Socket power.", "gauge", g.get("powerW"), L)
         d.add("klm_gpu_power_cap_watts", "Socket power cap.", "gauge", g.get("powerCapW"), L)
+        d.add("klm_gpu_power_average_watts", "Socket power from the energy accumulator over the last sampling period.", "gauge", g.get("powerAvgW"), L)
+        d.add("klm_gpu_energy_joules_total", "Socket energy accumulator.", "counter", g.get("energyJ"), L)
         d.add("klm_gpu_junction_temperature_celsius", "Junction (hotspot) temperature.", "gauge", g.get("temperature"), L)
         d.add("klm_gpu_hbm_temperature_celsius", "HBM temperature.", "gauge", g.get("temperatureHbm"), L)
         d.add("klm_gpu_gfx_clock_mhz", "Current GFX clock.", "gauge", g.get("clockGfxMHz"), L)

@@ -317,15 +317,19 @@ def overhead(torch, dev, seconds: float = 5.0, size: int = 8192, period_s: float
             "sampler_stats": stats}
 
 
-def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s: float = 8.0, cool_s: float = 4.0,
-                      hz: float = 4.0, size: int = 8192) -> Dict[str, Any]:
+def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s: float = 13.0, cool_s: float = 4.0,
+                      hz: float = 4.0, size: int = 8192, steady_after_s: float = 6.0) -> Dict[str, Any]:
     """Power and junction temperature against what a known load must do to them (BASELINE.json config 2).
 
     Power has two independent sources on this card: the firmware's socket-power gauge and the energy accumulator
     (the monitor's `powerAvgW` = delta energy / delta time). Under a steady 100 % duty load they must agree:
-    `power_error_pct` = |mean gauge - accumulator mean| / accumulator mean over the same window (under duty
-    cycling they differ by design: the gauge is a moving average sampled at one instant, which is why the card
-    shows the accumulator figure then). Temperature has no second source, so it is checked for shape: it must
+    `power_error_pct` = |mean gauge - accumulator mean| / accumulator mean over the same window, taken once the
+    load has run for `steady_after_s`; the first seconds after the load step are reported as `power_error_onset_pct`, not judged.
+    Both live in a metrics table the driver refreshes about once a second, so the accumulator is differenced
+    against the table's own firmware clock (against the host clock a window of a few seconds is off by up to one
+    refresh, which read as a 3 - 6 % "disagreement" before this was understood). Under duty
+    cycling the two differ by design: the gauge is a filtered value read at one instant, which is why the card
+    shows the accumulator figure then. Temperature has no second source, so it is checked for shape: it must
     rise under the burner without falling back by more than the sensor's 1-2 degree jitter, exceed idle by a
     clear margin, and fall again when the load stops."""
     from ..loadgen.burner import Burner
@@ -338,14 +342,16 @@ def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s
         while time.perf_counter() < t_end:
             s = _gpu_sample(src, smi_idx) or {}
             trace.append({"t": time.perf_counter(), "phase": phase, "power_w": s.get("powerW"), "power_avg_w": s.get("powerAvgW"),
-                          "temperature": s.get("temperature"), "hbm_temperature": s.get("temperatureHbm")})
+                          "temperature": s.get("temperature"), "hbm_temperature": s.get("temperatureHbm"), "energy_j": s.get("energyJ"), "table_t": s.get("metricsTableTimeS"),
+                          "clock_gfx_mhz": s.get("clockGfxMHz")})
             time.sleep(step)
 
     torch.cuda.synchronize(dev)
     time.sleep(0.5)
     watch(idle_s, "idle")
     b.start(burn_s + 60.0)
-    time.sleep(1.5)                                        # clocks and the firmware's power average settle
+    time.sleep(0.5)
+    t_burn0 = time.perf_counter()
     watch(burn_s, "burn")
     out = b.stop()
     watch(cool_s, "cool")
@@ -355,10 +361,23 @@ def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s
     burn = [r for r in trace if r["phase"] == "burn"]
     idle = [r for r in trace if r["phase"] == "idle"]
     cool = [r for r in trace if r["phase"] == "cool"]
-    gauge = _mean([r["power_w"] for r in burn])
-    # accumulator mean over the burn window: each sample's powerAvgW is delta energy / delta time since the
-    # previous sample of this source, and the samples are evenly spaced
-    acc = _mean([r["power_avg_w"] for r in burn[1:]])
+
+    def gauge_vs_accumulator(rows: List[Dict[str, Any]]):
+        """(mean gauge, accumulator mean) over the rows: energy at the last sample minus energy at the first over the
+        time between them (one long baseline), else the mean of the per-sample accumulator powers."""
+        gauge = _mean([r["power_w"] for r in rows[1:]])
+        # the accumulator is read out of a table the driver refreshes about once a second: its time is the table's
+        # own (firmware) clock, not the host time of the read
+        e = [(r["table_t"] if r.get("table_t") else r["t"], r["energy_j"]) for r in rows if r.get("energy_j") is not None]
+        acc = (e[-1][1] - e[0][1]) / (e[-1][0] - e[0][0]) if len(e) >= 2 and e[-1][0] > e[0][0] else None
+        if acc is None or acc <= 0:
+            acc = _mean([r["power_avg_w"] for r in rows[1:]])
+        return gauge, acc
+
+    steady = [r for r in burn if r["t"] - t_burn0 >= steady_after_s]
+    onset = [r for r in burn if r["t"] - t_burn0 < steady_after_s]
+    gauge, acc = gauge_vs_accumulator(steady)
+    gauge_on, acc_on = gauge_vs_accumulator(onset)
     temps = [r["temperature"] for r in burn if r["temperature"] is not None]
     t_idle = _mean([r["temperature"] for r in idle])
     worst_drop, run_max = 0.0, None
@@ -368,15 +387,19 @@ def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s
     t_cool_min = min([r["temperature"] for r in cool if r["temperature"] is not None], default=None)
     res: Dict[str, Any] = {
         "burn_s": burn_s, "samples": len(trace), "sample_hz": hz, "tflops_busy": out.get("tflops_busy"), "duty_achieved": out.get("duty_achieved"),
-        "power_gauge_mean_w": gauge, "power_accumulator_mean_w": acc,
+        "steady_after_s": steady_after_s, "power_gauge_mean_w": gauge, "power_accumulator_mean_w": acc,
+        "power_gauge_onset_mean_w": gauge_on, "power_accumulator_onset_mean_w": acc_on,
+        "power_error_onset_pct": abs(gauge_on - acc_on) / acc_on * 100.0 if gauge_on and acc_on else None,
+        "power_gauge_max_w": max([r["power_w"] for r in burn if r["power_w"] is not None], default=None),
         "power_idle_w": _mean([r["power_w"] for r in idle]),
         "power_error_pct": abs(gauge - acc) / acc * 100.0 if gauge and acc else None,
         "temperature_idle_c": t_idle, "temperature_burn_first_c": temps[0] if temps else None,
         "temperature_burn_last_c": temps[-1] if temps else None, "temperature_burn_max_c": max(temps) if temps else None,
         "temperature_worst_drop_under_load_c": worst_drop if temps else None, "temperature_cool_min_c": t_cool_min,
         "hbm_temperature_burn_max_c": max([r["hbm_temperature"] for r in burn if r["hbm_temperature"] is not None], default=None),
-        "trace": [{"t": round(r["t"] - trace[0]["t"], 2), "phase": r["phase"], "power_w": r["power_w"], "temperature": r["temperature"]}
-                  for r in trace[::max(1, int(hz / 2))]]}
+        "trace": [{"t": round(r["t"] - trace[0]["t"], 2), "phase": r["phase"], "power_w": r["power_w"],
+                   "power_avg_w": None if r["power_avg_w"] is None else round(r["power_avg_w"], 1), "temperature": r["temperature"],
+                   "clock_gfx_mhz": r["clock_gfx_mhz"]} for r in trace[::max(1, int(hz / 2))]]}
     if temps and t_idle is not None:
         rise = max(temps) - t_idle
         res["temperature_rise_c"] = rise
@@ -672,7 +695,7 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
         if "activity" in want:
             guard("activity_fidelity", lambda: activity_fidelity(torch, dev, src, idx, seconds=4.0 if quick else 10.0))
         if "power" in want:
-            guard("power_temperature", lambda: power_temperature(torch, dev, src, idx, burn_s=8.0 if quick else 20.0))
+            guard("power_temperature", lambda: power_temperature(torch, dev, src, idx, burn_s=13.0 if quick else 25.0))
         if "mem" in want:
             guard("mem_activity", lambda: mem_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
         if "overhead" in want:

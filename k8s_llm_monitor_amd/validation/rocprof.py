@@ -240,11 +240,16 @@ def overhead_kernel_trace(outdir: str, repeats: int = 3, seconds: float = 5.0, s
             cmd = burner_cmd(duty=100.0, seconds=seconds, size=size) + (["--monitored", "--monitor-period", str(monitor_period)] if leg == "on" else [])
             res = kernel_trace(cmd, os.path.join(outdir, f"{leg}{i}"))
             d = kernel_durations(res["rows"], "gemm_bf16")
+            ks = sorted((r for r in res["rows"] if "gemm_bf16" in r["name"]), key=lambda r: r["start"])[16:]
+            med = sorted(d)[len(d) // 2] if d else 0.0
+            # kernels that took more than twice the median: when in the window, and how long
+            outliers = [{"at_s": round((r["start"] - ks[0]["start"]) / 1e9, 3), "us": round((r["end"] - r["start"]) / 1e3, 1)}
+                        for r in ks if (r["end"] - r["start"]) / 1e3 > 2.0 * med][:20]
             d.sort()
             n = len(d)
             legs[leg].append({"kernels": n, "mean_us": sum(d) / n if n else None, "median_us": d[n // 2] if n else None,
                               "p99_us": d[min(n - 1, int(n * 0.99))] if n else None, "max_us": d[-1] if n else None,
-                              "monitor": "monitor" in res["stdout"]})
+                              "outliers_over_2x_median": outliers, "monitor": "monitor" in res["stdout"]})
     diffs = [(on["mean_us"] - off["mean_us"]) / off["mean_us"] * 100.0 for off, on in zip(legs["off"], legs["on"])
              if off["mean_us"] and on["mean_us"]]
     meds = [(on["median_us"] - off["median_us"]) / off["median_us"] * 100.0 for off, on in zip(legs["off"], legs["on"])

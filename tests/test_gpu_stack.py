@@ -196,3 +196,31 @@ def test_standalone_cpp_burner(torch_dev):
     assert fin["duty_achieved"] > 97.0 and fin["tflops_avg"] > 2500
     out = run("--kind", "hbm_copy", "--seconds", "1.5", "--hbm-gib", "8")
     assert out[0] == {"hbm_hold_gib": 8.0} and out[-1]["TBps_busy"] > 3.5
+
+
+def test_power_gauge_agrees_with_the_energy_accumulator_and_temperature_follows_the_load(torch_dev):
+    """The power / temperature phase of `validate`, shortened: two independent power sources at a steady 100 % duty."""
+    torch, dev = torch_dev
+    from k8s_llm_monitor_amd.collectors.gpu import open_gpu_source
+    from k8s_llm_monitor_amd.validation import phases
+    src = open_gpu_source("amdsmi")
+    try:
+        idx = phases._smi_index_for(torch, dev, src)
+        r = phases.power_temperature(torch, dev, src, idx, idle_s=1.0, burn_s=9.0, cool_s=3.0, steady_after_s=5.0)
+    finally:
+        src.close()
+    assert r["power_accumulator_mean_w"] > 800 and r["power_gauge_mean_w"] > 800, r
+    assert r["power_error_pct"] < 5.0, r                       # `validate` holds it to its 2 % target over a longer window
+    assert r["temperature_rise_c"] >= 3.0 and r["temperature_monotonic"] and r["temperature_follows_load"], r
+    assert r["power_idle_w"] < 0.6 * r["power_gauge_mean_w"]
+
+
+def test_product_overhead_leg_samples_at_least_four_times(torch_dev):
+    """The overhead phase in its shortest form: the whole product beside the burner, paired differences with an interval."""
+    torch, dev = torch_dev
+    from k8s_llm_monitor_amd.validation import phases
+    r = phases.overhead(torch, dev, seconds=2.5, period_s=0.5, repeats=2, pollers=2)
+    assert r["sampler_stats"]["on"]["calls"] >= 4 and r["sampler_stats"]["on"]["errors"] == 0
+    assert r["sampler_stats"]["on"]["clients"]["errors"] == 0 and r["sampler_stats"]["on"]["clients"]["sse_events"] >= 1
+    assert r["overhead"]["n"] == 2 and r["overhead"]["ci95_pct"] is not None
+    assert abs(r["overhead_pct"]) < 3.0 and abs(r["overhead_gpu_side_pct"]) < 3.0, r

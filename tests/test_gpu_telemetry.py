@@ -63,6 +63,43 @@ def test_normaliser_uses_accumulator_deltas(clock):
     assert s["hbmTotalBytes"] == HBM_TOTAL_MIB << 20 and 0 < s["hbmPercent"] < 100
 
 
+def test_rates_follow_the_tables_own_clock_and_hold_while_it_is_stale():
+    """The driver refreshes the metrics table about once a second (measured on MI355X). A read 0.61 s after the
+    previous one that sees a table 1.0 s newer must give delta energy over 1.0 s, and a second read of the same
+    table must repeat the period figures instead of reporting zero power and no activity."""
+    n = GpuNormalizer()
+    res_uj = 15.3
+    counts_per_s_at_1390w = 1390.0 / (res_uj * 1e-6)
+
+    def raw(host_t, table_s):
+        return {"index": 0, "t": host_t, "vram_used_mib": 1000, "vram_total_mib": 294896, "energy_resolution_uj": res_uj,
+                "firmware_timestamp": int(5_000_000_000 + table_s * 1e8), "accumulation_counter": int(1000 * table_s),
+                "gfx_activity_acc": int(1000 * table_s * 100), "mem_activity_acc": int(1000 * table_s * 40),
+                "energy_acc": int(10_000_000 + counts_per_s_at_1390w * table_s), "power_w": 1386,
+                "xgmi_read_kib": [int(table_s * 50e9 / 1024)] * 2, "xgmi_write_kib": [int(table_s * 25e9 / 1024)] * 2,
+                "xgmi_link_status": ["U", "U"]}
+
+    assert n.normalize(raw(0.00, 0.0))["powerAvgW"] is None
+    s = n.normalize(raw(0.61, 1.0))                          # host says 0.61 s, the table moved 1.0 s
+    assert s["powerAvgW"] == pytest.approx(1390.0, rel=1e-4) and s["gfxActivityAvg"] == pytest.approx(100.0)
+    assert s["xgmi"]["links"][0]["rxGBps"] == pytest.approx(50.0, rel=1e-3)
+    assert s["metricsTableTimeS"] == pytest.approx(51.0) and s["energyJ"] == pytest.approx((10_000_000 + counts_per_s_at_1390w) * res_uj * 1e-6)
+    for host_t in (0.66, 0.71):                              # the same table again: figures held, not zeroed
+        s = n.normalize(raw(host_t, 1.0))
+        assert s["powerAvgW"] == pytest.approx(1390.0, rel=1e-4) and s["gfxActivityAvg"] == pytest.approx(100.0)
+        assert s["memActivityAvg"] == pytest.approx(40.0) and s["xgmi"]["links"][1]["txGBps"] == pytest.approx(25.0, rel=1e-3)
+        assert s["utilization"] == 100
+    s = n.normalize(raw(1.62, 2.0))
+    assert s["powerAvgW"] == pytest.approx(1390.0, rel=1e-4)
+    # a reader without the firmware clock (the fakes, an older library) still gets host-time rates
+    m = GpuNormalizer()
+    a, b = raw(0.0, 0.0), raw(2.0, 2.0)
+    a.pop("firmware_timestamp"), b.pop("firmware_timestamp")
+    m.normalize(a)
+    s = m.normalize(b)
+    assert s["powerAvgW"] == pytest.approx(1390.0, rel=1e-4) and s["metricsTableTimeS"] is None
+
+
 def test_reference_keys_and_types(clock):
     s = GpuSource(FakeGpuReader(8, clock=clock)).sample()
     assert len(s) == 8 and [g["index"] for g in s] == list(range(8))

@@ -69,7 +69,7 @@ class GpuNormalizer:
         prev = self._prev.get(idx)
         self._prev[idx] = raw
         # The driver refreshes the metrics table about once a second (measured on MI355X: 6 changes in 6 s at 20 Hz
-        # polling, profiles/r2_prof/energy_timebase.json), so its accumulators belong to the table's OWN clock
+        # polling, profiles/r2_validation/energy_timebase.json), so its accumulators belong to the table's OWN clock
         # (firmware_timestamp, 10 ns ticks: 100.6 M per host second), not to the host time of the read: against
         # the host clock a rate is off by up to one refresh per period, and a table read twice gives a zero.
         fw = _int(raw.get("firmware_timestamp"))

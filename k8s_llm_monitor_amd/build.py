@@ -66,7 +66,8 @@ def targets() -> List[Target]:
     ]
     burner = PKG / "loadgen" / "native" / "klm_burner.cpp"
     if burner.exists():
-        out.append(Target("klm_burner", BIN_DIR / "klm_burner", [burner, *ops_src], "hip-exe",
+        # the standalone burner carries the load-generator kernels only (GEMMs, HBM, spin), not the serving engine's
+        out.append(Target("klm_burner", BIN_DIR / "klm_burner", [burner, *[x for x in ops_src if not x.name.startswith("llm_")]], "hip-exe",
                           extra=[f"-I{ops}"], deps=[hdr, ops / "llm_common.h", ops / "gemm_ring256.h", ops / "gemm_quad128.h"]))
     probe = PKG / "parallel" / "csrc" / "rccl_probe.cpp"
     if probe.exists():
@@ -156,7 +157,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--list", action="store_true")
-    ap.add_argument("--sanitize", action="store_true", help="also build the host-sanitizer preset (bin-asan/) of the C++ executables")
+    ap.add_argument("--sanitize", action="store_true", help="also build the host-sanitizer preset (bin-asan/) of the C++ and HIP executables")
     ap.add_argument("targets", nargs="*")
     a = ap.parse_args(argv)
     if a.list:
@@ -166,7 +167,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     built = build_all(force=a.force, only=a.targets or None)
     if a.sanitize:
         for t in targets():
-            if t.kind == "cxx-exe" and (not a.targets or t.name in a.targets):
+            # every executable: plain C++ ones whole, HIP ones on the host side (argument parsing, JSON printing, the launch loop)
+            if t.kind in ("cxx-exe", "hip-exe") and (not a.targets or t.name in a.targets):
                 if build_target(sanitized(t), force=a.force):
                     built.append(t.name + "-asan")
     print("built:", ", ".join(built) if built else "(nothing stale)")

@@ -8,6 +8,7 @@
 //              [--size 8192] [--duty 100] [--period-ms 100] [--seconds 10]
 //              [--hbm-gib G]   also allocate and touch G GiB (HBM exhaustion injector)
 //              [--device 0]
+//   klm_burner --selftest      no GPU: the window planner and the JSON writers on fixed inputs (sanitizer runs)
 // Output: one JSON line per second {"t","kernels","duty","tflops"|"TBps"} and a final summary.
 #include <hip/hip_runtime.h>
 
@@ -78,6 +79,66 @@ struct Args {
   double duty = 100, period_ms = 100, seconds = 10, hbm_gib = 0;
 };
 
+static const char* const KINDS[] = {"gemm_bf16", "gemm_fp8", "gemm_fp4", "hbm_copy", "hbm_read", "hbm_fill", "spin"};
+static bool known_kind(const std::string& k) {
+  for (const char* x : KINDS)
+    if (k == x) return true;
+  return false;
+}
+// a string inside a JSON value: quotes, backslashes and control bytes escaped
+static std::string json_escape(const std::string& in) {
+  std::string out;
+  for (unsigned char c : in) {
+    if (c == '"' || c == '\\') { out += '\\'; out += (char)c; }
+    else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); out += b; }
+    else out += (char)c;
+  }
+  return out;
+}
+// kernels per busy window: the whole number whose run time is closest to duty * period, at least 1 when
+// duty > 0 (the same law as loadgen/burner.py::plan_window)
+static int plan_window(double duty, double period_s, double kernel_s) {
+  if (duty <= 0 || kernel_s <= 0) return 0;
+  return std::max(1, (int)std::lround(std::min(1.0, duty / 100.0) * period_s / kernel_s));
+}
+static void print_report(double wall, long kernels, double busy_s, double flops, double bytes) {
+  printf("{\"t\":%.3f,\"kernels\":%ld,\"duty\":%.2f", wall, kernels, std::min(100.0, busy_s / wall * 100.0));
+  if (flops) printf(",\"tflops\":%.2f", flops * kernels / std::max(busy_s, 1e-9) / 1e12);
+  if (bytes) printf(",\"TBps\":%.3f", bytes * kernels / std::max(busy_s, 1e-9) / 1e12);
+  printf("}\n");
+  fflush(stdout);
+}
+static void print_summary(const Args& a, double kernel_s, long kernels, double wall, double busy_s, double flops, double bytes, double held) {
+  printf("{\"kind\":\"%s\",\"size\":%d,\"duty_target\":%.2f,\"period_ms\":%.2f,\"kernel_ms\":%.4f,\"kernels\":%ld,"
+         "\"wall_s\":%.3f,\"duty_achieved\":%.3f",
+         json_escape(a.kind).c_str(), a.size, a.duty, a.period_ms, kernel_s * 1e3, kernels, wall, std::min(100.0, busy_s / wall * 100.0));
+  if (flops) printf(",\"tflops_busy\":%.2f,\"tflops_avg\":%.2f", flops * kernels / std::max(busy_s, 1e-9) / 1e12, flops * kernels / wall / 1e12);
+  if (bytes) printf(",\"TBps_busy\":%.3f,\"TBps_avg\":%.3f", bytes * kernels / std::max(busy_s, 1e-9) / 1e12, bytes * kernels / wall / 1e12);
+  if (held > 0) printf(",\"hbm_hold_gib\":%.3f", held / (double)((size_t)1 << 30));
+  printf("}\n");
+  fflush(stdout);
+}
+
+// --selftest: no device. Prints the planner's answers for a fixed table (tests compare them with the Python
+// planner) and one report and one summary line built from fixed numbers, with a hostile kind string.
+static int selftest() {
+  const double duties[] = {0, 1, 25, 50, 75, 99.5, 100}, kernels_s[] = {20e-6, 730e-6, 2.1e-3, 0.25};
+  printf("{\"selftest\":\"plan\",\"period_s\":0.1,\"rows\":[");
+  bool first = true;
+  for (double d : duties)
+    for (double k : kernels_s) {
+      printf("%s[%.2f,%.6g,%d]", first ? "" : ",", d, k, plan_window(d, 0.1, k));
+      first = false;
+    }
+  printf("]}\n");
+  print_report(2.0, 2700, 1.97, 2.0 * 8192.0 * 8192.0 * 8192.0, 0.0);
+  print_report(2.0, 1400, 2.0, 0.0, 4294967296.0);
+  Args a;
+  a.kind = "gemm\"bf16\\\n";
+  print_summary(a, 730e-6, 2700, 2.0, 1.97, 2.0 * 8192.0 * 8192.0 * 8192.0, 0.0, 3.0 * (double)((size_t)1 << 30));
+  return 0;
+}
+
 int main(int argc, char** argv) {
   Args a;
   for (int i = 1; i < argc; ++i) {
@@ -93,7 +154,20 @@ int main(int argc, char** argv) {
     else if (k == "--seconds") a.seconds = atof(val());
     else if (k == "--hbm-gib") a.hbm_gib = atof(val());
     else if (k == "--device") a.device = atoi(val());
-    else { fprintf(stderr, "see the header of klm_burner.cpp for usage\n"); return k == "--help" ? 0 : 1; }
+    else if (k == "--selftest") return selftest();
+    else {
+      fprintf(stderr, "usage: klm_burner --kind gemm_bf16|gemm_fp8|gemm_fp4|hbm_copy|hbm_read|hbm_fill|spin [--size 8192] [--duty 100] "
+                      "[--period-ms 100] [--seconds 10] [--hbm-gib G] [--device 0] | --selftest\n");
+      return (k == "--help" || k == "-h") ? 0 : 1;
+    }
+  }
+  if (!known_kind(a.kind)) {      // before any HIP call: a typo must not need a GPU to be reported
+    printf("{\"error\":\"unknown kind %s\"}\n", json_escape(a.kind).c_str());
+    return 1;
+  }
+  if (a.device < 0 || a.hbm_gib < 0 || a.hbm_gib > 1024) {
+    printf("{\"error\":\"bad arguments (device >= 0, hbm-gib 0..1024)\"}\n");
+    return 1;
   }
   if (a.duty < 0 || a.duty > 100 || a.period_ms <= 0 || a.seconds <= 0 || a.size <= 0 || a.size % 256) {
     printf("{\"error\":\"bad arguments (size must be a multiple of 256, duty 0..100)\"}\n");
@@ -108,10 +182,6 @@ int main(int argc, char** argv) {
   const bool gemm = a.kind == "gemm_bf16" || a.kind == "gemm_fp8" || a.kind == "gemm_fp4";
   const bool fp8 = a.kind == "gemm_fp8", fp4 = a.kind == "gemm_fp4";
   const bool hbm = a.kind.rfind("hbm_", 0) == 0;
-  if (!gemm && !hbm && a.kind != "spin") {
-    printf("{\"error\":\"unknown kind %s\"}\n", a.kind.c_str());
-    return 1;
-  }
   void *A = nullptr, *B = nullptr, *C = nullptr, *X = nullptr, *Y = nullptr, *sink = nullptr;
   double flops = 0, bytes = 0;
   const size_t n2 = (size_t)a.size * a.size;
@@ -189,7 +259,7 @@ int main(int argc, char** argv) {
   const bool full = a.duty >= 100.0;
   // closed loop: every retired window updates the per-kernel estimate the next one is sized by
   double k_est = kernel_s;
-  auto plan = [&]() { return a.duty <= 0 ? 0 : std::max(1, (int)std::lround(std::min(1.0, a.duty / 100.0) * period_s / k_est)); };
+  auto plan = [&]() { return plan_window(a.duty, period_s, k_est); };
 
   struct Win { hipEvent_t e0, e1; int n; };
   std::deque<Win> pending;
@@ -243,23 +313,11 @@ int main(int argc, char** argv) {
     const double now = now_s();
     if (now >= next_report) {
       next_report += 1.0;
-      const double wall = now - t_start;
-      printf("{\"t\":%.3f,\"kernels\":%ld,\"duty\":%.2f", wall, kernels, std::min(100.0, busy_s / wall * 100.0));
-      if (flops) printf(",\"tflops\":%.2f", flops * kernels / std::max(busy_s, 1e-9) / 1e12);
-      if (bytes) printf(",\"TBps\":%.3f", bytes * kernels / std::max(busy_s, 1e-9) / 1e12);
-      printf("}\n");
-      fflush(stdout);
+      print_report(now - t_start, kernels, busy_s, flops, bytes);
     }
   }
   while (!pending.empty()) retire(true);
-  const double wall = now_s() - t_start;
-  printf("{\"kind\":\"%s\",\"size\":%d,\"duty_target\":%.2f,\"period_ms\":%.2f,\"kernel_ms\":%.4f,\"kernels\":%ld,"
-         "\"wall_s\":%.3f,\"duty_achieved\":%.3f",
-         a.kind.c_str(), a.size, a.duty, a.period_ms, kernel_s * 1e3, kernels, wall, std::min(100.0, busy_s / wall * 100.0));
-  if (flops) printf(",\"tflops_busy\":%.2f,\"tflops_avg\":%.2f", flops * kernels / std::max(busy_s, 1e-9) / 1e12, flops * kernels / wall / 1e12);
-  if (bytes) printf(",\"TBps_busy\":%.3f,\"TBps_avg\":%.3f", bytes * kernels / std::max(busy_s, 1e-9) / 1e12, bytes * kernels / wall / 1e12);
-  printf("}\n");
-  fflush(stdout);
+  print_summary(a, kernel_s, kernels, now_s() - t_start, busy_s, flops, bytes, held);
   for (void* p : hold) (void)hipFree(p);
   for (void* p : {A, B, C, X, Y, sink}) if (p) (void)hipFree(p);
   return 0;

@@ -5,9 +5,10 @@
 // over xGMI, algBW and busBW per size, JSON the server exposes and the dashboard plots".
 //
 // One process, one communicator per device (ncclCommInitAll), all ranks driven from this
-// thread inside ncclGroupStart/End. Per message size: `warmup` untimed rounds, then `iters`
-// rounds timed with hipEvents on rank 0's stream between two cross-device syncs; every
-// stream is synchronised before the clock stops, so the time is the slowest rank's.
+// thread inside ncclGroupStart/End, IN PLACE (send == recv, as a gradient all-reduce runs;
+// --out-of-place for the other form). Per message size: `warmup` untimed rounds, then `iters`
+// rounds timed with a hipEvent pair on EVERY rank's stream between two cross-device syncs; the
+// reported time is the slowest rank's (`time_us` = `time_us_max_rank`; rank 0's own beside it).
 // Output: JSON lines on stdout (parallel/probe.py parses them):
 //   {"type":"header",...}  {"type":"point",...}*  {"type":"summary",...}   or {"type":"error",...}
 //
@@ -15,7 +16,10 @@
 // device-local copy, reported as algBW with busBW 0.
 //
 // Data check: each rank's buffer holds (rank + 1) before the first all-reduce of a size; the
-// sum must be n(n+1)/2 in every element (exact in bf16 and fp32 for n <= 8).
+// sum must be n(n+1)/2 in EVERY element of every rank's buffer (exact in bf16 and fp32 for
+// n <= 8): a compare kernel counts the elements that differ. The timed rounds then reduce the
+// buffer onto itself again and again; the values grow (x n per round) and stay finite for the
+// default round counts, which is all a bandwidth figure needs.
 #include <hip/hip_runtime.h>
 #include <rccl.h>
 
@@ -51,7 +55,7 @@ struct Args {
   std::string dtype = "bf16";
   size_t min_bytes = 1024, max_bytes = (size_t)1 << 30;
   int factor = 4, warmup = 5, iters = 20;
-  bool check = true;
+  bool check = true, in_place = true, selftest = false;
 };
 
 static bool parse(int argc, char** argv, Args& a) {
@@ -72,6 +76,8 @@ static bool parse(int argc, char** argv, Args& a) {
     else if (k == "--warmup") a.warmup = atoi(next("--warmup"));
     else if (k == "--iters") a.iters = atoi(next("--iters"));
     else if (k == "--no-check") a.check = false;
+    else if (k == "--out-of-place") a.in_place = false;
+    else if (k == "--selftest") a.selftest = true;
     else if (k == "--help" || k == "-h") return false;
     else {
       printf("{\"type\":\"error\",\"error\":\"unknown argument %s\"}\n", k.c_str());
@@ -100,12 +106,89 @@ __global__ void fill16(uint16_t* p, size_t n, uint16_t v) {
 __global__ void fill32(float* p, size_t n, float v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+// elements of p[0..n) whose bit pattern is not `want` -> *bad (one atomic per thread that found any)
+template <typename T>
+__global__ void count_mismatch(const T* p, size_t n, T want, unsigned long long* bad) {
+  unsigned long long mine = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += p[i] != want;
+  if (mine) atomicAdd(bad, mine);
+}
+
+static std::string json_escape(const std::string& in) {
+  std::string out;
+  for (unsigned char c : in) {
+    if (c == '"' || c == '\\') { out += '\\'; out += (char)c; }
+    else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); out += b; }
+    else out += (char)c;
+  }
+  return out;
+}
+// message sizes of the sweep: min, min*f, ... below max, then max itself; each a whole number of elements
+static std::vector<size_t> sweep_sizes(size_t min_bytes, size_t max_bytes, int factor, size_t esz) {
+  std::vector<size_t> sizes;
+  for (size_t b = min_bytes; b < max_bytes; b *= (size_t)factor) {
+    sizes.push_back(b - b % esz);
+    if (b > max_bytes / (size_t)factor) break;      // the next product would pass max (or overflow)
+  }
+  sizes.push_back(max_bytes - max_bytes % esz);
+  return sizes;
+}
+static void print_header(const Args& a, int n, int ver, const char* device, const char* arch) {
+  printf("{\"type\":\"header\",\"n_gpus\":%d,\"dtype\":\"%s\",\"op\":\"allreduce\",\"warmup\":%d,\"iters\":%d,"
+         "\"rccl_version\":%d,\"device\":\"%s\",\"arch\":\"%s\",\"min_bytes\":%zu,\"max_bytes\":%zu,\"factor\":%d,"
+         "\"in_place\":%s,\"timing\":\"event pair per rank, max over ranks\",\"check\":\"%s\"}\n",
+         n, json_escape(a.dtype).c_str(), a.warmup, a.iters, ver, json_escape(device).c_str(), json_escape(arch).c_str(),
+         a.min_bytes, a.max_bytes, a.factor, a.in_place ? "true" : "false", a.check ? "every element, device compare" : "off");
+  fflush(stdout);
+}
+struct Point {
+  double sec = 0, sec_rank0 = 0, alg = 0, bus = 0;
+};
+static Point make_point(size_t bytes, int n, int iters, float ms_max, float ms_rank0) {
+  Point p;
+  p.sec = (double)ms_max * 1e-3 / iters;
+  p.sec_rank0 = (double)ms_rank0 * 1e-3 / iters;
+  p.alg = p.sec > 0 ? bytes / p.sec / 1e9 : 0.0;
+  p.bus = p.alg * (n > 1 ? 2.0 * (n - 1) / n : 0.0);
+  return p;
+}
+static void print_point(const Args& a, int n, size_t bytes, const Point& p, const char* check, size_t checked, unsigned long long mismatched) {
+  printf("{\"type\":\"point\",\"n_gpus\":%d,\"bytes\":%zu,\"dtype\":\"%s\",\"op\":\"allreduce\",\"time_us\":%.3f,"
+         "\"time_us_max_rank\":%.3f,\"time_us_rank0\":%.3f,\"algbw_GBps\":%.4f,\"busbw_GBps\":%.4f,\"check\":\"%s\","
+         "\"elements_checked\":%zu,\"elements_mismatched\":%llu}\n",
+         n, bytes, json_escape(a.dtype).c_str(), p.sec * 1e6, p.sec * 1e6, p.sec_rank0 * 1e6, p.alg, p.bus, check, checked, mismatched);
+  fflush(stdout);
+}
+static void print_summary(const Args& a, int n, double peak_bus, double peak_alg, size_t peak_bytes) {
+  printf("{\"type\":\"summary\",\"n_gpus\":%d,\"dtype\":\"%s\",\"peak_busbw_GBps\":%.4f,\"peak_algbw_GBps\":%.4f,"
+         "\"peak_bytes\":%zu,\"ceiling_mesh_GBps\":%.1f,\"ceiling_ring_GBps\":%.1f}\n",
+         n, json_escape(a.dtype).c_str(), peak_bus, peak_alg, peak_bytes, n > 1 ? (n - 1) * 153.0 : 0.0, n > 1 ? 153.0 : 0.0);
+  fflush(stdout);
+}
+// --selftest: no device and no RCCL call. The sweep's size list and the three JSON writers on fixed numbers
+// (8 ranks, 256 MiB in 1.25 ms on the slowest rank), for the sanitizer run and the parser's tests.
+static int selftest(Args a) {
+  a.gpus = 8;
+  print_header(a, 8, 22705, "AMD \"Instinct\" MI355X\\", "gfx950:sramecc+:xnack-");
+  double peak_bus = 0, peak_alg = 0;
+  size_t peak_bytes = 0;
+  for (size_t bytes : sweep_sizes(a.min_bytes, a.max_bytes, a.factor, a.dtype == "bf16" ? 2 : 4)) {
+    const float ms = (float)(20.0 * (0.02 + bytes / 214.7e6));          // 20 us latency + 214.7 GB/s algBW, 20 iters
+    const Point p = make_point(bytes, 8, 20, ms, ms * 0.97f);
+    if (p.bus > peak_bus) peak_bytes = bytes;
+    peak_bus = std::max(peak_bus, p.bus);
+    peak_alg = std::max(peak_alg, p.alg);
+    print_point(a, 8, bytes, p, "ok", bytes / 2 * 8, 0);
+  }
+  print_summary(a, 8, peak_bus, peak_alg, peak_bytes);
+  return 0;
+}
 
 int main(int argc, char** argv) {
   Args a;
   if (!parse(argc, argv, a)) {
     fprintf(stderr, "usage: klm_rccl_probe [--gpus N] [--dtype bf16|fp32] [--min B] [--max B] [--factor F] "
-                    "[--warmup W] [--iters I] [--no-check]\n");
+                    "[--warmup W] [--iters I] [--no-check] [--out-of-place] | --selftest\n");
     return 0;
   }
   const bool is_bf16 = a.dtype == "bf16";
@@ -119,6 +202,7 @@ int main(int argc, char** argv) {
     printf("{\"type\":\"error\",\"error\":\"bad arguments\"}\n");
     return 1;
   }
+  if (a.selftest) return selftest(a);
   int have = 0;
   HIPCHECK(hipGetDeviceCount(&have));
   if (have < a.gpus) {
@@ -135,23 +219,21 @@ int main(int argc, char** argv) {
 
   std::vector<hipStream_t> streams(n);
   std::vector<void*> send(n), recv(n);
+  std::vector<unsigned long long*> bad(n);
+  std::vector<hipEvent_t> ev0(n), ev1(n);
   for (int i = 0; i < n; ++i) {
     HIPCHECK(hipSetDevice(i));
     HIPCHECK(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
     HIPCHECK(hipMalloc(&send[i], a.max_bytes));
-    HIPCHECK(hipMalloc(&recv[i], a.max_bytes));
+    if (a.in_place) recv[i] = send[i];
+    else HIPCHECK(hipMalloc(&recv[i], a.max_bytes));
+    HIPCHECK(hipMalloc((void**)&bad[i], sizeof(unsigned long long)));
+    HIPCHECK(hipEventCreate(&ev0[i]));
+    HIPCHECK(hipEventCreate(&ev1[i]));
   }
   hipDeviceProp_t prop;
   HIPCHECK(hipGetDeviceProperties(&prop, 0));
-  printf("{\"type\":\"header\",\"n_gpus\":%d,\"dtype\":\"%s\",\"op\":\"allreduce\",\"warmup\":%d,\"iters\":%d,"
-         "\"rccl_version\":%d,\"device\":\"%s\",\"arch\":\"%s\",\"min_bytes\":%zu,\"max_bytes\":%zu,\"factor\":%d}\n",
-         n, a.dtype.c_str(), a.warmup, a.iters, ver, prop.name, prop.gcnArchName, a.min_bytes, a.max_bytes, a.factor);
-  fflush(stdout);
-
-  HIPCHECK(hipSetDevice(0));
-  hipEvent_t e0, e1;
-  HIPCHECK(hipEventCreate(&e0));
-  HIPCHECK(hipEventCreate(&e1));
+  print_header(a, n, ver, prop.name, prop.gcnArchName);
 
   auto sync_all = [&]() {
     for (int i = 0; i < n; ++i) {
@@ -165,15 +247,11 @@ int main(int argc, char** argv) {
     NCCLCHECK(ncclGroupEnd());
   };
 
-  std::vector<size_t> sizes;
-  for (size_t b = a.min_bytes; b < a.max_bytes; b *= (size_t)a.factor) sizes.push_back(b);
-  sizes.push_back(a.max_bytes);
+  const std::vector<size_t> sizes = sweep_sizes(a.min_bytes, a.max_bytes, a.factor, esz);
 
   double peak_bus = 0, peak_alg = 0;
   size_t peak_bytes = 0;
-  const double bus_factor = n > 1 ? 2.0 * (n - 1) / n : 0.0;
   for (size_t bytes : sizes) {
-    bytes -= bytes % esz;
     const size_t count = bytes / esz;
     for (int i = 0; i < n; ++i) {
       HIPCHECK(hipSetDevice(i));
@@ -185,60 +263,61 @@ int main(int argc, char** argv) {
     const char* check = "skipped";
     round(count);
     sync_all();
+    unsigned long long mismatched = 0;
     if (a.check) {
-      const double want = n * (n + 1) / 2.0;
-      bool ok = true;
-      const size_t probe_idx[3] = {0, count / 2, count - 1};
-      for (int i = 0; i < n && ok; ++i) {
+      const float want = (float)(n * (n + 1) / 2);
+      const int grid = (int)std::min<size_t>(2048, (count + 255) / 256);
+      for (int i = 0; i < n; ++i) {
         HIPCHECK(hipSetDevice(i));
-        for (size_t idx : probe_idx) {
-          double got;
-          if (is_bf16) {
-            uint16_t h;
-            HIPCHECK(hipMemcpy(&h, (uint16_t*)recv[i] + idx, 2, hipMemcpyDeviceToHost));
-            got = bf16_to_float(h);
-          } else {
-            float f;
-            HIPCHECK(hipMemcpy(&f, (float*)recv[i] + idx, 4, hipMemcpyDeviceToHost));
-            got = f;
-          }
-          if (got != want) ok = false;
-        }
+        HIPCHECK(hipMemsetAsync(bad[i], 0, sizeof(unsigned long long), streams[i]));
+        if (is_bf16) hipLaunchKernelGGL(count_mismatch<uint16_t>, dim3(grid), dim3(256), 0, streams[i], (const uint16_t*)recv[i], count, bf16_bits(want), bad[i]);
+        else hipLaunchKernelGGL(count_mismatch<float>, dim3(grid), dim3(256), 0, streams[i], (const float*)recv[i], count, want, bad[i]);
       }
-      check = ok ? "ok" : "MISMATCH";
+      for (int i = 0; i < n; ++i) {
+        HIPCHECK(hipSetDevice(i));
+        unsigned long long b = 0;
+        HIPCHECK(hipMemcpyAsync(&b, bad[i], sizeof(b), hipMemcpyDeviceToHost, streams[i]));
+        HIPCHECK(hipStreamSynchronize(streams[i]));
+        mismatched += b;
+      }
+      check = mismatched == 0 ? "ok" : "MISMATCH";
     }
     for (int w = 0; w < a.warmup; ++w) round(count);
     sync_all();
-    HIPCHECK(hipSetDevice(0));
-    HIPCHECK(hipEventRecord(e0, streams[0]));
+    for (int i = 0; i < n; ++i) {
+      HIPCHECK(hipSetDevice(i));
+      HIPCHECK(hipEventRecord(ev0[i], streams[i]));
+    }
     for (int it = 0; it < a.iters; ++it) round(count);
-    HIPCHECK(hipSetDevice(0));
-    HIPCHECK(hipEventRecord(e1, streams[0]));
+    for (int i = 0; i < n; ++i) {
+      HIPCHECK(hipSetDevice(i));
+      HIPCHECK(hipEventRecord(ev1[i], streams[i]));
+    }
     sync_all();
-    HIPCHECK(hipSetDevice(0));
-    HIPCHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-    const double sec = (double)ms * 1e-3 / a.iters;
-    const double alg = sec > 0 ? bytes / sec / 1e9 : 0.0;
-    const double bus = alg * bus_factor;
-    if ((n > 1 ? bus : alg) > (n > 1 ? peak_bus : peak_alg)) peak_bytes = bytes;
-    peak_bus = std::max(peak_bus, bus);
-    peak_alg = std::max(peak_alg, alg);
-    printf("{\"type\":\"point\",\"n_gpus\":%d,\"bytes\":%zu,\"dtype\":\"%s\",\"op\":\"allreduce\",\"time_us\":%.3f,"
-           "\"algbw_GBps\":%.4f,\"busbw_GBps\":%.4f,\"check\":\"%s\"}\n",
-           n, bytes, a.dtype.c_str(), sec * 1e6, alg, bus, check);
-    fflush(stdout);
+    float ms = 0, ms_rank0 = 0;
+    for (int i = 0; i < n; ++i) {
+      HIPCHECK(hipSetDevice(i));
+      HIPCHECK(hipEventSynchronize(ev1[i]));
+      float m = 0;
+      HIPCHECK(hipEventElapsedTime(&m, ev0[i], ev1[i]));
+      if (i == 0) ms_rank0 = m;
+      ms = std::max(ms, m);
+    }
+    const Point p = make_point(bytes, n, a.iters, ms, ms_rank0);
+    if ((n > 1 ? p.bus : p.alg) > (n > 1 ? peak_bus : peak_alg)) peak_bytes = bytes;
+    peak_bus = std::max(peak_bus, p.bus);
+    peak_alg = std::max(peak_alg, p.alg);
+    print_point(a, n, bytes, p, check, a.check ? count * (size_t)n : (size_t)0, mismatched);
   }
-  printf("{\"type\":\"summary\",\"n_gpus\":%d,\"dtype\":\"%s\",\"peak_busbw_GBps\":%.4f,\"peak_algbw_GBps\":%.4f,"
-         "\"peak_bytes\":%zu,\"ceiling_mesh_GBps\":%.1f,\"ceiling_ring_GBps\":%.1f}\n",
-         n, a.dtype.c_str(), peak_bus, peak_alg, peak_bytes, n > 1 ? (n - 1) * 153.0 : 0.0, n > 1 ? 153.0 : 0.0);
-  fflush(stdout);
+  print_summary(a, n, peak_bus, peak_alg, peak_bytes);
 
   for (int i = 0; i < n; ++i) {
     HIPCHECK(hipSetDevice(i));
     HIPCHECK(hipFree(send[i]));
-    HIPCHECK(hipFree(recv[i]));
+    if (!a.in_place) HIPCHECK(hipFree(recv[i]));
+    HIPCHECK(hipFree(bad[i]));
+    HIPCHECK(hipEventDestroy(ev0[i]));
+    HIPCHECK(hipEventDestroy(ev1[i]));
     HIPCHECK(hipStreamDestroy(streams[i]));
     ncclCommDestroy(comms[i]);
   }

@@ -87,3 +87,78 @@ def test_sampler_json_writer_under_asan_ubsan_feeds_the_python_reader(built, tmp
     finally:
         src.close()
 
+
+
+@pytest.fixture(scope="module")
+def asan_bins(built):
+    """Host-side AddressSanitizer + UBSan builds of the two HIP executables (device code unsanitized: the GPU
+    sanitizers are not available on the MI355X pool). Cached under _native/bin-asan, rebuilt when a source changed."""
+    out = {}
+    for t in build.targets():
+        if t.kind == "hip-exe":
+            san = build.sanitized(t)
+            build.build_target(san, verbose=False)
+            out[t.name] = san.out
+    return out
+
+
+def _clean(r):
+    return all(s not in r.stderr for s in ("ERROR: AddressSanitizer", "runtime error", "LeakSanitizer"))
+
+
+def test_probe_and_burner_host_code_under_asan_ubsan(asan_bins):
+    probe, burner = str(asan_bins["klm_rccl_probe"]), str(asan_bins["klm_burner"])
+    for cmd, rc in (([probe, "--help"], 0), ([probe, "--bogus"], 1), ([probe, "--gpus"], 1), ([probe, "--gpus", "0"], 1),
+                    ([probe, "--dtype", 'x"y'], 1), ([probe, "--min", "1", "--dtype", "fp32"], 1), ([probe, "--factor", "1"], 1),
+                    ([probe, "--gpus", "99999999999999999999"], None),
+                    ([burner, "--help"], 0), ([burner, "--bogus"], 1), ([burner, "--kind"], 1), ([burner, "--kind", 'a"b\\'], 1),
+                    ([burner, "--size", "1000"], 1), ([burner, "--duty", "101"], 1), ([burner, "--hbm-gib", "-1"], 1),
+                    ([burner, "--device", "-3"], 1)):
+        r = run(cmd)
+        assert _clean(r), (cmd, r.stderr[-1500:])
+        if rc is not None:
+            assert r.returncode == rc, (cmd, r.returncode, r.stdout, r.stderr[-300:])
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                json.loads(line)                                  # errors stay valid JSON whatever the argument held
+    # without a GPU both stop at the first HIP call with a JSON error, cleanly
+    import torch
+    if not torch.cuda.is_available():
+        for cmd in ([probe, "--gpus", "1"], [burner, "--seconds", "1"]):
+            r = run(cmd)
+            assert r.returncode == 2 and _clean(r) and "error" in json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_probe_selftest_output_feeds_the_curve_builder(asan_bins):
+    from k8s_llm_monitor_amd.parallel import probe
+    r = run([str(asan_bins["klm_rccl_probe"]), "--selftest", "--max", str(1 << 28), "--factor", "4"])
+    assert r.returncode == 0 and _clean(r), r.stderr[-1500:]
+    parsed = probe.parse_probe_output(r.stdout)
+    h = parsed["header"]
+    assert h["in_place"] is True and h["n_gpus"] == 8 and h["device"] == 'AMD "Instinct" MI355X\\' and "max over ranks" in h["timing"]
+    sizes = [p["bytes"] for p in parsed["points"]]
+    assert sizes == probe.sweep_sizes(1024, 1 << 28, 4) and not parsed["errors"]
+    for p in parsed["points"]:
+        assert p["time_us"] == p["time_us_max_rank"] >= p["time_us_rank0"] > 0
+        assert p["elements_checked"] == p["bytes"] // 2 * 8 and p["elements_mismatched"] == 0 and p["check"] == "ok"
+        assert p["busbw_GBps"] == pytest.approx(p["algbw_GBps"] * 2 * 7 / 8, rel=1e-3)
+    c = probe.curve(8, parsed["points"], "bf16", verified=True, executor="native")
+    assert c["peak_bytes"] == 1 << 28 and 300 < c["peak_busbw_GBps"] < 400
+    # an odd max and a factor whose product would overflow size_t end the list at max without looping
+    r = run([str(asan_bins["klm_rccl_probe"]), "--selftest", "--min", "3", "--max", str((1 << 63) + 5), "--factor", "1000000"])
+    assert r.returncode == 0 and _clean(r), r.stderr[-1500:]
+    pts = probe.parse_probe_output(r.stdout)["points"]
+    assert [p["bytes"] for p in pts] == [2, 3000000 - 3000000 % 2, 3000000000000, 3000000000000000000, (1 << 63) + 4]
+
+
+def test_burner_selftest_planner_matches_the_python_planner(asan_bins):
+    from k8s_llm_monitor_amd.loadgen.burner import plan_window
+    r = run([str(asan_bins["klm_burner"]), "--selftest"])
+    assert r.returncode == 0 and _clean(r), r.stderr[-1500:]
+    lines = [json.loads(x) for x in r.stdout.splitlines()]
+    rows = lines[0]["rows"]
+    assert len(rows) == 28
+    for duty, kernel_s, n in rows:
+        assert n == plan_window(duty, lines[0]["period_s"], kernel_s), (duty, kernel_s, n)
+    assert lines[1]["tflops"] == pytest.approx(2 * 8192 ** 3 * 2700 / 1.97 / 1e12, rel=1e-4) and lines[2]["TBps"] == pytest.approx(3.006, abs=1e-3)
+    assert lines[3]["kind"] == 'gemm"bf16\\\n' and lines[3]["hbm_hold_gib"] == 3.0 and lines[3]["duty_achieved"] == 98.5

@@ -26,7 +26,13 @@
 //     everywhere before call e+2 reuses its slot. No trailing barrier is needed.
 //   * every spin is bounded (a limit in seconds of the 100 MHz wall clock): a missing peer sets a status
 //     word and the kernel ends with a wrong result instead of hanging the GPU. The epochs keep advancing, so
-//     the protocol is in step again as soon as the late rank arrives.
+//     the protocol is in step again as soon as the late rank arrives. While the status word is set (nobody has
+//     read and cleared it yet) later barriers wait for 1/16384 of the limit only: a dead peer costs one limit,
+//     not one per collective of a 126-layer step;
+//   * beside its epoch every rank publishes a TAG of the call (bytes and mode) in a third flag region, double
+//     buffered by epoch parity like the data; a rank that passes the first barrier compares its peers' tags with
+//     its own and sets status bit 2 on a difference: ranks whose schedulers have drifted apart (one launches
+//     [T, hidden] for another T, or a gather against a sum) are caught instead of summing stale slot bytes.
 // Sums run in rank order in fp32 on every rank, so all ranks hold bit-identical results.
 //
 // No reference counterpart (the reference has no GPU code).
@@ -88,27 +94,42 @@ struct Acc8 {
 
 // Barrier between block b of every rank. All of this block's earlier stores are made visible to the
 // system before the flags go out; all of its later loads see what the peers stored before theirs.
+constexpr int ST_TAG_MISMATCH = 4;     // status bits: 1 << stage (1, 2) = a peer did not arrive; 4 = a peer ran a different call
+
+// `tag` != 0: this is the call's first barrier; publish the tag with the flag and compare the peers' with it.
 template <int N>
-__device__ __forceinline__ void block_barrier(const Peers& p, int rank, int stage, uint32_t epoch, int* status, long long spin_limit) {
+__device__ __forceinline__ void block_barrier(const Peers& p, int rank, int stage, uint32_t epoch, int* status, long long spin_limit,
+                                              uint32_t tag = 0) {
   __threadfence_system();
   __syncthreads();
   const int t = threadIdx.x;
   if (t < N) {
     const int slot = (stage * MAXB + blockIdx.x) * MAXR;
+    const int tslot = ((2 + (epoch & 1)) * MAXB + blockIdx.x) * MAXR;
+    if (tag) __hip_atomic_store(p.sig[t] + tslot + rank, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // ordered by the release below
     __hip_atomic_store(p.sig[t] + slot + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t* mine = p.my_sig + slot + t;
+    // an earlier barrier already gave up and nobody has cleared the word: do not pay the whole limit again
+    const long long limit = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? (spin_limit >> 14) + 1 : spin_limit;
     const long long t0 = wall_clock64();
+    bool arrived = true;
     while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      if (wall_clock64() - t0 > spin_limit) {
+      if (wall_clock64() - t0 > limit) {
         __hip_atomic_fetch_or(status, 1 << stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = false;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
+    if (tag && arrived && __hip_atomic_load(p.my_sig + tslot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag)
+      __hip_atomic_fetch_or(status, ST_TAG_MISMATCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   __threadfence_system();
 }
+
+// what a call is, in one nonzero word: its size in 16-byte units and its mode
+__device__ __forceinline__ uint32_t call_tag(size_t n16, int mode) { return ((uint32_t)n16 << 2 | (uint32_t)mode) + 1u; }
 
 // n16: 16-byte units of the vector. Block b owns the units i with (i / NT) % gridDim.x == b.
 template <int N, int MODE>
@@ -119,7 +140,7 @@ __global__ __launch_bounds__(NT) void xgmi_one_shot(Peers p, int rank, const u32
   const size_t first = (size_t)blockIdx.x * NT + threadIdx.x, step = (size_t)gridDim.x * NT;
   u32x4* mine = reinterpret_cast<u32x4*>(p.my_data + off);
   for (size_t i = first; i < n16; i += step) mine[i] = x[i];
-  block_barrier<N>(p, rank, 0, epoch, status, spin_limit);
+  block_barrier<N>(p, rank, 0, epoch, status, spin_limit, call_tag(n16, MODE));
   for (size_t i = first; i < n16; i += step) {
     u32x4 v[N];
 #pragma unroll
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(NT) void xgmi_two_shot(Peers p, int rank, const u32
   u32x4* mine = reinterpret_cast<u32x4*>(p.my_data + off);
   for (int q = 0; q < N; ++q)
     for (size_t j = first; j < part16; j += step) mine[q * part16 + j] = x[q * part16 + j];
-  block_barrier<N>(p, rank, 0, epoch, status, spin_limit);
+  block_barrier<N>(p, rank, 0, epoch, status, spin_limit, call_tag(part16 * N, SUM_TWO_SHOT));
   u32x4* my_res = reinterpret_cast<u32x4*>(p.my_data + res);
   for (size_t j = first; j < part16; j += step) {
     u32x4 v[N];
@@ -199,7 +220,7 @@ int launch(const Peers& p, int rank, const void* x, void* out, size_t nbytes, in
 int klm_xgmi_limits(int* max_ranks, int* max_blocks, int* sig_bytes, int* counter_bytes) {
   *max_ranks = MAXR;
   *max_blocks = MAXB;
-  *sig_bytes = 2 * MAXB * MAXR * (int)sizeof(uint32_t);
+  *sig_bytes = 4 * MAXB * MAXR * (int)sizeof(uint32_t);      // two barrier stages + two tag regions (epoch parity)
   *counter_bytes = MAXB * (int)sizeof(uint32_t);
   return 0;
 }

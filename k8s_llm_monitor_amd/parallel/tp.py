@@ -33,6 +33,9 @@ class SingleGroup:
     def broadcast_object(self, obj: Any = None) -> Any:
         return obj
 
+    def gather_objects(self, obj: Any) -> List[Any]:
+        return [obj]
+
     def barrier(self) -> None:
         pass
 
@@ -54,7 +57,7 @@ class TPGroup:
     the default group is nccl), "gloo" (CPU)."""
 
     def __init__(self, device, data: str = "auto", xgmi_max_bytes: int = 4 << 20, slot_bytes: int = 16 << 20,
-                 blocks: int = 32, ctrl_timeout_s: float = 7 * 24 * 3600.0):
+                 blocks: int = 32, ctrl_timeout_s: float = 7 * 24 * 3600.0, spin_limit_s: float = 20.0):
         import datetime
 
         import torch
@@ -78,12 +81,26 @@ class TPGroup:
         self.self_test_error: Optional[str] = None
         if data.startswith("xgmi"):
             from . import xgmi
-            self.comm = xgmi.XgmiComm(self.rank, self.world, self.device, xgmi.gloo_exchange(self.ctrl),
-                                      slot_bytes=slot_bytes, blocks=blocks)
-            self.self_test_error = self._self_test()
+            try:
+                self.comm = xgmi.XgmiComm(self.rank, self.world, self.device, xgmi.gloo_exchange(self.ctrl),
+                                          slot_bytes=slot_bytes, blocks=blocks, spin_limit_s=spin_limit_s)
+                mine = None
+            except xgmi.XgmiError as e:          # e.g. cached memory across different GPUs
+                self.comm, mine = None, f"rank {self.rank}: {e}"
+            # construction can fail on some ranks only (an allocation, an IPC open): agree before anyone launches
+            made: List[Optional[str]] = [None] * self.world
+            dist.all_gather_object(made, mine, group=self.ctrl)
+            if any(made):
+                self.self_test_error = "; ".join(m for m in made if m)
+                if self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+            else:
+                self.self_test_error = self._self_test()
             if self.self_test_error:
                 # the same verdict on every rank (it is gathered), so every rank takes the same branch
-                self.comm.close()
+                if self.comm is not None:
+                    self.comm.close()
                 self.comm = None
                 if default_backend != "nccl":
                     raise RuntimeError(f"xGMI mesh collectives failed their self-test and there is no RCCL group to fall "
@@ -147,6 +164,12 @@ class TPGroup:
         box: List[Optional[Any]] = [obj if self.rank == 0 else None]
         self.dist.broadcast_object_list(box, src=0, group=self.ctrl)
         return box[0]
+
+    def gather_objects(self, obj: Any) -> List[Any]:
+        """Every rank's object on every rank, in rank order (CPU, gloo)."""
+        out: List[Any] = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.ctrl)
+        return out
 
     def barrier(self) -> None:
         self.dist.barrier(group=self.ctrl)

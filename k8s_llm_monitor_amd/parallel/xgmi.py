@@ -97,36 +97,69 @@ class XgmiComm:
         base, fine = ctypes.c_void_p(), ctypes.c_int()
         handle = ctypes.create_string_buffer(64)
         rc = self.L.klm_xgmi_alloc(self.nbytes, ctypes.byref(base), handle, ctypes.byref(fine))
+        # From here on every rank makes the SAME exchanges whatever happens to it locally: a rank that raised before an
+        # exchange would leave its peers waiting in it. Local trouble travels as `err` and everyone raises at the end.
+        err: Optional[str] = None
         if rc != 0:
-            raise XgmiError(f"klm_xgmi_alloc({self.nbytes}) failed ({rc}): is HSA_ENABLE_IPC_MODE_LEGACY=0 set?")
+            err = f"klm_xgmi_alloc({self.nbytes}) failed ({rc}): is HSA_ENABLE_IPC_MODE_LEGACY=0 set?"
         self.base, self.fine_grained = base.value, bool(fine.value)
         self._closed = False
-        # everyone publishes (handle, pid, geometry); a rank whose geometry differs would deadlock the protocol
-        mine = handle.raw + f"|{os.getpid()}|{self.slot_bytes}|{self.blocks}|{self.one_shot_max}".encode()
-        infos = exchange(mine)
-        if len(infos) != world:
-            raise XgmiError(f"exchange returned {len(infos)} entries for {world} ranks")
         self.peer_base: List[int] = []
         self._opened: List[int] = []
-        for r, info in enumerate(infos):
-            h, meta = info[:64], info[65:].decode().split("|")
-            if meta[1:] != [str(self.slot_bytes), str(self.blocks), str(self.one_shot_max)]:
-                raise XgmiError(f"rank {r} was created with a different geometry: {meta[1:]}")
-            if r == rank:
-                self.peer_base.append(self.base)
-                continue
-            p = ctypes.c_void_p()
-            rc = self.L.klm_xgmi_open(h, ctypes.byref(p))
-            if rc != 0:
-                raise XgmiError(f"hipIpcOpenMemHandle of rank {r}'s buffer failed ({rc})")
-            self.peer_base.append(p.value)
-            self._opened.append(p.value)
-        self._data = (ctypes.c_void_p * world)(*[b + self.SIG_PAD for b in self.peer_base])
-        self._sig_table = torch.tensor(self.peer_base, dtype=torch.int64, device=self.device)
-        self._counters = torch.zeros(lim["max_blocks"], dtype=torch.int32, device=self.device)
-        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        torch.cuda.synchronize(self.device)
-        exchange(b"ready")                       # nobody launches before every buffer is mapped and zeroed
+        # everyone publishes (handle, pid, geometry, device, memory kind); a rank whose geometry differs would deadlock the protocol
+        mine = handle.raw + f"|{os.getpid()}|{self.slot_bytes}|{self.blocks}|{self.one_shot_max}|{self._device_id()}|{int(self.fine_grained)}|{int(err is None)}".encode()
+        infos = exchange(mine)
+        if len(infos) != world:
+            err = err or f"exchange returned {len(infos)} entries for {world} ranks"
+            infos = []
+        metas = [info[65:].decode().split("|") for info in infos]
+        failed = [r for r, m in enumerate(metas) if m[-1] != "1"]
+        if failed and err is None:
+            err = f"rank(s) {failed} could not allocate their buffer"
+        # cached memory is only coherent between processes that share ONE GPU (the single-box tests); across devices
+        # the flag protocol needs the uncached allocation
+        self.distinct_devices = len({m[4] for m in metas}) > 1
+        coarse = [r for r, m in enumerate(metas) if m[5] == "0"]
+        if err is None and self.distinct_devices and coarse:
+            err = (f"rank(s) {coarse} got ordinary (cached) device memory instead of an uncached allocation and the ranks are "
+                   f"on different GPUs: the flag protocol is not coherent across devices on such memory")
+        if err is None:
+            for r, (info, meta) in enumerate(zip(infos, metas)):
+                if meta[1:4] != [str(self.slot_bytes), str(self.blocks), str(self.one_shot_max)]:
+                    err = f"rank {r} was created with a different geometry: {meta[1:4]}"
+                    break
+                if r == rank:
+                    self.peer_base.append(self.base)
+                    continue
+                p = ctypes.c_void_p()
+                rc = self.L.klm_xgmi_open(info[:64], ctypes.byref(p))
+                if rc != 0:
+                    err = f"hipIpcOpenMemHandle of rank {r}'s buffer failed ({rc})"
+                    break
+                self.peer_base.append(p.value)
+                self._opened.append(p.value)
+        if err is None:
+            self._data = (ctypes.c_void_p * world)(*[b + self.SIG_PAD for b in self.peer_base])
+            self._sig_table = torch.tensor(self.peer_base, dtype=torch.int64, device=self.device)
+            self._counters = torch.zeros(lim["max_blocks"], dtype=torch.int32, device=self.device)
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize(self.device)
+        # nobody launches before every buffer is mapped and zeroed -- and nobody at all if any rank failed
+        verdicts = exchange(b"ready" if err is None else b"failed: " + err.encode())
+        bad = [f"rank {r}: {v.decode()[8:]}" for r, v in enumerate(verdicts) if v != b"ready"]
+        if bad:
+            if self.base:
+                self.close()
+            self._closed = True
+            raise XgmiError("; ".join(bad))
+
+    def _device_id(self) -> str:
+        """Something that names the physical GPU across processes (each process may call it cuda:0)."""
+        try:
+            pr = self.torch.cuda.get_device_properties(self.device)
+            return str(getattr(pr, "uuid", None) or f"{pr.pci_domain_id}:{pr.pci_bus_id}:{pr.pci_device_id}")
+        except Exception:
+            return f"unknown-{self.device}"
 
     # ------------------------------------------------------------------ launches
     def _launch(self, x_ptr: int, out_ptr: int, nbytes: int, mode: int) -> None:
@@ -178,14 +211,20 @@ class XgmiComm:
         return out
 
     def status(self) -> int:
-        """0, or a bit per barrier stage that gave up waiting for a peer (synchronises the stream)."""
+        """0, or bits: 1, 2 = a barrier stage gave up waiting for a peer; 4 = a peer ran a call of another size or
+        mode at the same step (synchronises the stream)."""
         return int(self._status.item())
 
     def check(self) -> None:
         st = self.status()
         if st:
             self._status.zero_()           # reported once: the protocol itself is in step again when the peer arrives
-            raise XgmiError(f"a peer did not reach barrier stage(s) {st:#x} within the spin limit: results since then are invalid")
+            what = []
+            if st & 3:
+                what.append(f"a peer did not reach barrier stage(s) {st & 3:#x} within the spin limit")
+            if st & 4:
+                what.append("a peer launched a collective of a different size or mode (the ranks' schedules differ)")
+            raise XgmiError("; ".join(what) + ": results since then are invalid")
 
     def close(self) -> None:
         if self._closed:
@@ -198,4 +237,5 @@ class XgmiComm:
 
     def describe(self) -> dict:
         return {"rank": self.rank, "world": self.world, "slot_bytes": self.slot_bytes, "blocks": self.blocks,
-                "one_shot_max": self.one_shot_max, "fine_grained": self.fine_grained}
+                "one_shot_max": self.one_shot_max, "fine_grained": self.fine_grained,
+                "distinct_devices": getattr(self, "distinct_devices", None)}

@@ -135,7 +135,8 @@ class Engine:
         self.tp = self.model.tp
         self.lcfg: LlamaConfig = self.model.lcfg          # this rank's shapes (== mcfg without tensor parallelism)
         self._inbox: List[Request] = []                   # tensor parallel: submitted at rank 0, not yet seen by the others
-        self._tp_reset = False                            # rank 0: tell the other ranks to drop their requests (after a failure)
+        self._tp_reset = False                            # this rank failed a step: the next control exchange makes every rank start clean
+        self.tp_resets = 0
         if self.cfg.decode_weights == "fp8" and not self.model.fp8_decode:
             self.model.enable_fp8_decode()
         elif self.cfg.decode_weights not in ("bf16", "fp8"):
@@ -146,6 +147,13 @@ class Engine:
             raise ValueError(f"kv_cache_dtype must be bf16 or fp8, not {self.cfg.kv_cache_dtype!r}")
         self.kv_dtype = torch.float8_e4m3fn if self.cfg.kv_cache_dtype == "fp8" else None
         nblocks = self.cfg.kv_blocks or self._auto_blocks()
+        if self.tp.world > 1:
+            # lock-step scheduling needs the SAME block count everywhere: free HBM differs per rank (ranks sharing a GPU see
+            # what earlier ranks left; a config file may differ), and one rank admitting or preempting alone desynchronises
+            # the collectives. Everyone takes the smallest.
+            counts = self.tp.gather_objects(int(nblocks))
+            self.kv_blocks_per_rank = counts
+            nblocks = min(counts)
         self.cache: KVCache = self.model.new_cache(nblocks, self.kv_dtype)
         self.alloc = BlockAllocator(nblocks)
         self.metrics = EngineMetrics(mcfg.name, clock=clock)
@@ -238,24 +246,37 @@ class Engine:
         Returns True when the engine is to stop."""
         if self.tp.world == 1:
             return stop
+        # One all-gather per step: rank 0's control message, and from EVERY rank whether its last step failed and a
+        # digest of its scheduler state. Scheduling is a deterministic function of that state, so equal digests mean
+        # equal launches; a rank that failed (out of memory, a bad launch, its own tp.check()) or drifted is seen by
+        # all ranks here, BEFORE the next collective is launched, and all of them start clean together.
+        with self._lock:
+            digest = (len(self.waiting), tuple(r.rid for r in self.prefilling), tuple((r.rid, len(r.out)) for r in self.running),
+                      self.alloc.free, self.alloc.total)
+        failed, self._tp_reset = self._tp_reset, False
+        ctl = None
         if self.tp.rank == 0:
             with self._lock:
                 new, self._inbox = self._inbox, []
-            reset, self._tp_reset = self._tp_reset, False
-            msg = self.tp.broadcast_object((bool(stop), reset, [(r.rid, r.prompt, r.max_tokens) for r in new]))
-            with self._lock:
-                self.waiting.extend(new)
-            return msg[0]
-        stop, reset, new = self.tp.broadcast_object(None)
-        if reset:
-            # rank 0 failed a step (or saw a peer miss a collective) and dropped its requests: drop ours too, or the
-            # ranks would schedule different batches from here on
-            self._fail_all("reset by rank 0")
+            ctl = (bool(stop), [(r.rid, r.prompt, r.max_tokens) for r in new])
+        msgs = self.tp.gather_objects((failed, digest, ctl))
+        stop_all, new_specs = msgs[0][2]
+        bad = [i for i, m in enumerate(msgs) if m[0]]
+        drift = [i for i, m in enumerate(msgs) if m[1] != msgs[0][1]]
+        if bad or drift:
+            why = (f"rank(s) {bad} failed a step" if bad else f"rank(s) {drift} scheduled differently from rank 0")
+            self.tp_resets += 1
+            self.last_error = self.last_error or why
+            self._fail_all("tensor-parallel reset: " + why)
         now = self.clock()
         with self._lock:
-            for rid, prompt, max_tokens in new:
-                self.waiting.append(Request(rid, list(prompt), int(max_tokens), now))
-        return bool(stop)
+            # requests that arrived with this message were not part of the failed step: every rank takes them, reset or not
+            if self.tp.rank == 0:
+                self.waiting.extend(new)
+            else:
+                for rid, prompt, max_tokens in new_specs:
+                    self.waiting.append(Request(rid, list(prompt), int(max_tokens), now))
+        return bool(stop_all)
 
     def step_all(self) -> int:
         """`step()` for callers that drive a tensor-parallel engine by hand: every rank calls it the same
@@ -531,7 +552,7 @@ class Engine:
                 self.last_error = f"{type(e).__name__}: {e}"
                 self.errors += 1
                 self._fail_all(self.last_error)
-                self._tp_reset = True   # tensor parallel: the next control message tells every rank to start clean
+                self._tp_reset = True   # tensor parallel: the next control exchange tells every rank (from ANY rank) to start clean
                 n = 0
             if n == 0 and self.tp.world == 1:
                 self._wake.wait(0.05)

@@ -52,6 +52,12 @@ def test_xgmi_collectives_between_processes(world):
         assert all(r["sizes"].values()), r["sizes"]                  # bit-exact against the fp32 rank-order sum
         assert r["modes"]["4096"] == [0] and r["modes"]["1048576"] == [1], r["modes"]      # one shot / two shot
         assert r["repeat_mismatches"] == 0 and r["gather_ok"] and r["graph_ok"] and r["status"] == 0, r
+        # a call of another size on one rank is seen by every rank, and costs nothing afterwards
+        assert r["mismatch_status"] & 4 and "different size or mode" in r["mismatch_error"] and r["after_mismatch_ok"], r
+        if r["rank"] != 0:
+            # three calls against an absent peer: one spin limit (1.5 s) plus two short ones, not three limits
+            assert r["absent_peer_status"] & 1 and "did not reach" in r["absent_peer_error"] and 1.4 < r["absent_peer_seconds"] < 2.6, r
+        assert r["after_absent_peer_ok"], r
     print("xgmi collectives:", {k: res[0][k] for k in ("describe", "us_32KiB", "us_2MiB")})
 
 
@@ -70,6 +76,19 @@ def test_tensor_parallel_model_and_engine_two_ranks_on_one_gpu():
     assert r0["engine_done"] and r0["engine_tokens"] == 24 and r0["graph_equals_eager"], r0
     print("tp2 on one GPU:", {k: r0[k] for k in ("model_max_abs_err", "model_logit_scale", "engine_tokens_match",
                                                  "engine_first_tokens_match", "engine_counts", "graphs")})
+
+
+@pytest.mark.timeout(300)
+def test_a_launch_that_fails_on_one_rank_only_resets_every_rank():
+    """Rank 1's prefill raises, rank 0's does not: rank 0's mesh collectives give up after the spin limit, its step fails
+    its check, the control exchange resets both ranks, and the next request is served with the right tokens."""
+    res = run_ranks("tp_worker.py", 2, ["--gpu", "--model", "small", "--what", "follower", "--spin-limit", "2.0"], timeout=280)
+    r0 = [r for r in res if r["rank"] == 0][0]
+    r1 = [r for r in res if r["rank"] == 1][0]
+    assert r0["follower_failed_request_error"] and r0["follower_recovered"], r0
+    assert r0["follower_resets"] >= 1 and r1["follower_resets"] >= 1 and r1["follower_errors"] == 1, (r0, r1)
+    assert r0["follower_seconds_to_fail"] < 30.0, r0              # one spin limit, not one per collective of the step
+    print("follower-only failure:", {k: r0[k] for k in ("follower_failed_request_error", "follower_seconds_to_fail", "follower_resets")})
 
 
 @pytest.mark.timeout(400)

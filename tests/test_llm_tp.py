@@ -75,6 +75,70 @@ def test_two_rank_model_and_engine_match_the_unsharded_model():
 
 
 @pytest.mark.timeout(300)
+def test_ranks_with_unequal_kv_space_agree_on_the_smallest_and_stay_in_step():
+    res = run_ranks(2, args=("--what", "unequal"))
+    for r in res:
+        assert r["unequal_counts"] == [40, 28] and r["unequal_blocks_total"] == 28, r
+        assert r["unequal_steps"] == res[0]["unequal_steps"] and r["unequal_step_counts"] == res[0]["unequal_step_counts"]
+        assert r["unequal_resets"] == 0 and r["unequal_preemptions"] == res[0]["unequal_preemptions"]
+    r0 = [r for r in res if r["rank"] == 0][0]
+    assert r0["unequal_tokens_match"] and r0["unequal_done"], r0
+
+
+class _ScriptedGroup:
+    """Stands in for a TPGroup in `_tp_sync`: this rank's message goes in, the scripted messages of all ranks come out."""
+
+    def __init__(self, rank, script):
+        self.rank, self.world, self.script, self.sent = rank, 2, script, []
+
+    def gather_objects(self, obj):
+        self.sent.append(obj)
+        return self.script(obj)
+
+
+def _tiny_engine():
+    import torch
+    from k8s_llm_monitor_amd.serving.engine import Engine, EngineConfig
+    return Engine(EngineConfig(model="tiny", device="cpu", max_num_seqs=4, max_model_len=128, kv_blocks=16, use_graphs=False))
+
+
+def test_tp_sync_resets_every_rank_when_any_rank_failed_or_drifted():
+    from k8s_llm_monitor_amd.serving.engine import Request
+    # a follower: rank 0 reports two new requests, nobody failed
+    e = _tiny_engine()
+    e.tp = _ScriptedGroup(1, lambda mine: [(False, mine[1], (False, [(0, [1, 2, 3], 4), (1, [4, 5], 2)])), mine])
+    assert e._tp_sync() is False and [r.rid for r in e.waiting] == [0, 1] and e.tp_resets == 0
+    assert e.tp.sent[0][0] is False and e.tp.sent[0][2] is None                  # followers send no control part
+    # the follower failed its last step: it says so, and drops what it holds like everyone else
+    e._tp_reset = True
+    e.tp = _ScriptedGroup(1, lambda mine: [(False, mine[1], (False, [(2, [7], 1)])), mine])
+    e._tp_sync()
+    assert e.tp.sent[0][0] is True and [r.rid for r in e.waiting] == [2] and e.tp_resets == 1 and e._tp_reset is False
+    # rank 0 hears that rank 1 failed: its requests in flight and the just-submitted one all end with an error
+    e0 = _tiny_engine()
+    e0.tp = _ScriptedGroup(0, lambda mine: [mine, (True, mine[1], None)])
+    held = Request(5, [1, 2, 3], 4, 0.0)
+    e0.waiting.append(held)
+    fresh = Request(6, [9], 2, 0.0)
+    e0._inbox.append(fresh)
+    e0._tp_sync()
+    assert held.done.is_set() and "rank(s) [1] failed" in held.error
+    # ... while a request that arrived with this very message was no part of the failed step and is kept, on every rank
+    assert not fresh.done.is_set() and list(e0.waiting) == [fresh] and not e0._inbox and e0.tp_resets == 1
+    # equal failure flags but a different scheduler state on rank 1 (one more block free): also a reset, before any launch
+    e0 = _tiny_engine()
+    e0.tp = _ScriptedGroup(0, lambda mine: [mine, (False, mine[1][:3] + (mine[1][3] + 1,) + mine[1][4:], None)])
+    held = Request(7, [1, 2, 3], 4, 0.0)
+    e0.waiting.append(held)
+    e0._tp_sync()
+    assert "scheduled differently" in held.error and e0.tp_resets == 1
+    # the stop wish travels in rank 0's control part
+    e = _tiny_engine()
+    e.tp = _ScriptedGroup(1, lambda mine: [(False, mine[1], (True, [])), mine])
+    assert e._tp_sync() is True
+
+
+@pytest.mark.timeout(300)
 def test_serve_llm_tp_cli_two_cpu_ranks():
     """`serve-llm --tp 2` end to end on CPU: the launcher starts both ranks, rank 0 answers HTTP, a completion runs
     through both shards, SIGTERM at the launcher ends rank 0 and, through the control channel, rank 1."""

@@ -118,11 +118,84 @@ def engine_check(cfg, dev, dtype, tp, out, use_graphs):
     eng.model.prefill = real_prefill
 
 
+def unequal_check(cfg, dev, dtype, tp, out):
+    """Ranks that would size their KV cache differently (their own free memory, their own config) agree on the
+    smallest count at construction and then schedule identically."""
+    full = LlamaModel(cfg, dev, seed=5, dtype=dtype)
+    part = LlamaModel(cfg, dev, seed=0, dtype=dtype, tp=tp).load_shard_from(full)
+    ecfg = EngineConfig(model=cfg.name, device=str(dev), max_num_seqs=8, max_model_len=256, max_num_batched_tokens=96,
+                        kv_blocks=40 - 12 * tp.rank, use_graphs=False)          # rank 0: 40 blocks, rank 1: 28
+    eng = Engine(ecfg, model=part)
+    gen = torch.Generator().manual_seed(29)
+    # 4 x (100 + 24) tokens = 32 blocks: more than 28, so the engine with the agreed count must preempt or queue --
+    # identically on both ranks -- where a 40-block rank alone would not
+    prompts = [torch.randint(0, cfg.vocab, (100,), generator=gen).tolist() for _ in range(4)]
+    reqs = [eng.submit(p, 24) for p in prompts] if tp.rank == 0 else []
+    eng.step_all()
+    steps = 1
+    while not eng.idle() and steps < 2000:
+        eng.step_all()
+        steps += 1
+    out.update(unequal_blocks_total=eng.alloc.total, unequal_counts=list(eng.kv_blocks_per_rank), unequal_steps=steps,
+               unequal_step_counts=dict(eng.step_counts), unequal_resets=eng.tp_resets,
+               unequal_preemptions=eng.metrics.truth()["totals"]["preemptions"])
+    if tp.rank == 0:
+        ref = Engine(EngineConfig(model=cfg.name, device=str(dev), max_num_seqs=8, max_model_len=256, max_num_batched_tokens=96,
+                                  kv_blocks=28, use_graphs=False), model=full)
+        rr = [ref.submit(p, 24) for p in prompts]
+        while not ref.idle():
+            ref.step()
+        out.update(unequal_tokens_match=[r.out for r in reqs] == [r.out for r in rr],
+                   unequal_done=all(r.done.is_set() and not r.error for r in reqs))
+
+
+def follower_failure_check(cfg, dev, dtype, tp, out):
+    """GPU + mesh kernels only: a launch fails on rank 1 ALONE. Rank 0's collectives give up after the spin limit (once:
+    later barriers of the step wait for a fraction of it), its tp.check() fails the step, and the next control exchange
+    resets every rank; the request after that is served correctly."""
+    import time
+    full = LlamaModel(cfg, dev, seed=5, dtype=dtype)
+    part = LlamaModel(cfg, dev, seed=0, dtype=dtype, tp=tp).load_shard_from(full)
+    ecfg = EngineConfig(model=cfg.name, device=str(dev), max_num_seqs=8, max_model_len=256, max_num_batched_tokens=96,
+                        kv_blocks=64, use_graphs=False)
+    eng = Engine(ecfg, model=part)
+    gen = torch.Generator().manual_seed(31)
+    prompts = [torch.randint(0, cfg.vocab, (n,), generator=gen).tolist() for n in (33, 50)]
+    real_prefill, state = eng.model.prefill, {"failed": False}
+
+    def failing_once(*a, **kw):
+        if tp.rank == 1 and not state["failed"]:
+            state["failed"] = True
+            raise RuntimeError("injected failure on rank 1 only")
+        return real_prefill(*a, **kw)
+    eng.model.prefill = failing_once
+    if tp.rank == 0:
+        ref = Engine(ecfg, model=full)
+        rr = ref.submit(prompts[1], 5)
+        while not ref.idle():
+            ref.step()
+        t0 = time.monotonic()
+        eng.start()
+        bad = eng.submit(prompts[0], 3)
+        bad.done.wait(120)
+        t_fail = time.monotonic() - t0
+        good = eng.submit(prompts[1], 5)
+        ok = good.done.wait(120)
+        eng.stop()
+        out.update(follower_failed_request_error=bad.error, follower_recovered=bool(ok) and good.out == rr.out and not good.error,
+                   follower_seconds_to_fail=t_fail, follower_resets=eng.tp_resets, follower_errors=eng.errors)
+    else:
+        eng.follow()
+        out.update(follower_resets=eng.tp_resets, follower_errors=eng.errors)
+    eng.model.prefill = real_prefill
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--model", default="tiny")
     ap.add_argument("--what", default="model,engine")
+    ap.add_argument("--spin-limit", type=float, default=20.0)
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -131,7 +204,7 @@ def main() -> int:
         torch.cuda.set_device(dev)
     else:
         dev, dtype = torch.device("cpu"), torch.float32
-    tp = TPGroup(dev, data="xgmi" if a.gpu else "gloo", slot_bytes=8 << 20)
+    tp = TPGroup(dev, data="xgmi" if a.gpu else "gloo", slot_bytes=8 << 20, spin_limit_s=a.spin_limit)
     out = {"rank": rank, "tp": tp.describe()}
     cfg = PRESETS[a.model]
     with torch.no_grad():
@@ -139,6 +212,10 @@ def main() -> int:
             model_check(cfg, dev, dtype, tp, out)
         if "engine" in a.what:
             engine_check(cfg, dev, dtype, tp, out, use_graphs=a.gpu)
+        if "unequal" in a.what:
+            unequal_check(cfg, dev, dtype, tp, out)
+        if "follower" in a.what:
+            follower_failure_check(cfg, dev, dtype, tp, out)
     tp.barrier()
     tp.close()
     print("RESULT " + json.dumps(out), flush=True)

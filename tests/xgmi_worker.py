@@ -21,7 +21,7 @@ def main() -> int:
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    comm = xgmi.XgmiComm(rank, world, dev, xgmi.gloo_exchange(), slot_bytes=8 << 20, blocks=32)
+    comm = xgmi.XgmiComm(rank, world, dev, xgmi.gloo_exchange(), slot_bytes=8 << 20, blocks=32, spin_limit_s=1.5)
     out = {"rank": rank, "describe": comm.describe(), "sizes": {}, "modes": {}}
 
     def expected(n):
@@ -91,6 +91,49 @@ def main() -> int:
     out["us_32KiB"] = round(timed(16384, 200) * 1e6, 2)
     out["us_2MiB"] = round(timed(1 << 20, 50) * 1e6, 2)
     out["status"] = comm.status()
+
+    # ranks whose schedules differ: rank 0 sums 4096 elements where the others sum 8192. Every rank sees a peer's tag
+    # differ from its own (status bit 4) instead of quietly summing stale slot bytes; the next matching call is clean.
+    dist.barrier()
+    y = make(rank, 4096 if rank == 0 else 8192, dev)
+    comm.all_reduce(y)
+    out["mismatch_status"] = comm.status()
+    try:
+        comm.check()
+        out["mismatch_error"] = None
+    except xgmi.XgmiError as e:
+        out["mismatch_error"] = str(e)
+    dist.barrier()
+    y = make(rank, 4096, dev)
+    comm.all_reduce(y)
+    out["after_mismatch_ok"] = bool(torch.equal(y, expected(4096))) and comm.status() == 0
+
+    # a peer that never launches: ranks != 0 make three calls rank 0 does not make. The first gives up after the spin
+    # limit, the next two after a fraction of it (the status word is still set); rank 0 then makes its three calls
+    # (they pass at once: its peers' flags are already there) and the protocol is in step again.
+    dist.barrier()
+    t0 = time.perf_counter()
+    if rank != 0:
+        for _ in range(3):
+            comm.all_reduce(make(rank, 4096, dev))
+        torch.cuda.synchronize()
+        out["absent_peer_seconds"] = round(time.perf_counter() - t0, 3)
+        out["absent_peer_status"] = comm.status()
+        try:
+            comm.check()
+            out["absent_peer_error"] = None
+        except xgmi.XgmiError as e:
+            out["absent_peer_error"] = str(e)
+    dist.barrier()
+    if rank == 0:
+        for _ in range(3):
+            comm.all_reduce(make(rank, 4096, dev))
+        torch.cuda.synchronize()
+        comm._status.zero_()
+    dist.barrier()
+    y = make(rank, 65536, dev)
+    comm.all_reduce(y)
+    out["after_absent_peer_ok"] = bool(torch.equal(y, expected(65536))) and comm.status() == 0
     dist.barrier()
     comm.close()
     print("RESULT " + json.dumps(out), flush=True)

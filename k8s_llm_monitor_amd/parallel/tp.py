@@ -42,6 +42,9 @@ class SingleGroup:
     def check(self) -> None:
         pass
 
+    def resync(self) -> None:
+        pass
+
     def close(self) -> None:
         pass
 
@@ -177,6 +180,13 @@ class TPGroup:
     def check(self) -> None:
         if self.comm is not None:
             self.comm.check()
+
+    def resync(self) -> None:
+        """Collective: bring the mesh collectives' epochs back in step after a step that not every rank completed."""
+        if self.comm is not None:
+            self.comm.resync()
+        else:
+            self.barrier()
 
     def close(self) -> None:
         if self.comm is not None:

@@ -87,6 +87,7 @@ class XgmiComm:
         if not 1 <= blocks <= lim["max_blocks"] or slot_bytes % (32 * world) or lim["sig_bytes"] > self.SIG_PAD:
             raise ValueError("blocks or slot_bytes out of range")
         self.torch, self.L = torch, load_lib()
+        self._exchange = exchange
         self.spin_limit_s = float(spin_limit_s)        # how long a kernel waits for a peer before it gives up (status != 0)
         self.rank, self.world, self.device = rank, world, torch.device(device)
         self.slot_bytes, self.blocks, self.one_shot_max = int(slot_bytes), int(blocks), int(one_shot_max)
@@ -225,6 +226,22 @@ class XgmiComm:
             if st & 4:
                 what.append("a peer launched a collective of a different size or mode (the ranks' schedules differ)")
             raise XgmiError("; ".join(what) + ": results since then are invalid")
+
+    def resync(self) -> None:
+        """Collective (every rank, through the exchange the communicator was built with): after a step in which some rank
+        launched collectives its peers never launched, the ranks' epoch counters differ for good -- the rank that is behind
+        would sail through every barrier on stale flags while the one ahead waits out the limit each time. All ranks drain
+        their streams, take the largest epoch any of them reached, and start from there with a clear status word."""
+        if self._closed:
+            raise XgmiError("communicator is closed")
+        torch = self.torch
+        torch.cuda.synchronize(self.device)
+        mine = int(self._counters.max().item())
+        every = [int(v.decode()) for v in self._exchange(str(mine).encode())]
+        self._counters.fill_(max(every))
+        self._status.zero_()
+        torch.cuda.synchronize(self.device)
+        self._exchange(b"resynced")              # nobody launches before every rank's counters are set
 
     def close(self) -> None:
         if self._closed:

@@ -268,6 +268,9 @@ class Engine:
             self.tp_resets += 1
             self.last_error = self.last_error or why
             self._fail_all("tensor-parallel reset: " + why)
+            if self.on_gpu:
+                torch.cuda.synchronize(self.device)
+            self.tp.resync()                    # the ranks launched different numbers of collectives in the failed step
         now = self.clock()
         with self._lock:
             # requests that arrived with this message were not part of the failed step: every rank takes them, reset or not

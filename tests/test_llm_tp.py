@@ -95,6 +95,9 @@ class _ScriptedGroup:
         self.sent.append(obj)
         return self.script(obj)
 
+    def resync(self):
+        self.resyncs = getattr(self, "resyncs", 0) + 1
+
 
 def _tiny_engine():
     import torch
@@ -131,7 +134,7 @@ def test_tp_sync_resets_every_rank_when_any_rank_failed_or_drifted():
     held = Request(7, [1, 2, 3], 4, 0.0)
     e0.waiting.append(held)
     e0._tp_sync()
-    assert "scheduled differently" in held.error and e0.tp_resets == 1
+    assert "scheduled differently" in held.error and e0.tp_resets == 1 and e0.tp.resyncs == 1
     # the stop wish travels in rank 0's control part
     e = _tiny_engine()
     e.tp = _ScriptedGroup(1, lambda mine: [(False, mine[1], (True, [])), mine])

@@ -109,8 +109,8 @@ def main() -> int:
     out["after_mismatch_ok"] = bool(torch.equal(y, expected(4096))) and comm.status() == 0
 
     # a peer that never launches: ranks != 0 make three calls rank 0 does not make. The first gives up after the spin
-    # limit, the next two after a fraction of it (the status word is still set); rank 0 then makes its three calls
-    # (they pass at once: its peers' flags are already there) and the protocol is in step again.
+    # limit, the next two after a fraction of it (the status word is still set); resync() then puts every rank on the
+    # same epoch again and the next call is exact.
     dist.barrier()
     t0 = time.perf_counter()
     if rank != 0:
@@ -125,12 +125,7 @@ def main() -> int:
         except xgmi.XgmiError as e:
             out["absent_peer_error"] = str(e)
     dist.barrier()
-    if rank == 0:
-        for _ in range(3):
-            comm.all_reduce(make(rank, 4096, dev))
-        torch.cuda.synchronize()
-        comm._status.zero_()
-    dist.barrier()
+    comm.resync()                               # rank 0 is three epochs behind: everyone moves to the largest
     y = make(rank, 65536, dev)
     comm.all_reduce(y)
     out["after_absent_peer_ok"] = bool(torch.equal(y, expected(65536))) and comm.status() == 0

@@ -296,7 +296,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     p = sub.add_parser("serve-llm")
     p.add_argument("--model", default="llama3-8b", help="llama3-8b, llama3-70b, llama3-405b (needs --tp), mistral-7b, wide, small, tiny")
     p.add_argument("--device", default="cuda")
-    p.add_argument("--host", default="0.0.0.0")
+    p.add_argument("--host", default="127.0.0.1", help="bind address (0.0.0.0 to serve other hosts: the API is unauthenticated)")
     p.add_argument("--port", type=int, default=8000)
     p.add_argument("--max-num-seqs", type=int, default=256)
     p.add_argument("--max-model-len", type=int, default=4096)

@@ -85,7 +85,13 @@ class Router:
                 if self.path.split("?")[0] != "/v1/completions":
                     self._send(404, b'{"error": "not found"}')
                     return
-                n = int(self.headers.get("Content-Length") or 0)
+                try:
+                    n = int(self.headers.get("Content-Length") or 0)
+                except ValueError:
+                    n = -1
+                if n < 0 or n > (8 << 20):                   # the same bound the replicas apply
+                    self._send(400, b'{"error": "bad or oversized Content-Length"}')
+                    return
                 body = self.rfile.read(n) if n else b"{}"
                 code, out = outer.dispatch(body)
                 self._send(code, out)
@@ -120,6 +126,8 @@ class Router:
                                              headers={"Content-Type": "application/json"})
                 with urllib.request.urlopen(req, timeout=self.timeout) as r:
                     out = json.loads(r.read())
+                if not isinstance(out, dict):
+                    raise ValueError("replica answered with something that is not a JSON object")
                 out["replica"] = i
                 return 200, json.dumps(out).encode()
             except urllib.error.HTTPError as e:
@@ -128,7 +136,7 @@ class Router:
                 with self._lock:                         # 503: the replica is stopping or failed the launch: try another
                     self.failed[i] += 1
                 tried.append(i)
-            except (urllib.error.URLError, OSError):
+            except (urllib.error.URLError, OSError, ValueError):     # unreachable, or a body that is not JSON: a replica failure
                 with self._lock:
                     self.failed[i] += 1
                 tried.append(i)

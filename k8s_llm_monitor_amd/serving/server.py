@@ -73,7 +73,11 @@ class LlmServer:
                     n = int(self.headers.get("Content-Length") or 0)
                     if n > (8 << 20):
                         raise ValueError("body too large")
+                    if n < 0:
+                        raise ValueError("bad Content-Length")
                     req = json.loads(self.rfile.read(n) or b"{}")
+                    if not isinstance(req, dict):
+                        raise ValueError("the body must be a JSON object")
                     prompt = req.get("prompt")
                     if isinstance(prompt, list) and prompt and all(isinstance(t, int) for t in prompt):
                         ids = prompt
@@ -81,9 +85,15 @@ class LlmServer:
                         plen = int(req.get("prompt_len") or 0)
                         if plen < 1:
                             raise ValueError("give `prompt` (token ids) or `prompt_len`")
+                        if plen + 1 > outer.engine.max_len:      # before any ids are made: a huge number must cost nothing
+                            raise ValueError(f"prompt_len {plen} does not fit max_model_len {outer.engine.max_len}")
                         rng = random.Random(req.get("seed"))
                         ids = [rng.randrange(outer.engine.mcfg.vocab) for _ in range(plen)]
+                    if len(ids) + 1 > outer.engine.max_len:
+                        raise ValueError(f"prompt of {len(ids)} tokens does not fit max_model_len {outer.engine.max_len}")
                     max_tokens = int(req.get("max_tokens") or 16)
+                    if not 1 <= max_tokens <= outer.engine.max_len:
+                        raise ValueError(f"max_tokens must be within 1..{outer.engine.max_len}")
                 except (ValueError, TypeError, json.JSONDecodeError) as e:
                     self._json(400, {"error": str(e)})
                     return

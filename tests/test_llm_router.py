@@ -56,6 +56,23 @@ def test_router_spreads_requests_and_merges_metrics():
             with pytest.raises(urllib.error.HTTPError) as e:                      # a replica's 400 is passed through
                 _post(router.url, {"max_tokens": 2})
             assert e.value.code == 400
+            # sizes are judged before anything is built from them: a prompt_len of a billion costs nothing
+            import time as _t
+            t0 = _t.monotonic()
+            for bad in ({"prompt_len": 10 ** 9}, {"prompt_len": 5, "max_tokens": -3}, {"prompt_len": 5, "max_tokens": 10 ** 9},
+                        {"prompt": list(range(500)), "max_tokens": 2}, [1, 2, 3]):
+                with pytest.raises(urllib.error.HTTPError) as e:
+                    _post(servers[1].url, bad)
+                assert e.value.code == 400, bad
+            assert _t.monotonic() - t0 < 2.0
+            # the router bounds the body like the replicas do
+            import http.client
+            c = http.client.HTTPConnection(router.host, router.port, timeout=5)
+            c.putrequest("POST", "/v1/completions")
+            c.putheader("Content-Length", str(1 << 30))
+            c.endheaders()
+            assert c.getresponse().status == 400
+            c.close()
             # one replica dies: requests keep being answered by the other
             servers[0].stop()
             engines[0].stop()
@@ -66,6 +83,34 @@ def test_router_spreads_requests_and_merges_metrics():
             s.stop()
         for e in engines:
             e.stop()
+
+
+def test_router_counts_a_replica_that_answers_garbage_as_failed():
+    import http.server
+    import threading
+
+    class Garbage(http.server.BaseHTTPRequestHandler):
+        def do_POST(self):
+            self.rfile.read(int(self.headers.get("Content-Length") or 0))
+            body = b"<html>not json</html>"
+            self.send_response(200)
+            self.send_header("Content-Length", str(len(body)))
+            self.end_headers()
+            self.wfile.write(body)
+
+        def log_message(self, *a):
+            pass
+
+    srv = http.server.ThreadingHTTPServer(("127.0.0.1", 0), Garbage)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    try:
+        with Router([f"http://127.0.0.1:{srv.server_address[1]}"]) as router:
+            with pytest.raises(urllib.error.HTTPError) as e:
+                _post(router.url, {"prompt": [1, 2], "max_tokens": 2})
+            assert e.value.code == 503 and router.failed == [1] and router.outstanding == [0]
+    finally:
+        srv.shutdown()
+        srv.server_close()
 
 
 def _free_port_block(n):

@@ -28,6 +28,7 @@
 // query heads, so a 16-row tile is 16/G tokens x G heads and K/V are read once per group.
 // Decode (one token per sequence) uses G of the 16 rows; the kernel is HBM-bound and the
 // MFMA time is noise (16 MFMAs per 16 KiB of cache read).
+#include "klm_launch.h"
 #include "llm_common.h"
 
 using namespace klm_llm;
@@ -749,13 +750,7 @@ int klm_paged_attn_prefill(const void* q, const void* k_cache, const void* v_cac
   } while (0)
 #define KLM_PREFILL_LDS(QT)                                                                                        \
   do {                                                                                                           \
-    static bool attr_done = false;                                                                               \
-    if (!attr_done) {                                                                                            \
-      if (hipFuncSetAttribute((const void*)paged_attn_prefill_lds_kernel<QT>,                                    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, PF_STAGES * PF_STAGE_BYTES) != hipSuccess) \
-        return KLM_ERR_HIP;                                                                                      \
-      attr_done = true;                                                                                          \
-    }                                                                                                            \
+    if (klm_ensure_dyn_lds<paged_attn_prefill_lds_kernel<QT>>(PF_STAGES * PF_STAGE_BYTES) != KLM_OK) return KLM_ERR_HIP;     \
     hipLaunchKernelGGL((paged_attn_prefill_lds_kernel<QT>), dim3(n_kv, n_tiles), dim3(256),                      \
                        PF_STAGES * PF_STAGE_BYTES, static_cast<hipStream_t>(stream), (const uint16_t*)q,         \
                        (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, seq_info, tiles,        \

@@ -109,9 +109,10 @@ def version() -> str:
 def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
 
-    variant None picks the 256x256 ring kernel on its fastest schedule when the shape allows, else the 128x128 one
-    (0: 128x128; 1: ring, schedule 0; 2: ring, one half-tile per phase -- see gemm_ring256.h; 3: experimental
-    4-wave 128x128-per-wave kernel, gemm_quad128.h).
+    variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream (4) for whole
+    256 x 256 tiles and an even number of K tiles >= 4, else the 8-wave ring kernel (2, or 1 for an odd tile count), else
+    the 128x128 one (0). 3: the compiler-scheduled 4-wave kernel (gemm_quad128.h); 5..7: earlier placements of the
+    hand-scheduled stream; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
     """
     import torch
     _require_cuda(a, b)
@@ -123,7 +124,7 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     N = b.shape[0]
     if variant is None:
         if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
-            variant = 2 if (K % 128 == 0 and K >= 256) else 1      # schedule 1 needs an even number of K tiles >= 4
+            variant = 4 if (K % 128 == 0 and K >= 256) else 1      # an even number of K tiles >= 4, else the ring's schedule 0
         else:
             variant = 0
     if out is None:
@@ -173,9 +174,11 @@ def fp4_decode(packed):
     return torch.stack((lo, hi), dim=-1).reshape(*packed.shape[:-1], packed.shape[-1] * 2)
 
 
-def gemm_fp4(a, b, out=None, variant: int = 1):
+def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] (bf16) = A[M,K] @ B[N,K].T`` with e2m1 (fp4) inputs packed two per byte:
-    `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2]."""
+    `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2].
+    variant None: the hand-scheduled 4-wave stream (2) when the packed row is a multiple of 256 bytes and >= 512, else
+    the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0)."""
     import torch
     _require_cuda(a, b)
     ok = (torch.uint8, getattr(torch, "float4_e2m1fn_x2", torch.uint8))
@@ -185,6 +188,8 @@ def gemm_fp4(a, b, out=None, variant: int = 1):
         raise KlmOpsError("gemm_fp4 shapes do not match")
     M, Kb = a.shape
     N = b.shape[0]
+    if variant is None:
+        variant = 2 if (Kb % 256 == 0 and Kb >= 512) else 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()

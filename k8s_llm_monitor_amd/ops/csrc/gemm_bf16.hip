@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "gemm_quad128.h"
+#include "gemm_quad_asm.h"
 #include "gemm_ring256.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -316,55 +317,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_quad(const uint16_t* __restrict
     }
 }
 
-// ------------------------------------------------------------------------------------
-// The same geometry (4 waves of 128 x 128, gemm_quad128.h's LDS image and swizzle) with the WHOLE instruction stream
-// written out: scripts/gen_gemm_quad_asm.py generates gemm_quad_asm.inc (schedule and register map are documented
-// there). HIP computes the descriptors and per-lane offsets; one asm statement does the rest, stores included.
-// ------------------------------------------------------------------------------------
-#include "gemm_quad_asm.inc"
-
-__global__ __launch_bounds__(256) void gemm_bf16_quad_asm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
-                                                          uint16_t* __restrict__ C, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 1, wc = wid & 1;
-  int tm, tn;
-  tile_of_block<8>(blockIdx.x, M >> 8, N >> 8, tm, tn);
-  const int brow = tm << 8, bcol = tn << 8;
-  const unsigned lda = (unsigned)K * 2, ldc = (unsigned)N * 2;
-  // descriptors start at this WAVE's first staged row (it stages rows [64 wid, 64 wid + 64) of both operands) and at
-  // its 128 x 128 part of C, so every offset inside the asm is small and wave-independent
-  const uint64_t pa = reinterpret_cast<uint64_t>(A) + (uint64_t)(brow + wid * 64) * lda;
-  const uint64_t pb = reinterpret_cast<uint64_t>(B) + (uint64_t)(bcol + wid * 64) * lda;
-  const uint64_t pc = reinterpret_cast<uint64_t>(C) + (uint64_t)(brow + wr * 128) * ldc + (uint64_t)(bcol + wc * 128) * 2;
-  auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-  const unsigned ra0 = uni((unsigned)pa), ra1 = uni((unsigned)(pa >> 32) & 0xffffu), ra2 = uni(64u * lda);
-  const unsigned rb0 = uni((unsigned)pb), rb1 = uni((unsigned)(pb >> 32) & 0xffffu);
-  const unsigned rc0 = uni((unsigned)pc), rc1 = uni((unsigned)(pc >> 32) & 0xffffu), rc2 = uni(128u * ldc);
-  const unsigned r3 = 0x00020000u;
-  const unsigned ldsbase = (unsigned)(uintptr_t)(KLM_AS3 char*)smem;
-  const unsigned lw = uni(ldsbase + (unsigned)wid * 8192u);
-  const unsigned passes = uni((unsigned)((K >> 6) - 2) >> 1);
-  // per lane: staging source offset (row lane >> 3 of an 8-row piece, swizzled 16-byte chunk) ...
-  const unsigned srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const unsigned va = srow * lda + schunk * 16;
-  // ... fragment read addresses (row lane & 15 of a 16-row tile, chunk k-step * 4 + (lane >> 4), swizzled by row & 7) ...
-  const unsigned fr = lane & 15, fq = lane >> 4, key = lane & 7;
-  const unsigned ch0 = ((fq ^ key) << 4), ch1 = (((4 + fq) ^ key) << 4);
-  const unsigned a0 = ldsbase + ((unsigned)wr * 128 + fr) * 128 + ch0, a1 = ldsbase + ((unsigned)wr * 128 + fr) * 128 + ch1;
-  const unsigned b0 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch0;
-  const unsigned b1 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch1;
-  // ... and where its 4 consecutive columns of an accumulator tile go in C
-  const unsigned vc = fr * ldc + fq * 8;
-  asm volatile(KLM_QUAD_ASM_BODY
-               :
-               : [ra0] "s"(ra0), [ra1] "s"(ra1), [ra2] "s"(ra2), [ra3] "s"(r3), [rb0] "s"(rb0), [rb1] "s"(rb1), [rb2] "s"(ra2),
-                 [rb3] "s"(r3), [rc0] "s"(rc0), [rc1] "s"(rc1), [rc2] "s"(rc2), [rc3] "s"(r3), [lda] "s"(lda), [ldc] "s"(ldc),
-                 [passes] "s"(passes), [lw] "s"(lw), [va] "v"(va), [vc] "v"(vc), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1)
-               : KLM_QUAD_ASM_CLOBBERS);
-}
-
 extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                              void* stream) {
   if (!A || !B || !C) return KLM_ERR_ARG;
@@ -383,12 +335,21 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     if (int e = klm_ensure_dyn_lds<gemm_bf16_quad>(KLM_QUAD_LDS_BYTES)) return e;
     hipLaunchKernelGGL(gemm_bf16_quad, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, (const uint16_t*)A,
                        (const uint16_t*)B, (uint16_t*)C, M, N, K);
-  } else if (variant == 4) {
-    // hand-scheduled stream; an even number of K tiles >= 4; descriptors use 32-bit byte ranges
-    if ((M & 255) || (N & 255) || (K & 127) || K < 256 || (size_t)K * 2 * 64 > 0x7fffffffull || (size_t)N * 2 * 128 > 0x7fffffffull) return KLM_ERR_SHAPE;
-    if (int e = klm_ensure_dyn_lds<gemm_bf16_quad_asm>(KLM_QUAD_LDS_BYTES)) return e;
-    hipLaunchKernelGGL(gemm_bf16_quad_asm, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, (const uint16_t*)A,
-                       (const uint16_t*)B, (uint16_t*)C, M, N, K);
+  } else if ((variant >= 4 && variant <= 7) || (variant >= 40 && variant <= 43)) {
+    // hand-scheduled streams (gemm_quad_asm.h): 4 the kernel; 5..7 earlier placements; 40..43 diagnostic, results meaningless
+    if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
+    int e = KLM_OK;
+    switch (variant) {
+      case 4: e = klm_launch_quad_asm<0>(A, B, C, M, N, K * 2, s); break;
+      case 5: e = klm_launch_quad_asm<1>(A, B, C, M, N, K * 2, s); break;
+      case 6: e = klm_launch_quad_asm<2>(A, B, C, M, N, K * 2, s); break;
+      case 7: e = klm_launch_quad_asm<3>(A, B, C, M, N, K * 2, s); break;
+      case 40: e = klm_launch_quad_asm<10>(A, B, C, M, N, K * 2, s); break;
+      case 41: e = klm_launch_quad_asm<11>(A, B, C, M, N, K * 2, s); break;
+      case 42: e = klm_launch_quad_asm<12>(A, B, C, M, N, K * 2, s); break;
+      default: e = klm_launch_quad_asm<13>(A, B, C, M, N, K * 2, s); break;
+    }
+    if (e) return e;
   } else if (variant == 1 || variant == 2) {
     if ((M & 255) || (N & 255) || (K & 63) || K < 128) return KLM_ERR_SHAPE;
     const int grid = (M >> 8) * (N >> 8);

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemm_quad_asm.h"
 #include "gemm_ring256.h"
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -38,12 +39,26 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // Fragments as [ks][tile]: fp8 uses ks = 0 only and all 8 registers (chunks g, g+4); fp4 uses ks = 0, 1 with the
 // low 4 registers each (chunk 4*ks+g); the compiler drops what a format does not touch (the fp4 form of the
 // instruction reads v[0:3] only).
+// The MFMA is written as inline asm with the accumulator TIED (destination = source C): as a builtin, hipcc (ROCm 7.2)
+// leaves the two untied for this instruction, picks other destination registers inside the unrolled loop and copies
+// the accumulators back at the loop's end (259 v_mov_b32 per two K tiles = 4 per MFMA, measured 0.68 MFMA-busy for
+// fp8 where the bf16 kernel of the same pipeline reaches 0.80). Inline asm is invisible to the hazard recognizer:
+// dependent MFMAs on one accumulator are 8 MFMAs apart here, and the kernel drains the pipe (s_nop) before the
+// epilogue reads the accumulators.
+template <int FMT>
+struct klm_mx_frag;
+template <>
+struct klm_mx_frag<0> { typedef i32x8 type; };     // fp8: 32 bytes per lane (K = 128 in one instruction)
+template <>
+struct klm_mx_frag<4> { typedef i32x4 type; };     // fp4: 16 bytes per lane per k step (the instruction reads v[0:3])
+
 template <int FMT>
 struct klm_op_mx {
+  typedef typename klm_mx_frag<FMT>::type frag;
   f32x4 acc[2][2][4][2];
-  i32x8 a[2][4];
-  i32x8 b[2][2][2];        // [register set][ks][n tile]
-  int c0, c1, a_row, b_row;
+  frag a[2][4];
+  frag b[2][2][2];        // [register set][ks][n tile]
+  int c0, c1, a_row, b_row, scale;
 
   __device__ __forceinline__ void init(int lane, int wr, int wc) {
     const int fr = lane & 15, fq = lane >> 4, key = lane & 7;
@@ -51,6 +66,7 @@ struct klm_op_mx {
     c1 = c0 ^ 64;
     a_row = (wr * 64 + fr) * 128;
     b_row = (wc * 32 + fr) * 128;
+    scale = KLM_UNIT_SCALE;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -60,14 +76,15 @@ struct klm_op_mx {
 #pragma unroll
           for (int n = 0; n < 2; ++n) acc[i][j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  __device__ __forceinline__ void load_frag(i32x8& f0, i32x8& f1, const char* base) const {
+  // fp8 uses ks = 0 only (chunks g and g + 4 side by side in one 8-register fragment); fp4 one 4-register fragment per ks
+  __device__ __forceinline__ void load_frag(frag& f0, frag& f1, const char* base) const {
     const i32x4 lo = *reinterpret_cast<const i32x4*>(base + c0);
     const i32x4 hi = *reinterpret_cast<const i32x4*>(base + c1);
-    if (FMT == 0) {
+    if constexpr (FMT == 0) {
       f0 = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     } else {
-      f0 = i32x8{lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
-      f1 = i32x8{hi[0], hi[1], hi[2], hi[3], 0, 0, 0, 0};
+      f0 = lo;
+      f1 = hi;
     }
   }
   __device__ __forceinline__ void read_a(const char* slot) {
@@ -79,6 +96,15 @@ struct klm_op_mx {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) load_frag(b[SET][0][ni], b[SET][1][ni], slot + b_row + ni * 2048);
   }
+  __device__ __forceinline__ void mfma1(f32x4& c, const frag& x, const frag& y) const {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc parses this body too and knows no "v" registers
+    if constexpr (FMT == 0)
+      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(x), "v"(y), "v"(scale));
+    else
+      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                   : "+v"(c) : "v"(x), "v"(y), "v"(scale));
+#endif
+  }
   template <int AH, int BH, int SET>
   __device__ __forceinline__ void mfma() {
     __builtin_amdgcn_s_setprio(1);
@@ -87,9 +113,7 @@ struct klm_op_mx {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[AH][BH][mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-              b[SET][ks][ni], a[ks][mi], acc[AH][BH][mi][ni], FMT, FMT, 0, KLM_UNIT_SCALE, 0, KLM_UNIT_SCALE);
+        for (int ni = 0; ni < 2; ++ni) mfma1(acc[AH][BH][mi][ni], b[SET][ks][ni], a[ks][mi]);
     __builtin_amdgcn_s_setprio(0);
   }
 };
@@ -114,6 +138,8 @@ __global__ __launch_bounds__(512) void gemm_mx_256(const uint8_t* __restrict__ A
   klm_op_mx<FMT> op;
   op.init(lane, wr, wc);
   klm_ring256_mainloop<SCHED>(op, st, smem, K >> 7, wr);
+  // the asm MFMAs are invisible to the hazard recognizer: let the last ones leave the pipe before the epilogue reads acc
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -166,6 +192,15 @@ extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N,
 extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                             void* stream) {
   if (K <= 0 || (K & 1)) return KLM_ERR_SHAPE;
+  if (variant == 2) {
+    // the hand-scheduled 4-wave stream (gemm_quad_asm.h): same fragments and K tile as bf16, the MX MFMA with unit scales
+    if (!A || !B || !C) return KLM_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
+    if (!klm_quad_asm_shape_ok(M, N, K >> 1)) return KLM_ERR_SHAPE;
+    if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
+    if (int e = klm_launch_quad_asm<20>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;
+    return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+  }
   if (int e = check_mx(A, B, C, M, N, K >> 1, variant)) return e;
   return launch_mx<4>(A, B, C, M, N, K >> 1, variant, stream);
 }

@@ -1,0 +1,84 @@
+// The hand-scheduled 4-wave 256 x 256 kernels: kernel template + launcher around the generated instruction streams
+// (gemm_quad_asm.inc, from scripts/gen_gemm_quad_asm.py). Shared by the bf16 and fp4 burners.
+#pragma once
+#include "gemm_quad128.h"
+#include "gemm_quad_asm.inc"
+
+// ------------------------------------------------------------------------------------
+// The same geometry (4 waves of 128 x 128, gemm_quad128.h's LDS image and swizzle) with the WHOLE instruction stream
+// written out: scripts/gen_gemm_quad_asm.py generates gemm_quad_asm.inc (schedule and register map are documented
+// there). HIP computes the descriptors and per-lane offsets; one asm statement does the rest, stores included.
+// ------------------------------------------------------------------------------------
+
+// BODY: 0 the bf16 kernel (schedule "stagger"); 1..3 earlier placements of the same instructions (spread, one_barrier,
+// per_operand), kept for the A/B record; 10..13 diagnostic streams without the loop's DMA / fragment reads / K advance
+// (DMA from L2 only) / all of it (results meaningless: they price each kind of instruction); 20 the fp4 kernel.
+// Kb: the operands' row length in BYTES (bf16: 2 K, fp4: K / 2); a K tile is 128 bytes of a row in every format.
+template <int BODY>
+__global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A, const void* __restrict__ B,
+                                                     uint16_t* __restrict__ C, int M, int N, int Kb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  int tm, tn;
+  tile_of_block<8>(blockIdx.x, M >> 8, N >> 8, tm, tn);
+  const int brow = tm << 8, bcol = tn << 8;
+  const unsigned lda = (unsigned)Kb, ldc = (unsigned)N * 2;
+  // descriptors start at this WAVE's first staged row (it stages rows [64 wid, 64 wid + 64) of both operands) and at
+  // its 128 x 128 part of C, so every offset inside the asm is small and wave-independent
+  const uint64_t pa = reinterpret_cast<uint64_t>(A) + (uint64_t)(brow + wid * 64) * lda;
+  const uint64_t pb = reinterpret_cast<uint64_t>(B) + (uint64_t)(bcol + wid * 64) * lda;
+  const uint64_t pc = reinterpret_cast<uint64_t>(C) + (uint64_t)(brow + wr * 128) * ldc + (uint64_t)(bcol + wc * 128) * 2;
+  auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  const unsigned ra0 = uni((unsigned)pa), ra1 = uni((unsigned)(pa >> 32) & 0xffffu), ra2 = uni(64u * lda);
+  const unsigned rb0 = uni((unsigned)pb), rb1 = uni((unsigned)(pb >> 32) & 0xffffu);
+  const unsigned rc0 = uni((unsigned)pc), rc1 = uni((unsigned)(pc >> 32) & 0xffffu), rc2 = uni(128u * ldc);
+  const unsigned r3 = 0x00020000u;
+  const unsigned ldsbase = (unsigned)(uintptr_t)(KLM_AS3 char*)smem;
+  const unsigned lw = uni(ldsbase + (unsigned)wid * 8192u);
+  const unsigned passes = uni((unsigned)((Kb >> 7) - 2) >> 1);
+  // per lane: staging source offset (row lane >> 3 of an 8-row piece, swizzled 16-byte chunk) ...
+  const unsigned srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const unsigned va = srow * lda + schunk * 16;
+  // ... fragment read addresses (row lane & 15 of a 16-row tile, chunk k-step * 4 + (lane >> 4), swizzled by row & 7) ...
+  const unsigned fr = lane & 15, fq = lane >> 4, key = lane & 7;
+  const unsigned ch0 = ((fq ^ key) << 4), ch1 = (((4 + fq) ^ key) << 4);
+  const unsigned a0 = ldsbase + ((unsigned)wr * 128 + fr) * 128 + ch0, a1 = ldsbase + ((unsigned)wr * 128 + fr) * 128 + ch1;
+  const unsigned b0 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch0;
+  const unsigned b1 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch1;
+  // ... and where its 4 consecutive columns of an accumulator tile go in C
+  const unsigned vc = fr * ldc + fq * 8;
+#define KLM_QUAD_ASM(BODY_TEXT)                                                                                                \
+  asm volatile(BODY_TEXT                                                                                                       \
+               :                                                                                                               \
+               : [ra0] "s"(ra0), [ra1] "s"(ra1), [ra2] "s"(ra2), [ra3] "s"(r3), [rb0] "s"(rb0), [rb1] "s"(rb1), [rb2] "s"(ra2), \
+                 [rb3] "s"(r3), [rc0] "s"(rc0), [rc1] "s"(rc1), [rc2] "s"(rc2), [rc3] "s"(r3), [lda] "s"(lda), [ldc] "s"(ldc), \
+                 [passes] "s"(passes), [lw] "s"(lw), [wid] "s"(wid), [va] "v"(va), [vc] "v"(vc), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0),     \
+                 [b1] "v"(b1)                                                                                                  \
+               : KLM_QUAD_ASM_CLOBBERS)
+  if constexpr (BODY == 0) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY);
+  else if constexpr (BODY == 1) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_SPREAD);
+  else if constexpr (BODY == 2) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_ONEBAR);
+  else if constexpr (BODY == 3) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_PEROP);
+  else if constexpr (BODY == 10) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_NODMA);
+  else if constexpr (BODY == 11) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_NOREAD);
+  else if constexpr (BODY == 12) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_L2ONLY);
+  else if constexpr (BODY == 13) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_MFMAONLY);
+  else KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_FP4);
+#undef KLM_QUAD_ASM
+}
+
+template <int BODY>
+static int klm_launch_quad_asm(const void* A, const void* B, void* C, int M, int N, int Kb, hipStream_t s) {
+  if (int e = klm_ensure_dyn_lds<gemm_quad_asm<BODY>>(KLM_QUAD_LDS_BYTES)) return e;
+  hipLaunchKernelGGL(gemm_quad_asm<BODY>, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, A, B, (uint16_t*)C, M, N, Kb);
+  return KLM_OK;
+}
+
+// shapes the hand-scheduled kernels take: whole 256 x 256 tiles, an even number of K tiles >= 4, 32-bit descriptor ranges
+static inline bool klm_quad_asm_shape_ok(int M, int N, int Kb) {
+  return M > 0 && N > 0 && !(M & 255) && !(N & 255) && !(Kb & 255) && Kb >= 512 && (size_t)Kb * 64 <= 0x7fffffffull &&
+         (size_t)N * 2 * 128 <= 0x7fffffffull;
+}
+

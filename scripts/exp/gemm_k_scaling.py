@@ -17,7 +17,8 @@ for K in Ks:
     c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     one = torch.ones((), device=dev)
     bt, b8t = b.t(), b8.t()
-    cands = {"bf16_klm": lambda: ops.gemm_bf16(a, b, out=c, variant=2), "bf16_quad": lambda: ops.gemm_bf16(a, b, out=c, variant=3),
+    cands = {"bf16_klm": lambda: ops.gemm_bf16(a, b, out=c, variant=2), "bf16_quad": lambda: ops.gemm_bf16(a, b, out=c, variant=3), "bf16_asm_spread": lambda: ops.gemm_bf16(a, b, out=c, variant=6),
+             "bf16_asm_stagger": lambda: ops.gemm_bf16(a, b, out=c, variant=8),
              "bf16_vendor": lambda: torch.matmul(a, bt, out=c),
              "fp8_klm": lambda: ops.gemm_fp8(a8, b8, out=c), "fp8_vendor": lambda: torch._scaled_mm(a8, b8t, scale_a=one, scale_b=one, out_dtype=torch.bfloat16)}
     iters = max(10, int(40 * 8192 / K))

@@ -1,0 +1,47 @@
+"""What each kind of loop instruction costs the hand-scheduled 4-wave kernel: the real stream, two other placements, and
+diagnostic streams without the loop's DMA / fragment reads / barriers (results meaningless, timing meaningful), all
+interleaved at 8192^3 next to the ring kernel and hipBLASLt."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from k8s_llm_monitor_amd import ops
+dev = torch.device("cuda:0")
+n = 8192
+g = torch.Generator(device=dev); g.manual_seed(7)
+a = (torch.rand(n, n, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+b = (torch.rand(n, n, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+c = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+ref = ops.gemm_bf16(a, b, variant=2)
+ok = {v: bool(torch.equal(ops.gemm_bf16(a, b, variant=v), ref)) for v in (4, 5, 6, 7)}
+print("bit-equal to the ring kernel:", ok, flush=True)
+# fp4: the hand-scheduled stream against the ring kernel (exact: integer-valued products of e2m1 codes, same sum order per element)
+a4 = torch.randint(0, 256, (n, n // 2), device=dev, generator=g, dtype=torch.uint8)
+b4 = torch.randint(0, 256, (n, n // 2), device=dev, generator=g, dtype=torch.uint8)
+r4 = ops.gemm_fp4(a4, b4, variant=1)
+ok["fp4_v2_equals_ring"] = bool(torch.equal(ops.gemm_fp4(a4, b4, variant=2), r4))
+small = ops.fp4_decode(a4[:256, :512]) @ ops.fp4_decode(b4[:512, :512]).t()
+ok["fp4_v2_small_exact"] = bool(torch.equal(ops.gemm_fp4(a4[:256, :512].contiguous(), b4[:512, :512].contiguous(), variant=2).float(), small.to(torch.bfloat16).float()))
+print("fp4:", ok, flush=True)
+bt = b.t()
+c4 = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+cands = {"fp4_ring": lambda: ops.gemm_fp4(a4, b4, out=c4, variant=1), "fp4_asm": lambda: ops.gemm_fp4(a4, b4, out=c4, variant=2),
+         "v2_ring": lambda: ops.gemm_bf16(a, b, out=c, variant=2), "hipblaslt": lambda: torch.matmul(a, bt, out=c),
+         "v4_stagger": lambda: ops.gemm_bf16(a, b, out=c, variant=4), "v5_spread": lambda: ops.gemm_bf16(a, b, out=c, variant=5),
+         "v6_one_barrier": lambda: ops.gemm_bf16(a, b, out=c, variant=6), "v7_per_operand": lambda: ops.gemm_bf16(a, b, out=c, variant=7),
+         "v40_no_dma": lambda: ops.gemm_bf16(a, b, out=c, variant=40), "v41_no_reads": lambda: ops.gemm_bf16(a, b, out=c, variant=41),
+         "v42_dma_from_l2_only": lambda: ops.gemm_bf16(a, b, out=c, variant=42), "v43_mfma_only": lambda: ops.gemm_bf16(a, b, out=c, variant=43)}
+runs = {k: [] for k in cands}
+for r in range(6):
+    for name, fn in cands.items():
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record(); e1.synchronize()
+        if r:
+            runs[name].append(2.0 * n ** 3 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+out = {"bit_equal": ok, "tflops": {k: {"median": sorted(v)[len(v) // 2], "min": min(v), "max": max(v)} for k, v in runs.items()}}
+for k, v in out["tflops"].items():
+    print(k, {x: round(y, 1) for x, y in v.items()}, flush=True)
+json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/quad_asm_ablate.json", "w"), indent=1)

@@ -9,14 +9,18 @@ statements pinned with sched_barrier) the compiler still decides the waits and t
 instruction's place is fixed:
 
   per K tile (stage S, 128 MFMAs, m-tile-major so consecutive MFMAs share the A fragment):
-    after MFMA 0,2,..,30     the 16 ds_read_b128 of this tile's k-step 1 -> fragment set 1
-    after MFMA 40            s_waitcnt lgkmcnt(0); s_barrier            (#1: every wave is done reading stage S)
-    after MFMA 41,43,..,63   LDS-DMA pieces 0..11 of tile t+2 -> stage S
-    after MFMA 63            s_waitcnt vmcnt(12); s_barrier             (#2: tile t+1 landed, for every wave)
-    after MFMA 64,66,..,94   the 16 ds_read_b128 of tile t+1's k-step 0 -> fragment set 0
-    after MFMA 65,..,71      LDS-DMA pieces 12..15
+    after MFMA 0,2,..,14     the 8 B fragments of this tile's k-step 1 -> fragment set 1
+    after MFMA 20            s_waitcnt lgkmcnt(0); s_barrier       (#1: every wave is done with the B half of stage S)
+    after MFMA 21,23,..,35   LDS-DMA: the 8 B pieces of tile t+2 -> stage S
+    after MFMA 22,24,..,36   the 8 A fragments of k-step 1 -> set 1
+    after MFMA 46            s_waitcnt lgkmcnt(0); s_barrier       (#2: done with the A half)
+    after MFMA 47,49,..,61   LDS-DMA: the 8 A pieces of tile t+2
+    after MFMA 87            s_waitcnt vmcnt(16); s_barrier        (#3: tile t+1 landed, for every wave)
+    after MFMA 88,90,..,118  the 16 fragments of tile t+1's k-step 0 -> set 0
     after MFMA 126           s_waitcnt lgkmcnt(0)
-  never more than one memory instruction in an MFMA gap.
+  never more than one memory instruction in an MFMA gap. (First version: one barrier for both halves at MFMA 40, DMA
+  from 41 on, the wait for tile t+1 at MFMA 63: 1506 TFLOP/s at 8192^3, no better than the compiler-scheduled
+  gemm_quad128.h -- the DMA had only ~2 k cycles to land.)
 
 Registers (fixed, all on the asm statement's clobber list):
   a[0:255]        accumulators, tile (mi, ni) at a[4 (8 mi + ni)]
@@ -41,10 +45,20 @@ def frag(base, i):
     return f"v[{base + 4 * i}:{base + 4 * i + 3}]"
 
 
+NMAJOR = False      # True: consecutive MFMAs share the B fragment (the instruction's FIRST source) instead of the A fragment
+DTYPE = "bf16"      # or "fp4": same 16-byte fragments and K tile of 128 bytes per row, the MX-scaled MFMA with unit scales
+SCALE = 176         # fp4: VGPR holding four E8M0 scales of 2^0
+
+
 def mfma(i):
-    """MFMA i of a K tile: k-step i // 64, m tile (i % 64) // 8, n tile i % 8."""
+    """MFMA i of a K tile: k-step i // 64, m tile (i % 64) // 8, n tile i % 8 (NMAJOR: the roles of m and n swapped)."""
     ks, mi, ni = i // 64, (i % 64) // 8, i % 8
+    if NMAJOR:
+        mi, ni = ni, mi
     a, b = (A0, B0) if ks == 0 else (A1, B1)
+    if DTYPE == "fp4":
+        return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {acc(mi, ni)}, v{SCALE}, v{SCALE} "
+                f"op_sel_hi:[0,0,0] cbsz:4 blgp:4")
     return f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {acc(mi, ni)}"
 
 
@@ -53,6 +67,8 @@ def read(setno, stage, j):
     abase, bbase = (A0, B0) if setno == 0 else (A1, B1)
     ra = RB + 4 * stage + setno          # a, k-step = setno
     rb = RB + 4 * stage + 2 + setno
+    if NMAJOR:                           # need order B[0], A[0..7], B[1..7]
+        abase, bbase, ra, rb = bbase, abase, rb, ra
     if j == 0:
         return f"ds_read_b128 {frag(abase, 0)}, v{ra}"
     if j <= 8:
@@ -75,33 +91,80 @@ def dma(stage, p):
     return pre, main
 
 
-def tile(stage, mode):
-    """mode: 'full' (issues tile t+2), 'tail2' (tile nt-2: no DMA), 'last' (tile nt-1: no DMA, no next reads)."""
-    out = [f"; ---- K tile in stage {stage}, {mode}"]
+def read_b(setno, stage, j):
+    return read(setno, stage, 1 + j)                      # B[j]
+
+
+def read_a(setno, stage, j):
+    return read(setno, stage, 0 if j == 0 else 8 + j)     # A[j]
+
+
+def tile(stage, mode, sched="one_barrier", ablate=(), wave=0):
+    """mode: 'full' (issues tile t+2), 'tail2' (tile nt-2: no DMA), 'last' (tile nt-1: no DMA, no next reads).
+    sched: where the pieces go (see SCHEDULES). ablate: diagnostic builds that drop 'dma', 'read' or 'barrier'
+    instructions from the loop (wrong results, right timing: what each kind of instruction costs)."""
+    out = [f"; ---- K tile in stage {stage}, {mode}, {sched}"]
     after = {i: [] for i in range(128)}
-    for j in range(16):
-        after[2 * j].append(read(1, stage, j))
-    after[40] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    P = SCHEDULES[sched]
+    if callable(P):
+        P = P(wave)
+    for j, i in enumerate(P["b1"]):
+        after[i].append(read_b(1, stage, j))
+    for j, i in enumerate(P["a1"]):
+        after[i].append(read_a(1, stage, j))
+    for i in P["free_barriers"]:
+        after[i] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    n_before = sum(1 for i in P["dma"] if i <= P["landed"])
     if mode == "full":
-        for p in range(16):
-            i = 41 + 2 * p if p < 12 else 65 + 2 * (p - 12)
+        for p, i in zip(P["dma_order"], P["dma"]):
             pre, main = dma(stage, p)
             after[i - 1] += pre          # the gap before: an MFMA sits between the M0 write and its use
             after[i] += main
-        after[63] += ["s_waitcnt vmcnt(12)", "s_barrier"]
+        after[P["landed"]] += (["s_waitcnt lgkmcnt(0)"] if P.get("landed_lgkm") else []) + [f"s_waitcnt vmcnt({n_before})", "s_barrier"]
     elif mode == "tail2":
-        after[63] += ["s_waitcnt vmcnt(0)", "s_barrier"]
+        after[P["landed"]] += (["s_waitcnt lgkmcnt(0)"] if P.get("landed_lgkm") else []) + ["s_waitcnt vmcnt(0)", "s_barrier"]
+    elif P.get("landed_lgkm"):
+        after[P["landed"]] += ["s_waitcnt lgkmcnt(0)"]
     if mode != "last":
-        for j in range(16):
-            after[64 + 2 * j].append(read(0, stage ^ 1, j))
+        for j, i in enumerate(P["next"]):
+            after[i].append(read(0, stage ^ 1, j))
         after[126].append("s_waitcnt lgkmcnt(0)")
+    drop = []
+    if "dma" in ablate:
+        drop += ["buffer_load", "s_mov_b32 m0", "s_add_u32 m0", "s_add_u32 s64", "s_addc_u32 s65", "s_add_u32 s68", "s_addc_u32 s69", "s_waitcnt vmcnt"]
+    if "bump" in ablate:       # DMA stays, but every tile re-fetches K tile 0/1 (L2-resident): no HBM / fabric traffic
+        drop += ["s_add_u32 s64", "s_addc_u32 s65", "s_add_u32 s68", "s_addc_u32 s69"]
+    if "read" in ablate:
+        drop += ["ds_read", "s_waitcnt lgkmcnt"]
+    if "barrier" in ablate:
+        drop += ["s_barrier"]
     for i in range(128):
         out.append(mfma(i))
-        out += after[i]
+        out += [x for x in after[i] if not any(x.startswith(d) for d in drop)]
     return out
 
 
-def body():
+# gap (= "after MFMA i") of every loop instruction, per schedule. dma_order: pieces 0..7 = A, 8..15 = B.
+SCHEDULES = {
+    # one barrier frees the whole stage; DMA from 41 on; the wait for tile t+1 at 63
+    "one_barrier": {"b1": [2 * (1 + j) for j in range(8)], "a1": [0] + [2 * (9 + j) for j in range(7)], "free_barriers": [40],
+                    "dma_order": list(range(16)), "dma": [41 + 2 * p for p in range(12)] + [65, 67, 69, 71], "landed": 63,
+                    "next": [64 + 2 * j for j in range(16)]},
+    # an operand's half of stage S is refilled as soon as every wave has read that operand's k-step 1 fragments
+    # (one barrier each), the wait for tile t+1 comes late (its DMA gets 160 - 200 MFMA slots to land)
+    "per_operand": {"b1": [2 * j for j in range(8)], "a1": [22 + 2 * j for j in range(8)], "free_barriers": [20, 46],
+                    "dma_order": [8 + q for q in range(8)] + list(range(8)), "dma": [21 + 2 * q for q in range(8)] + [47 + 2 * q for q in range(8)],
+                    "landed": 87, "next": [88 + 2 * j for j in range(16)]},
+    # as one_barrier, but the 16 DMA pieces spread over the rest of the tile, one per five MFMAs
+    "spread": {"b1": [2 * (1 + j) for j in range(8)], "a1": [0] + [2 * (9 + j) for j in range(7)], "free_barriers": [36],
+               "dma_order": list(range(16)), "dma": [39 + 5 * p for p in range(16)], "landed": 85,
+               "next": [86 + 2 * j + (1 if (86 + 2 * j - 39) % 5 == 0 else 0) for j in range(16)]},
+}
+
+
+def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
+    global NMAJOR, DTYPE
+    NMAJOR, DTYPE = nmajor, dtype
     o = []
     o += ["; ==== setup", "s_mov_b32 s64, %[ra0]", "s_mov_b32 s65, %[ra1]", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s67, %[ra3]",
           "s_mov_b32 s68, %[rb0]", "s_mov_b32 s69, %[rb1]", "s_mov_b32 s70, %[rb2]", "s_mov_b32 s71, %[rb3]",
@@ -112,7 +175,8 @@ def body():
           "s_mov_b32 s90, %[lw]", "s_add_u32 s91, s90, 0x8000", "s_add_u32 s92, s90, 0x10000", "s_add_u32 s93, s90, 0x18000",
           f"v_mov_b32 v{RB}, %[a0]", f"v_mov_b32 v{RB + 1}, %[a1]", f"v_mov_b32 v{RB + 2}, %[b0]", f"v_mov_b32 v{RB + 3}, %[b1]",
           f"v_add_u32 v{RB + 4}, 0x10000, v{RB}", f"v_add_u32 v{RB + 5}, 0x10000, v{RB + 1}",
-          f"v_add_u32 v{RB + 6}, 0x10000, v{RB + 2}", f"v_add_u32 v{RB + 7}, 0x10000, v{RB + 3}"]
+          f"v_add_u32 v{RB + 6}, 0x10000, v{RB + 2}", f"v_add_u32 v{RB + 7}, 0x10000, v{RB + 3}",
+          f"v_mov_b32 v{SCALE}, 0x7f7f7f7f"]
     o += ["; ==== prologue: tiles 0 and 1 on their way, accumulators cleared meanwhile"]
     for st in (0, 1):
         for p in range(16):
@@ -124,12 +188,27 @@ def body():
     for j in range(16):
         o.append(read(0, 0, j))
     o += ["s_waitcnt lgkmcnt(0)"]
-    o += ["; ==== main loop: two K tiles per pass", "1:"]
-    o += tile(0, "full")
-    o += tile(1, "full")
-    o += ["s_sub_u32 s88, s88, 1", "s_cmp_lg_u32 s88, 0", "s_cbranch_scc1 1b"]
-    o += tile(0, "tail2")
-    o += tile(1, "last")
+    if sched in PER_WAVE:
+        # four copies of the loop, one per wave of the workgroup (they differ only in where the DMA pieces sit)
+        for w in (1, 2, 3):
+            o += [f"s_cmp_eq_u32 %[wid], {w}", f"s_cbranch_scc1 Lklm%=_w{w}"]
+        for w in range(4):
+            o += [f"; ==== main loop of wave {w}: two K tiles per pass", f"Lklm%=_w{w}:"]
+            o += tile(0, "full", sched, ablate, w)
+            o += tile(1, "full", sched, ablate, w)
+            o += ["s_sub_u32 s88, s88, 1", "s_cmp_lg_u32 s88, 0", f"s_cbranch_scc1 Lklm%=_w{w}"]
+            o += tile(0, "tail2", sched, ablate, w)
+            o += tile(1, "last", sched, ablate, w)
+            if w < 3:
+                o += ["s_branch Lklm%=_epilogue"]
+        o += ["Lklm%=_epilogue:"]
+    else:
+        o += ["; ==== main loop: two K tiles per pass", "1:"]
+        o += tile(0, "full", sched, ablate)
+        o += tile(1, "full", sched, ablate)
+        o += ["s_sub_u32 s88, s88, 1", "s_cmp_lg_u32 s88, 0", "s_cbranch_scc1 1b"]
+        o += tile(0, "tail2", sched, ablate)
+        o += tile(1, "last", sched, ablate)
     o += ["; ==== epilogue: fp32 -> bf16, 8 bytes per lane and tile", "s_nop 15", "s_nop 15", "s_mov_b32 s94, 0", "s_lshl_b32 s95, %[ldc], 4"]
     t = 0
     for mi in range(8):
@@ -149,24 +228,54 @@ def body():
 def clobbers():
     c = ["memory", "scc", "vcc", "m0"]
     c += [f"s{i}" for i in range(64, 76)] + [f"s{i}" for i in range(80, 96)]
-    c += [f"v{i}" for i in range(40, 176)]
+    c += [f"v{i}" for i in range(40, 177)]
     c += [f"a{i}" for i in range(256)]
     return c
+
+
+def _stagger(wave, first=39, step=5, landed=85):
+    """'spread', with wave w's DMA pieces one gap later per wave: the four waves of a workgroup run in lockstep (the
+    barriers keep them there), so without this all four hand their DMA to the CU's one texture-address unit in the same
+    cycle and three of them wait in its queue with their MFMA issue blocked behind the DMA."""
+    dma_gaps = [first + step * p + wave for p in range(16)]
+    nxt, g = [], landed + 1
+    while len(nxt) < 16:
+        if g not in dma_gaps:
+            nxt.append(g)
+            g += 2
+        else:
+            g += 1
+    return {"b1": [2 * (1 + j) for j in range(8)], "a1": [0] + [2 * (9 + j) for j in range(7)], "free_barriers": [36],
+            "dma_order": list(range(16)), "dma": dma_gaps, "landed": landed, "next": nxt}
+
+
+SCHEDULES["stagger"] = _stagger
+PER_WAVE = {"stagger"}
+
+
+# macro suffix -> (schedule, ablations, dtype). The ablated streams keep a GEMM's timing, not its result.
+BODIES = {"": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEBAR": ("one_barrier", (), "bf16"),
+          "_PEROP": ("per_operand", (), "bf16"),
+          "_NODMA": ("spread", ("dma",), "bf16"), "_NOREAD": ("spread", ("read",), "bf16"), "_L2ONLY": ("spread", ("bump",), "bf16"),
+          "_MFMAONLY": ("spread", ("dma", "read", "barrier"), "bf16"),
+          "_FP4": ("stagger", (), "fp4")}
 
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                              "k8s_llm_monitor_amd", "ops", "csrc", "gemm_quad_asm.inc")
-    lines = body()
     with open(out, "w") as f:
-        f.write("// GENERATED by scripts/gen_gemm_quad_asm.py -- do not edit; the schedule is documented there.\n")
-        f.write("#define KLM_QUAD_ASM_BODY \\\n")
-        for ln in lines:
-            f.write('  "%s\\n\\t" \\\n' % ln.replace('"', '\\"'))
-        f.write('  ""\n')
+        f.write("// GENERATED by scripts/gen_gemm_quad_asm.py -- do not edit; the schedules are documented there.\n")
+        for suffix, (sched, ablate, dtype) in BODIES.items():
+            lines = body(sched, ablate, dtype=dtype)
+            f.write(f"#define KLM_QUAD_ASM_BODY{suffix} \\\n")
+            for ln in lines:
+                f.write('  "%s\\n\\t" \\\n' % ln.replace('"', '\\"'))
+            f.write('  ""\n')
+            n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
+            print(f"KLM_QUAD_ASM_BODY{suffix}: {len(lines)} lines, {n_mfma} MFMAs, {sum(1 for l in lines if l.startswith('buffer_load'))} DMA, "
+                  f"{sum(1 for l in lines if l.startswith('ds_read'))} reads, {sum(1 for l in lines if l.startswith('s_barrier'))} barriers")
         f.write("#define KLM_QUAD_ASM_CLOBBERS " + ", ".join('"%s"' % c for c in clobbers()) + "\n")
-    n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
-    print(f"{out}: {len(lines)} instructions/labels, {n_mfma} MFMAs")
 
 
 if __name__ == "__main__":

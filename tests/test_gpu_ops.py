@@ -19,7 +19,9 @@ def env():
                                            (1, (256, 256, 128)), (1, (512, 768, 320)), (1, (2048, 1024, 4096)),
                                            (2, (256, 256, 256)), (2, (512, 768, 384)), (2, (2048, 1024, 4096)), (2, (256, 512, 4224)),
                                            (3, (256, 256, 256)), (3, (512, 768, 384)), (3, (1024, 512, 4096)),
-                                           (None, (1024, 1024, 1024)), (None, (384, 128, 64))])
+                                           (4, (256, 256, 256)), (4, (512, 768, 384)), (4, (2048, 1024, 4096)), (4, (256, 512, 4352)),
+                                           (5, (512, 768, 384)), (6, (512, 768, 384)), (7, (512, 768, 384)), (5, (256, 256, 4352)),
+                                           (None, (1024, 1024, 1024)), (None, (384, 128, 64)), (None, (256, 256, 192))])
 def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch, ops, dev = env
     M, N, K = shape
@@ -32,7 +34,7 @@ def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=1e-2 * K ** 0.5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_gemm_bf16_exact_on_small_integers_with_asymmetric_operands(env, variant):
     torch, ops, dev = env
     M, N, K = 512, 256, (192 if variant < 2 else 384)
@@ -50,7 +52,7 @@ def test_gemm_bf16_identity_picks_rows_not_columns(env):
     n = 256
     eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
     b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)      # asymmetric
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4, 5, 6, 7):
         assert torch.equal(ops.gemm_bf16(eye, b, variant=v), b.t().contiguous())      # C = I @ B^T
 
 
@@ -59,7 +61,7 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
     a = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     b = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     c0 = ops.gemm_bf16(a, b, variant=1).clone()
-    for v in (1, 2, 3):                                               # every pipeline gives the same bits, every run
+    for v in (1, 2, 3, 4, 5, 6, 7):                                   # every pipeline gives the same bits, every run
         for _ in range(20):
             assert torch.equal(ops.gemm_bf16(a, b, variant=v), c0)   # a ring-buffer race would show as a rare diff
 
@@ -89,7 +91,7 @@ def test_gemm_fp8_exact_on_small_integers(env):
     assert torch.equal(c, (a @ b.t()).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 512), (512, 768, 1024), (1024, 512, 8192)])
+@pytest.mark.parametrize("shape", [(256, 256, 512), (512, 768, 1024), (1024, 512, 8192), (256, 512, 1536), (512, 256, 768)])
 def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     """e2m1 values are multiples of 0.5 up to 6: products and fp32 sums of a few thousand of them are
     exact, so the only rounding is the bf16 store."""
@@ -100,8 +102,8 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     b = torch.randint(0, 256, (N, K // 2), device=dev, generator=g, dtype=torch.uint8)
     a[:, 3] = (torch.arange(M, device=dev) % 251).to(torch.uint8)            # position- and row-dependent bytes
     b[:, K // 2 - 5] = (torch.arange(N, device=dev) % 239).to(torch.uint8)
-    c = ops.gemm_fp4(a, b)
-    assert torch.equal(c, ops.gemm_fp4(a, b, variant=0))
+    c = ops.gemm_fp4(a, b)                                                    # the hand-scheduled stream where the shape allows
+    assert torch.equal(c, ops.gemm_fp4(a, b, variant=0)) and torch.equal(c, ops.gemm_fp4(a, b, variant=1))
     ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
     assert torch.equal(c, ref.float().to(torch.bfloat16))
     if hasattr(torch, "float4_e2m1fn_x2"):

@@ -139,9 +139,10 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     return out
 
 
-def gemm_fp8(a, b, out=None, variant: int = 1):
+def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the MX-scaled MFMA.
-    variant 1 (default): ring schedule 1 when the K tile count allows, else schedule 0; variant 0: schedule 0."""
+    variant None: the hand-scheduled 4-wave stream (2) when K is a multiple of 256 and >= 512, else the ring kernel
+    (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 3: another placement of stream 2."""
     import torch
     _require_cuda(a, b)
     if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
@@ -150,6 +151,8 @@ def gemm_fp8(a, b, out=None, variant: int = 1):
         raise KlmOpsError("gemm_fp8 shapes do not match")
     M, K = a.shape
     N = b.shape[0]
+    if variant is None:
+        variant = 2 if (K % 256 == 0 and K >= 512) else 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()

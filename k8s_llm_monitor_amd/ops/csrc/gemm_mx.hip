@@ -184,6 +184,16 @@ static int check_mx(const void* A, const void* B, const void* C, int M, int N, i
 
 extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                             void* stream) {
+  if (variant == 2 || variant == 3) {
+    // the hand-scheduled 4-wave stream (gemm_quad_asm.h, generator: body_fp8); 3: another placement, for the A/B record
+    if (!A || !B || !C) return KLM_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
+    if (!klm_quad_asm_shape_ok(M, N, K)) return KLM_ERR_SHAPE;
+    if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
+    if (int e = variant == 2 ? klm_launch_quad_asm<30>(A, B, C, M, N, K, (hipStream_t)stream)
+                             : klm_launch_quad_asm<31>(A, B, C, M, N, K, (hipStream_t)stream)) return e;
+    return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+  }
   if (int e = check_mx(A, B, C, M, N, K, variant)) return e;
   return launch_mx<0>(A, B, C, M, N, K, variant, stream);
 }

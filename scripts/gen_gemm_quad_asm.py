@@ -162,9 +162,7 @@ SCHEDULES = {
 }
 
 
-def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
-    global NMAJOR, DTYPE
-    NMAJOR, DTYPE = nmajor, dtype
+def setup_lines(RB, SCALE):
     o = []
     o += ["; ==== setup", "s_mov_b32 s64, %[ra0]", "s_mov_b32 s65, %[ra1]", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s67, %[ra3]",
           "s_mov_b32 s68, %[rb0]", "s_mov_b32 s69, %[rb1]", "s_mov_b32 s70, %[rb2]", "s_mov_b32 s71, %[rb3]",
@@ -177,6 +175,31 @@ def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
           f"v_add_u32 v{RB + 4}, 0x10000, v{RB}", f"v_add_u32 v{RB + 5}, 0x10000, v{RB + 1}",
           f"v_add_u32 v{RB + 6}, 0x10000, v{RB + 2}", f"v_add_u32 v{RB + 7}, 0x10000, v{RB + 3}",
           f"v_mov_b32 v{SCALE}, 0x7f7f7f7f"]
+    return o
+
+
+def epilogue_lines():
+    o = []
+    o += ["; ==== epilogue: fp32 -> bf16, 8 bytes per lane and tile", "s_nop 15", "s_nop 15", "s_mov_b32 s94, 0", "s_lshl_b32 s95, %[ldc], 4"]
+    t = 0
+    for mi in range(8):
+        for ni in range(8):
+            r = A0 + 8 * (t % 8)
+            b = 4 * (8 * mi + ni)
+            o += [f"v_accvgpr_read_b32 v{r}, a{b}", f"v_accvgpr_read_b32 v{r + 1}, a{b + 1}",
+                  f"v_accvgpr_read_b32 v{r + 2}, a{b + 2}", f"v_accvgpr_read_b32 v{r + 3}, a{b + 3}",
+                  f"v_cvt_pk_bf16_f32 v{r}, v{r}, v{r + 1}", f"v_cvt_pk_bf16_f32 v{r + 1}, v{r + 2}, v{r + 3}",
+                  f"buffer_store_dwordx2 v[{r}:{r + 1}], %[vc], s[72:75], s94 offen offset:{ni * 32}"]
+            t += 1
+        o.append("s_add_u32 s94, s94, s95")
+    o += ["s_waitcnt vmcnt(0)"]
+    return o
+
+
+def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
+    global NMAJOR, DTYPE
+    NMAJOR, DTYPE = nmajor, dtype
+    o = setup_lines(RB, SCALE)
     o += ["; ==== prologue: tiles 0 and 1 on their way, accumulators cleared meanwhile"]
     for st in (0, 1):
         for p in range(16):
@@ -209,26 +232,14 @@ def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
         o += ["s_sub_u32 s88, s88, 1", "s_cmp_lg_u32 s88, 0", "s_cbranch_scc1 1b"]
         o += tile(0, "tail2", sched, ablate)
         o += tile(1, "last", sched, ablate)
-    o += ["; ==== epilogue: fp32 -> bf16, 8 bytes per lane and tile", "s_nop 15", "s_nop 15", "s_mov_b32 s94, 0", "s_lshl_b32 s95, %[ldc], 4"]
-    t = 0
-    for mi in range(8):
-        for ni in range(8):
-            r = A0 + 8 * (t % 8)
-            b = 4 * (8 * mi + ni)
-            o += [f"v_accvgpr_read_b32 v{r}, a{b}", f"v_accvgpr_read_b32 v{r + 1}, a{b + 1}",
-                  f"v_accvgpr_read_b32 v{r + 2}, a{b + 2}", f"v_accvgpr_read_b32 v{r + 3}, a{b + 3}",
-                  f"v_cvt_pk_bf16_f32 v{r}, v{r}, v{r + 1}", f"v_cvt_pk_bf16_f32 v{r + 1}, v{r + 2}, v{r + 3}",
-                  f"buffer_store_dwordx2 v[{r}:{r + 1}], %[vc], s[72:75], s94 offen offset:{ni * 32}"]
-            t += 1
-        o.append("s_add_u32 s94, s94, s95")
-    o += ["s_waitcnt vmcnt(0)"]
+    o += epilogue_lines()
     return o
 
 
 def clobbers():
     c = ["memory", "scc", "vcc", "m0"]
     c += [f"s{i}" for i in range(64, 76)] + [f"s{i}" for i in range(80, 96)]
-    c += [f"v{i}" for i in range(40, 177)]
+    c += [f"v{i}" for i in range(40, 241)]
     c += [f"a{i}" for i in range(256)]
     return c
 
@@ -253,12 +264,109 @@ SCHEDULES["stagger"] = _stagger
 PER_WAVE = {"stagger"}
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3, MX MFMA 16x16x128 with unit scales): same LDS image, DMA and read addresses as bf16 -- an fp8 fragment
+# is 32 bytes per lane = the two 16-byte chunks bf16 reads as k-step 0 and k-step 1 -- but a K tile is ONE k-step of 64
+# MFMAs of 32 cycles, and a fragment takes 8 registers, so two whole fragment sets do not fit beside 256 accumulators:
+#   v[40:103] / v[104:167]   A fragments of the even / odd K tiles (8 x 8 registers each)
+#   v[168:231]               B fragments, ONE set: slot ni is refilled with the next tile's B[ni] once this tile's 8
+#                            MFMAs on it are issued (the MFMAs run n-tile-major)
+#   v[232:239] read bases (as bf16), v240 the unit scales
+# per K tile t (stage S = t & 1), gaps = "after MFMA i", i < 64:
+#   0, 1        B[7](t) (its slot was busy until the previous tile's last MFMA)
+#   6           s_waitcnt lgkmcnt(0); s_barrier     every wave holds all of tile t in registers: stage S is free
+#   7 .. 44     the 16 LDS-DMA pieces of tile t+2 -> stage S, every 2.5 gaps (= 80 cycles, what bf16 'spread' settled on)
+#   46          s_waitcnt vmcnt(16); s_barrier      tile t+1 landed for every wave (>= 60 gaps = 1.9 k cycles after its last piece)
+#   47 .. 61    A[0..7](t+1) -> the other A set, B[0..5](t+1) -> their slots (two reads per gap), B[6] after MFMA 55
+#   62          s_waitcnt lgkmcnt(0)
+FA = (40, 104)
+FB = 168
+FRB = 232
+FSCALE = 240
+
+
+def f8(base, i):
+    return f"v[{base + 8 * i}:{base + 8 * i + 7}]"
+
+
+def mfma_fp8(i, aset):
+    ni, mi = i // 8, i % 8
+    return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {f8(FB, ni)}, {f8(FA[aset], mi)}, {acc(mi, ni)}, v{FSCALE}, v{FSCALE} "
+            f"op_sel_hi:[0,0,0]")
+
+
+def read_fp8(operand, idx, half, stage, aset=0):
+    """One ds_read_b128: half 0 = chunk (lane >> 4), half 1 = chunk 4 + (lane >> 4) of tile `idx` of operand 'a' / 'b'."""
+    base = (FA[aset] if operand == "a" else FB) + 8 * idx + 4 * half
+    reg = FRB + 4 * stage + (0 if operand == "a" else 2) + half
+    off = f" offset:{idx * 2048}" if idx else ""
+    return f"ds_read_b128 v[{base}:{base + 3}], v{reg}{off}"
+
+
+def tile_fp8(t, mode, landed=46, step2=5):
+    """`step2`: DMA spacing in half gaps (5 = every 2.5 gaps); `landed`: the gap of the wait for tile t+1."""
+    stage, aset = t & 1, t & 1
+    out = [f"; ---- fp8 K tile in stage {stage}, {mode}"]
+    after = {i: [] for i in range(64)}
+    after[0].append(read_fp8("b", 7, 0, stage))
+    after[1].append(read_fp8("b", 7, 1, stage))
+    after[6] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    if mode == "full":
+        for p in range(16):
+            i = 7 + (step2 * p) // 2
+            pre, main = dma(stage, p)
+            after[i - 1] += pre
+            after[i] += main
+        n_before = sum(1 for p in range(16) if 7 + (step2 * p) // 2 <= landed)
+        after[landed] = after[landed] + [f"s_waitcnt vmcnt({n_before})", "s_barrier"]
+    elif mode == "tail2":
+        after[landed] += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    if mode != "last":
+        # A[0..7](t+1) and B[0..4](t+1) (26 reads) over the gaps up to 59, then B[5] (slot free after MFMA 47) and B[6] (after 55)
+        nxt = [("a", j, h) for j in range(8) for h in (0, 1)] + [("b", j, h) for j in range(5) for h in (0, 1)]
+        span = 60 - (landed + 1)
+        for k, (op, j, h) in enumerate(nxt):
+            after[landed + 1 + (k * span) // len(nxt)].append(read_fp8(op, j, h, stage ^ 1, aset ^ 1))
+        for op, j, h in (("b", 5, 0), ("b", 5, 1)):
+            after[60].append(read_fp8(op, j, h, stage ^ 1))
+        for op, j, h in (("b", 6, 0), ("b", 6, 1)):
+            after[61].append(read_fp8(op, j, h, stage ^ 1))
+        # the next tile starts on A[*] and B[0]; B[5], B[6] (the last four reads, in order) may still be in flight
+        after[63].append("s_waitcnt lgkmcnt(4)")
+    for i in range(64):
+        out.append(mfma_fp8(i, aset))
+        out += after[i]
+    return out
+
+
+def body_fp8(**kw):
+    o = setup_lines(FRB, FSCALE)
+    o += ["; ==== prologue: tiles 0 and 1 on their way, accumulators cleared meanwhile"]
+    for st in (0, 1):
+        for p in range(16):
+            pre, main = dma(st, p)
+            o += pre + ["s_nop 0"] + main
+    for i in range(256):
+        o.append(f"v_accvgpr_write_b32 a{i}, 0")
+    o += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    for j in range(8):
+        o += [read_fp8("a", j, 0, 0, 0), read_fp8("a", j, 1, 0, 0)]
+    for j in range(7):                    # B[7] is read by the tile itself, like every tile's
+        o += [read_fp8("b", j, 0, 0), read_fp8("b", j, 1, 0)]
+    o += ["s_waitcnt lgkmcnt(0)", "; ==== main loop: two K tiles per pass", "1:"]
+    o += tile_fp8(0, "full", **kw) + tile_fp8(1, "full", **kw)
+    o += ["s_sub_u32 s88, s88, 1", "s_cmp_lg_u32 s88, 0", "s_cbranch_scc1 1b"]
+    o += tile_fp8(0, "tail2", **kw) + tile_fp8(1, "last", **kw)
+    o += epilogue_lines()
+    return o
+
+
 # macro suffix -> (schedule, ablations, dtype). The ablated streams keep a GEMM's timing, not its result.
 BODIES = {"": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEBAR": ("one_barrier", (), "bf16"),
           "_PEROP": ("per_operand", (), "bf16"),
           "_NODMA": ("spread", ("dma",), "bf16"), "_NOREAD": ("spread", ("read",), "bf16"), "_L2ONLY": ("spread", ("bump",), "bf16"),
           "_MFMAONLY": ("spread", ("dma", "read", "barrier"), "bf16"),
-          "_FP4": ("stagger", (), "fp4")}
+          "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"), "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8")}
 
 
 def main():
@@ -267,7 +375,7 @@ def main():
     with open(out, "w") as f:
         f.write("// GENERATED by scripts/gen_gemm_quad_asm.py -- do not edit; the schedules are documented there.\n")
         for suffix, (sched, ablate, dtype) in BODIES.items():
-            lines = body(sched, ablate, dtype=dtype)
+            lines = body_fp8(**dict(ablate)) if dtype == "fp8" else body(sched, ablate, dtype=dtype)
             f.write(f"#define KLM_QUAD_ASM_BODY{suffix} \\\n")
             for ln in lines:
                 f.write('  "%s\\n\\t" \\\n' % ln.replace('"', '\\"'))

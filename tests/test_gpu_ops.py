@@ -66,22 +66,25 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
             assert torch.equal(ops.gemm_bf16(a, b, variant=v), c0)   # a ring-buffer race would show as a rare diff
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096)])
+@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096), (256, 512, 512), (768, 256, 4608)])
 def test_gemm_fp8_matches_fp32_reference(env, shape):
     torch, ops, dev = env
     M, N, K = shape
     torch.manual_seed(K)
     a = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
     b = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.float8_e4m3fn)
-    c = ops.gemm_fp8(a, b)
+    c = ops.gemm_fp8(a, b)                               # the hand-scheduled stream where K allows, else the ring kernel
     ref = a.float() @ b.float().t()                      # the fp8 VALUES are exact in fp32
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=2e-3 * K ** 0.5)
-    assert torch.equal(c, ops.gemm_fp8(a, b, variant=0))   # both ring schedules: same order of accumulation, same bits
+    # every pipeline sums an element's products in the same order: same bits
+    assert torch.equal(c, ops.gemm_fp8(a, b, variant=0)) and torch.equal(c, ops.gemm_fp8(a, b, variant=1))
+    if K % 256 == 0 and K >= 512:
+        assert torch.equal(c, ops.gemm_fp8(a, b, variant=2)) and torch.equal(c, ops.gemm_fp8(a, b, variant=3))
 
 
 def test_gemm_fp8_exact_on_small_integers(env):
     torch, ops, dev = env
-    M, N, K = 256, 512, 384
+    M, N, K = 256, 512, 768
     g = torch.Generator(device=dev).manual_seed(11)
     a = torch.randint(-2, 3, (M, K), device=dev, generator=g).float()
     b = torch.randint(-2, 3, (N, K), device=dev, generator=g).float()

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A,
   const unsigned b0 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch0;
   const unsigned b1 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch1;
   // ... and where its 4 consecutive columns of an accumulator tile go in C
-  const unsigned vc = fr * ldc + fq * 8;
+  // (after the epilogue's lane exchange: 8 consecutive columns of n tile (pair + (fq & 1)), its half fq >> 1)
+  const unsigned vc = fr * ldc + (fq & 1) * 32 + (fq >> 1) * 16;
 #define KLM_QUAD_ASM(BODY_TEXT)                                                                                                \
   asm volatile(BODY_TEXT                                                                                                       \
                :                                                                                                               \

@@ -17,10 +17,9 @@ for K in Ks:
     c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     one = torch.ones((), device=dev)
     bt, b8t = b.t(), b8.t()
-    cands = {"bf16_klm": lambda: ops.gemm_bf16(a, b, out=c, variant=2), "bf16_quad": lambda: ops.gemm_bf16(a, b, out=c, variant=3), "bf16_asm_spread": lambda: ops.gemm_bf16(a, b, out=c, variant=6),
-             "bf16_asm_stagger": lambda: ops.gemm_bf16(a, b, out=c, variant=8),
+    cands = {"bf16_klm": lambda: ops.gemm_bf16(a, b, out=c, variant=2), "bf16_quad": lambda: ops.gemm_bf16(a, b, out=c, variant=3), "bf16_asm": lambda: ops.gemm_bf16(a, b, out=c, variant=4),
              "bf16_vendor": lambda: torch.matmul(a, bt, out=c),
-             "fp8_klm": lambda: ops.gemm_fp8(a8, b8, out=c), "fp8_vendor": lambda: torch._scaled_mm(a8, b8t, scale_a=one, scale_b=one, out_dtype=torch.bfloat16)}
+             "fp8_klm": lambda: ops.gemm_fp8(a8, b8, out=c, variant=1), "fp8_asm": lambda: ops.gemm_fp8(a8, b8, out=c, variant=2), "fp8_vendor": lambda: torch._scaled_mm(a8, b8t, scale_a=one, scale_b=one, out_dtype=torch.bfloat16)}
     iters = max(10, int(40 * 8192 / K))
     runs = {k: [] for k in cands}
     for r in range(6):
@@ -45,4 +44,6 @@ for name in res[Ks[0]]:
                  "tflops_at_8192": round(2.0 * M * N * 8192 / res[8192][name] / 1e6, 1)}
     print(name, fit[name], flush=True)
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gemm_k_scaling.json"
+_o = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/out.json"
+os.makedirs(os.path.dirname(_o) or ".", exist_ok=True)
 json.dump({"M": M, "N": N, "us": res, "fit": fit}, open(out, "w"), indent=1)

@@ -44,4 +44,6 @@ for r in range(6):
 out = {"bit_equal": ok, "tflops": {k: {"median": sorted(v)[len(v) // 2], "min": min(v), "max": max(v)} for k, v in runs.items()}}
 for k, v in out["tflops"].items():
     print(k, {x: round(y, 1) for x, y in v.items()}, flush=True)
+_o = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/out.json"
+os.makedirs(os.path.dirname(_o) or ".", exist_ok=True)
 json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/quad_asm_ablate.json", "w"), indent=1)

@@ -179,20 +179,29 @@ def setup_lines(RB, SCALE):
 
 
 def epilogue_lines():
-    o = []
-    o += ["; ==== epilogue: fp32 -> bf16, 8 bytes per lane and tile", "s_nop 15", "s_nop 15", "s_mov_b32 s94, 0", "s_lshl_b32 s95, %[ldc], 4"]
+    """fp32 -> bf16 and out, 16 bytes per lane and PAIR of n tiles. A lane holds 4 consecutive columns of one row per tile
+    (8 bytes); v_permlane16_swap_b32 exchanges the odd 16-lane rows of tile ni's registers with the even rows of tile
+    ni+1's, after which lanes with (lane >> 4) even hold 8 consecutive columns of tile ni and the odd ones of tile ni+1:
+    one buffer_store_dwordx4 per pair, 64 contiguous bytes per output row and instruction. The store tail is bound by
+    the NUMBER of store instructions (64 x dwordx2 per lane took ~10 us per round of output tiles: a fifth of an
+    8192 x 8192 x 1024 GEMM), so halving it is worth more than the extra VALU."""
+    o = ["; ==== epilogue", "s_nop 15", "s_nop 15", "s_mov_b32 s94, 0", "s_lshl_b32 s95, %[ldc], 4"]
     t = 0
     for mi in range(8):
-        for ni in range(8):
+        for ni in range(0, 8, 2):
             r = A0 + 8 * (t % 8)
-            b = 4 * (8 * mi + ni)
-            o += [f"v_accvgpr_read_b32 v{r}, a{b}", f"v_accvgpr_read_b32 v{r + 1}, a{b + 1}",
-                  f"v_accvgpr_read_b32 v{r + 2}, a{b + 2}", f"v_accvgpr_read_b32 v{r + 3}, a{b + 3}",
-                  f"v_cvt_pk_bf16_f32 v{r}, v{r}, v{r + 1}", f"v_cvt_pk_bf16_f32 v{r + 1}, v{r + 2}, v{r + 3}",
-                  f"buffer_store_dwordx2 v[{r}:{r + 1}], %[vc], s[72:75], s94 offen offset:{ni * 32}"]
+            x, y = 4 * (8 * mi + ni), 4 * (8 * mi + ni + 1)
+            o += [f"v_accvgpr_read_b32 v{r + k}, a{x + k}" for k in range(4)]
+            o += [f"v_accvgpr_read_b32 v{r + 4 + k}, a{y + k}" for k in range(4)]
+            o += [f"v_cvt_pk_bf16_f32 v{r}, v{r}, v{r + 1}", f"v_cvt_pk_bf16_f32 v{r + 1}, v{r + 2}, v{r + 3}",
+                  f"v_cvt_pk_bf16_f32 v{r + 2}, v{r + 4}, v{r + 5}", f"v_cvt_pk_bf16_f32 v{r + 3}, v{r + 6}, v{r + 7}",
+                  "s_nop 1",                                   # VALU write -> permlane swap read: 2 wait states
+                  f"v_permlane16_swap_b32 v{r}, v{r + 2}", f"v_permlane16_swap_b32 v{r + 1}, v{r + 3}",
+                  f"buffer_store_dwordx4 v[{r}:{r + 3}], %[vc], s[72:75], s94 offen offset:{ni * 32}"]
             t += 1
         o.append("s_add_u32 s94, s94, s95")
-    o += ["s_waitcnt vmcnt(0)"]
+    # no wait for the stores: the wave may end with them in flight (the memory system owns them), and the CU gets its LDS
+    # back for the next workgroup that much earlier
     return o
 
 

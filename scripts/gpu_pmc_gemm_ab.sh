@@ -14,7 +14,7 @@ echo "=== kernel trace"
 timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 scripts/prof_gemm_ab.py > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }
 echo "=== lds pass (optional)"
 timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --output-format csv -d $O/pmc_lds -- python3 scripts/prof_gemm_ab.py > $O/pmc_lds.log 2>&1 || { tail -5 $O/pmc_lds.log; rm -rf $O/pmc_lds; }
-python3 scripts/summarize_pmc.py $O "gemm_bf16,gemm_mx,Cijk,gemm" > $O/pmc_summary.json 2> $O/summarize.err || { tail -5 $O/summarize.err; }
+python3 scripts/summarize_pmc.py $O "gemm_bf16,gemm_mx,gemm_quad,Cijk,gemm" > $O/pmc_summary.json 2> $O/summarize.err || { tail -5 $O/summarize.err; }
 find $O -name "*.csv" -size +3M -delete
 ls $O
 echo "=== done"

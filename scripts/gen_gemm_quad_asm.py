@@ -1,31 +1,30 @@
 #!/usr/bin/env python3
-"""Generates ops/csrc/gemm_quad_asm.inc: the hand-scheduled gfx950 instruction stream of the 4-wave 256 x 256 bf16 GEMM
-(`gemm_bf16_quad_asm` in gemm_bf16.hip) as one inline-asm body.
+"""Generates ops/csrc/gemm_quad_asm.inc: the hand-scheduled gfx950 instruction streams of the 4-wave 256 x 256 GEMM kernels
+(`gemm_quad_asm<BODY>` in ops/csrc/gemm_quad_asm.h; bf16, fp4 and fp8) as inline-asm bodies.
 
 Why generated text and not HIP source: with one wave per SIMD there is no partner wave to hide anything behind, so the
 order of the wave's own instruction stream IS the schedule. Written as HIP (gemm_quad128.h: builtins or per-MFMA asm
 statements pinned with sched_barrier) the compiler still decides the waits and the interleave, and that kernel reached
-0.75 MFMA-busy; the vendor's hand-written kernel of the same geometry reaches 0.88 (profiles/r2_prof). Here every
-instruction's place is fixed:
+0.75 MFMA-busy; the vendor's hand-written kernel of the same geometry reaches 0.86 - 0.88. Here every instruction's place
+is fixed. The shipped bf16 / fp4 schedule ("stagger", see SCHEDULES for the others and docs/KERNELS.md for what each measured):
 
-  per K tile (stage S, 128 MFMAs, m-tile-major so consecutive MFMAs share the A fragment):
-    after MFMA 0,2,..,14     the 8 B fragments of this tile's k-step 1 -> fragment set 1
-    after MFMA 20            s_waitcnt lgkmcnt(0); s_barrier       (#1: every wave is done with the B half of stage S)
-    after MFMA 21,23,..,35   LDS-DMA: the 8 B pieces of tile t+2 -> stage S
-    after MFMA 22,24,..,36   the 8 A fragments of k-step 1 -> set 1
-    after MFMA 46            s_waitcnt lgkmcnt(0); s_barrier       (#2: done with the A half)
-    after MFMA 47,49,..,61   LDS-DMA: the 8 A pieces of tile t+2
-    after MFMA 87            s_waitcnt vmcnt(16); s_barrier        (#3: tile t+1 landed, for every wave)
-    after MFMA 88,90,..,118  the 16 fragments of tile t+1's k-step 0 -> set 0
-    after MFMA 126           s_waitcnt lgkmcnt(0)
-  never more than one memory instruction in an MFMA gap. (First version: one barrier for both halves at MFMA 40, DMA
-  from 41 on, the wait for tile t+1 at MFMA 63: 1506 TFLOP/s at 8192^3, no better than the compiler-scheduled
-  gemm_quad128.h -- the DMA had only ~2 k cycles to land.)
+  per K tile (stage S, 128 MFMAs, m-tile-major so consecutive MFMAs share the A fragment), gap = "after MFMA i":
+    0, 2, .., 30       the 16 ds_read_b128 of this tile's k-step 1 -> fragment set 1 (A[0], B[0..7], A[1..7])
+    36                 s_waitcnt lgkmcnt(0); s_barrier      every wave is done reading stage S
+    39 + 5 p + w       LDS-DMA piece p (0..7 A, 8..15 B) of tile t+2 -> stage S, for wave w: one per FIVE MFMAs (closer
+                       costs up to 13 %; further apart gains nothing), one gap later per wave (the lockstep waves do not
+                       hand their DMA to the texture-address unit in the same cycle)
+    85                 s_waitcnt vmcnt(#pieces issued so far); s_barrier     tile t+1 landed, for every wave
+    86, 88, ..         the 16 fragments of tile t+1's k-step 0 -> set 0, skipping the DMA gaps
+    126                s_waitcnt lgkmcnt(0)
+  An M0 write sits one gap before the DMA that uses it (SALU write of M0 -> LDS-DMA needs a wait state).
+  Epilogue: fp32 -> bf16, v_permlane16_swap_b32 pairs n tiles so every store is 16 bytes per lane (epilogue_lines).
+  fp8 has its own register plan and tile (tile_fp8).
 
 Registers (fixed, all on the asm statement's clobber list):
   a[0:255]        accumulators, tile (mi, ni) at a[4 (8 mi + ni)]
-  v[40:71]        A fragments set 0 (k-step 0), v[72:103] B set 0, v[104:135] A set 1, v[136:167] B set 1
-  v[168:175]      ds_read bases: stage 0 {a k0, a k1, b k0, b k1}, stage 1 the same + 64 KiB
+  v[40:71]        A fragments set 0 (k-step 0), v[72:103] B set 0, v[104:135] A set 1, v[136:167] B set 1   (bf16 / fp4)
+  v[168:175]      ds_read bases: stage 0 {a k0, a k1, b k0, b k1}, stage 1 the same + 64 KiB; v176 fp4 unit scales
   s[64:67] A descriptor, s[68:71] B, s[72:75] C; s[81:87] piece offsets p * 8 * lda; s88 loop count;
   s[90:93] LDS-DMA bases {A stage 0, B stage 0, A stage 1, B stage 1}; s[94:95] scratch
 """

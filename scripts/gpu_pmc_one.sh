@@ -6,7 +6,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for pass in mfma stall; do
   C=$(python3 -c "from k8s_llm_monitor_amd.validation.rocprof import PASSES; print(' '.join(PASSES['$pass']))")
-  timeout -s KILL 150 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$pass -- python3 scripts/prof_gemm_one.py > $O/pmc_$pass.log 2>&1 || { tail -5 $O/pmc_$pass.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$pass -- python3 ${KLM_PROF_SCRIPT:-scripts/prof_gemm_one.py} > $O/pmc_$pass.log 2>&1 || { tail -5 $O/pmc_$pass.log; exit 1; }
 done
 python3 scripts/summarize_pmc.py $O "gemm_bf16,gemm_mx,Cijk,gemm" > $O/pmc_summary.json 2> $O/summarize.err
 python3 - <<PY

@@ -235,8 +235,9 @@ int main(int argc, char** argv) {
 
   auto launch = [&]() -> int {
     // the hand-scheduled 4-wave streams where the shape allows (bf16, fp8: any multiple of 256; fp4: of 512), else the ring kernels
-    if (fp4) return klm_gemm_fp4(A, B, C, a.size, a.size, a.size, (a.size % 512 == 0 && a.size >= 1024) ? 2 : 1, s);
-    if (gemm) return fp8 ? klm_gemm_fp8(A, B, C, a.size, a.size, a.size, a.size >= 512 ? 2 : 1, s) : klm_gemm_bf16(A, B, C, a.size, a.size, a.size, 4, s);
+    // the persistent hand-scheduled streams (bf16 8, fp8 4, fp4 3) where the size allows, else the ring kernels
+    if (fp4) return klm_gemm_fp4(A, B, C, a.size, a.size, a.size, (a.size % 512 == 0 && a.size >= 1024) ? 3 : 1, s);
+    if (gemm) return fp8 ? klm_gemm_fp8(A, B, C, a.size, a.size, a.size, a.size >= 512 ? 4 : 1, s) : klm_gemm_bf16(A, B, C, a.size, a.size, a.size, 8, s);
     if (a.kind == "hbm_copy") return klm_hbm_copy(Y, X, (size_t)2 << 30, s);
     if (a.kind == "hbm_read") return klm_hbm_read(X, (size_t)2 << 30, sink, s);
     if (a.kind == "hbm_fill") return klm_hbm_fill(X, (size_t)2 << 30, 0x5A5A5A5Au, s);

@@ -51,6 +51,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         vp, i, sz, u32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64
         lib.klm_gemm_bf16.argtypes = [vp, vp, vp, i, i, i, i, vp]
         lib.klm_gemm_bf16.restype = i
+        lib.klm_gemm_persistent_grid.argtypes = [i]
+        lib.klm_gemm_persistent_grid.restype = i
         if hasattr(lib, "klm_gemm_fp8"):
             lib.klm_gemm_fp8.argtypes = [vp, vp, vp, i, i, i, i, vp]
             lib.klm_gemm_fp8.restype = i
@@ -109,10 +111,12 @@ def version() -> str:
 def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
 
-    variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream (4) for whole
+    variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream in its persistent
+    form (8: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue) for whole
     256 x 256 tiles and an even number of K tiles >= 4, else the 8-wave ring kernel (2, or 1 for an odd tile count), else
-    the 128x128 one (0). 3: the compiler-scheduled 4-wave kernel (gemm_quad128.h); 5..7: earlier placements of the
-    hand-scheduled stream; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
+    the 128x128 one (0). 4: the same stream, one workgroup per tile; 3: the compiler-scheduled 4-wave kernel
+    (gemm_quad128.h); 5..7: earlier placements of the hand-scheduled stream; 44..47: stream 4 with cache-policy bits on
+    its LDS-DMA; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
     """
     import torch
     _require_cuda(a, b)
@@ -124,7 +128,7 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     N = b.shape[0]
     if variant is None:
         if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
-            variant = 4 if (K % 128 == 0 and K >= 256) else 1      # an even number of K tiles >= 4, else the ring's schedule 0
+            variant = 8 if (K % 128 == 0 and K >= 256) else 1      # an even number of K tiles >= 4, else the ring's schedule 0
         else:
             variant = 0
     if out is None:
@@ -139,10 +143,18 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     return out
 
 
+def gemm_persistent_grid(grid: int = -1) -> int:
+    """Workgroup count of the persistent GEMM kernels (bf16 variant 8, fp8 4, fp4 3): 0 = one per CU (the default), a
+    positive value for tests that want several output tiles per workgroup on a small problem; < 0 only reads.
+    Returns the previous setting."""
+    return int(load().klm_gemm_persistent_grid(int(grid)))
+
+
 def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the MX-scaled MFMA.
-    variant None: the hand-scheduled 4-wave stream (2) when K is a multiple of 256 and >= 512, else the ring kernel
-    (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 3: another placement of stream 2."""
+    variant None: the hand-scheduled 4-wave stream in its persistent form (4) when K is a multiple of 256 and >= 512, else
+    the ring kernel (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 2: the stream with one
+    workgroup per tile; 3: another placement of stream 2."""
     import torch
     _require_cuda(a, b)
     if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
@@ -152,7 +164,7 @@ def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     M, K = a.shape
     N = b.shape[0]
     if variant is None:
-        variant = 2 if (K % 256 == 0 and K >= 512) else 1
+        variant = 4 if (K % 256 == 0 and K >= 512) else 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()
@@ -180,8 +192,9 @@ def fp4_decode(packed):
 def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] (bf16) = A[M,K] @ B[N,K].T`` with e2m1 (fp4) inputs packed two per byte:
     `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2].
-    variant None: the hand-scheduled 4-wave stream (2) when the packed row is a multiple of 256 bytes and >= 512, else
-    the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0)."""
+    variant None: the hand-scheduled 4-wave stream in its persistent form (3) when the packed row is a multiple of 256
+    bytes and >= 512, else the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0). 2: the stream with
+    one workgroup per tile."""
     import torch
     _require_cuda(a, b)
     ok = (torch.uint8, getattr(torch, "float4_e2m1fn_x2", torch.uint8))
@@ -192,7 +205,7 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     M, Kb = a.shape
     N = b.shape[0]
     if variant is None:
-        variant = 2 if (Kb % 256 == 0 and Kb >= 512) else 1
+        variant = 3 if (Kb % 256 == 0 and Kb >= 512) else 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()

@@ -317,6 +317,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_quad(const uint16_t* __restrict
     }
 }
 
+// tests only: workgroup count of the persistent kernels (0 = one per CU)
+extern "C" int klm_gemm_persistent_grid(int grid) {
+  const int before = klm_quad_p_grid_override();
+  if (grid >= 0) klm_quad_p_grid_override() = grid;
+  return before;
+}
+
 extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                              void* stream) {
   if (!A || !B || !C) return KLM_ERR_ARG;
@@ -335,7 +342,11 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     if (int e = klm_ensure_dyn_lds<gemm_bf16_quad>(KLM_QUAD_LDS_BYTES)) return e;
     hipLaunchKernelGGL(gemm_bf16_quad, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, (const uint16_t*)A,
                        (const uint16_t*)B, (uint16_t*)C, M, N, K);
-  } else if ((variant >= 4 && variant <= 7) || (variant >= 40 && variant <= 43)) {
+  } else if (variant == 8) {
+    // the persistent form of stream 4: one workgroup per CU, the next output tile's operands fetched under the epilogue
+    if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
+    if (int e = klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s)) return e;
+  } else if ((variant >= 4 && variant <= 7) || (variant >= 40 && variant <= 47)) {
     // hand-scheduled streams (gemm_quad_asm.h): 4 the kernel; 5..7 earlier placements; 40..43 diagnostic, results meaningless
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
     int e = KLM_OK;
@@ -347,7 +358,11 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
       case 40: e = klm_launch_quad_asm<10>(A, B, C, M, N, K * 2, s); break;
       case 41: e = klm_launch_quad_asm<11>(A, B, C, M, N, K * 2, s); break;
       case 42: e = klm_launch_quad_asm<12>(A, B, C, M, N, K * 2, s); break;
-      default: e = klm_launch_quad_asm<13>(A, B, C, M, N, K * 2, s); break;
+      case 43: e = klm_launch_quad_asm<13>(A, B, C, M, N, K * 2, s); break;
+      case 44: e = klm_launch_quad_asm<14>(A, B, C, M, N, K * 2, s); break;   // 44..47: cache bits on the LDS-DMA
+      case 45: e = klm_launch_quad_asm<15>(A, B, C, M, N, K * 2, s); break;
+      case 46: e = klm_launch_quad_asm<16>(A, B, C, M, N, K * 2, s); break;
+      default: e = klm_launch_quad_asm<17>(A, B, C, M, N, K * 2, s); break;
     }
     if (e) return e;
   } else if (variant == 1 || variant == 2) {

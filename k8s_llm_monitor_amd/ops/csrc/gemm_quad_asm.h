@@ -12,7 +12,8 @@
 
 // BODY: 0 the bf16 kernel (schedule "stagger"); 1..3 earlier placements of the same instructions (spread, one_barrier,
 // per_operand), kept for the A/B record; 10..13 diagnostic streams without the loop's DMA / fragment reads / K advance
-// (DMA from L2 only) / all of it (results meaningless: they price each kind of instruction); 20 the fp4 kernel; 30 the fp8 kernel.
+// (DMA from L2 only) / all of it (results meaningless: they price each kind of instruction); 14..17 stream 0 with cache-policy
+// bits sc0 / sc1 / nt / sc1 nt on its LDS-DMA (right results; an experiment); 20 the fp4 kernel; 30 the fp8 kernel.
 // Kb: the operands' row length in BYTES (bf16: 2 K, fp4: K / 2); a K tile is 128 bytes of a row in every format.
 template <int BODY>
 __global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A, const void* __restrict__ B,
@@ -66,6 +67,10 @@ __global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A,
   else if constexpr (BODY == 11) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_NOREAD);
   else if constexpr (BODY == 12) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_L2ONLY);
   else if constexpr (BODY == 13) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_MFMAONLY);
+  else if constexpr (BODY == 14) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_SC0);
+  else if constexpr (BODY == 15) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_SC1);
+  else if constexpr (BODY == 16) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_NT);
+  else if constexpr (BODY == 17) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_SC1NT);
   else if constexpr (BODY == 20) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_FP4);
   else if constexpr (BODY == 30) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_FP8);
   else KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_FP8B);
@@ -76,6 +81,102 @@ template <int BODY>
 static int klm_launch_quad_asm(const void* A, const void* B, void* C, int M, int N, int Kb, hipStream_t s) {
   if (int e = klm_ensure_dyn_lds<gemm_quad_asm<BODY>>(KLM_QUAD_LDS_BYTES)) return e;
   hipLaunchKernelGGL(gemm_quad_asm<BODY>, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, A, B, (uint16_t*)C, M, N, Kb);
+  return KLM_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Persistent form: `grid` workgroups (one per CU) each walk output tiles bid, bid + grid, .. -- the tile -> XCD / round
+// map of the kernel above under in-order dispatch -- as ONE stream of K tiles: the last pass of an output tile already
+// fetches the next tile's first two K tiles, so the epilogue's stores (32 MB per round on the chip) never sit in front of
+// a cold prologue, and launch / argument loads / set-up are paid once per CU (generator: body_p).
+// The HIP part writes this workgroup's tile table behind the two LDS stages: {A rows, B rows, C} addresses per tile.
+// BODY: 0 bf16, 20 fp4, 30 fp8.
+// ------------------------------------------------------------------------------------
+#define KLM_QUAD_P_MAX_TILES 512     // per workgroup: 16 KiB of table
+template <int BODY>
+__global__ __launch_bounds__(256) void gemm_quad_asm_p(const void* __restrict__ A, const void* __restrict__ B,
+                                                       uint16_t* __restrict__ C, int M, int N, int Kb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const unsigned lda = (unsigned)Kb, ldc = (unsigned)N * 2;
+  const int tiles_m = M >> 8, tiles_n = N >> 8, ntiles = tiles_m * tiles_n, grid = (int)gridDim.x;
+  const int mine = (ntiles - (int)blockIdx.x + grid - 1) / grid;          // >= 1: the launcher keeps grid <= ntiles
+  uint4* table = reinterpret_cast<uint4*>(smem + KLM_QUAD_LDS_BYTES);
+  for (int i = tid; i < mine; i += 256) {
+    int tm, tn;
+    tile_of_block<8>((int)blockIdx.x + i * grid, tiles_m, tiles_n, tm, tn);
+    const uint64_t pa = reinterpret_cast<uint64_t>(A) + (uint64_t)(tm << 8) * lda;
+    const uint64_t pb = reinterpret_cast<uint64_t>(B) + (uint64_t)(tn << 8) * lda;
+    const uint64_t pc = reinterpret_cast<uint64_t>(C) + (uint64_t)(tm << 8) * ldc + (uint64_t)(tn << 8) * 2;
+    table[2 * i] = make_uint4((unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, (unsigned)pb, (unsigned)(pb >> 32) & 0xffffu);
+    table[2 * i + 1] = make_uint4((unsigned)pc, (unsigned)(pc >> 32) & 0xffffu, 0u, 0u);
+  }
+  __syncthreads();
+  auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  // this wave's part of a tile: it stages rows [64 wid, 64 wid + 64) of both operands and owns a 128 x 128 part of C
+  const unsigned dab = uni((unsigned)wid * 64u * lda), dc = uni((unsigned)wr * 128u * ldc + (unsigned)wc * 256u);
+  const unsigned ra2 = uni(64u * lda), rc2 = uni(128u * ldc), r3 = 0x00020000u;
+  const unsigned ldsbase = (unsigned)(uintptr_t)(KLM_AS3 char*)smem;
+  const unsigned lw = uni(ldsbase + (unsigned)wid * 8192u);
+  const unsigned passes = uni((unsigned)(Kb >> 7) >> 1);
+  const unsigned ntl = uni((unsigned)mine);
+  const unsigned tbl = ldsbase + KLM_QUAD_LDS_BYTES;
+  const unsigned srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const unsigned va = srow * lda + schunk * 16;
+  const unsigned fr = lane & 15, fq = lane >> 4, key = lane & 7;
+  const unsigned ch0 = ((fq ^ key) << 4), ch1 = (((4 + fq) ^ key) << 4);
+  const unsigned a0 = ldsbase + ((unsigned)wr * 128 + fr) * 128 + ch0, a1 = ldsbase + ((unsigned)wr * 128 + fr) * 128 + ch1;
+  const unsigned b0 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch0;
+  const unsigned b1 = ldsbase + KLM_QUAD_B_OFFSET + ((unsigned)wc * 128 + fr) * 128 + ch1;
+  const unsigned vc = fr * ldc + (fq & 1) * 32 + (fq >> 1) * 16;
+#define KLM_QUAD_ASM_P(BODY_TEXT)                                                                                              \
+  asm volatile(BODY_TEXT                                                                                                       \
+               :                                                                                                               \
+               : [ra2] "s"(ra2), [ra3] "s"(r3), [rc2] "s"(rc2), [lda] "s"(lda), [ldc] "s"(ldc), [passes] "s"(passes),           \
+                 [lw] "s"(lw), [wid] "s"(wid), [dab] "s"(dab), [dc] "s"(dc), [ntl] "s"(ntl), [tbl] "v"(tbl), [va] "v"(va),        \
+                 [vc] "v"(vc), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1)                                            \
+               : KLM_QUAD_ASM_CLOBBERS)
+  if constexpr (BODY == 0) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P);
+  else if constexpr (BODY == 20) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP4);
+  else KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP8);
+#undef KLM_QUAD_ASM_P
+}
+
+// tests: a fixed workgroup count (0 = one per CU), so that a small problem walks several tiles per workgroup on any device
+inline int& klm_quad_p_grid_override() {
+  static int g = 0;
+  return g;
+}
+
+// one workgroup per CU of the current device (queried once per device)
+static int klm_quad_p_grid(int ntiles) {
+  if (const int g = klm_quad_p_grid_override(); g > 0) {
+    const int need = (ntiles + KLM_QUAD_P_MAX_TILES - 1) / KLM_QUAD_P_MAX_TILES;
+    return g > ntiles ? ntiles : (g < need ? need : g);
+  }
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  int n = __atomic_load_n(&cus[dev], __ATOMIC_ACQUIRE);
+  if (!n) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
+    __atomic_store_n(&cus[dev], n, __ATOMIC_RELEASE);
+  }
+  int grid = ntiles < n ? ntiles : n;
+  const int need = (ntiles + KLM_QUAD_P_MAX_TILES - 1) / KLM_QUAD_P_MAX_TILES;
+  return grid < need ? need : grid;
+}
+
+template <int BODY>
+static int klm_launch_quad_asm_p(const void* A, const void* B, void* C, int M, int N, int Kb, hipStream_t s) {
+  const int ntiles = (M >> 8) * (N >> 8), grid = klm_quad_p_grid(ntiles);
+  if (grid <= 0) return KLM_ERR_HIP;
+  const int lds = KLM_QUAD_LDS_BYTES + 32 * KLM_QUAD_P_MAX_TILES;
+  if (int e = klm_ensure_dyn_lds<gemm_quad_asm_p<BODY>>(lds)) return e;
+  const int per = (ntiles + grid - 1) / grid;
+  hipLaunchKernelGGL(gemm_quad_asm_p<BODY>, dim3(grid), dim3(256), KLM_QUAD_LDS_BYTES + 32 * per, s, A, B, (uint16_t*)C, M, N, Kb);
   return KLM_OK;
 }
 

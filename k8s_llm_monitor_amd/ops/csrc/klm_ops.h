@@ -46,6 +46,10 @@ int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int
 int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                  void* stream);
 
+// Persistent GEMM variants (bf16 variant 8, fp8 variant 4, fp4 variant 3): one workgroup per CU walks its output tiles.
+// Tests: set a fixed workgroup count (0 = one per CU; < 0 = only read); returns the previous setting.
+int klm_gemm_persistent_grid(int grid);
+
 // HBM helpers. `bytes` must be a multiple of 16 and pointers 16-byte aligned.
 int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream);   // write-only
 int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stream);    // read+write

@@ -47,18 +47,21 @@ def frag(base, i):
 NMAJOR = False      # True: consecutive MFMAs share the B fragment (the instruction's FIRST source) instead of the A fragment
 DTYPE = "bf16"      # or "fp4": same 16-byte fragments and K tile of 128 bytes per row, the MX-scaled MFMA with unit scales
 SCALE = 176         # fp4: VGPR holding four E8M0 scales of 2^0
+DMA_CACHE = ""      # cache-policy bits on the LDS-DMA (" sc0", " sc1", " nt", ..): experiment bodies only
 
 
-def mfma(i):
-    """MFMA i of a K tile: k-step i // 64, m tile (i % 64) // 8, n tile i % 8 (NMAJOR: the roles of m and n swapped)."""
+def mfma(i, czero=False):
+    """MFMA i of a K tile: k-step i // 64, m tile (i % 64) // 8, n tile i % 8 (NMAJOR: the roles of m and n swapped).
+    czero: an output tile's first K tile -- k-step 0 adds to the constant 0 instead of the accumulator (no clearing pass)."""
     ks, mi, ni = i // 64, (i % 64) // 8, i % 8
     if NMAJOR:
         mi, ni = ni, mi
     a, b = (A0, B0) if ks == 0 else (A1, B1)
+    c = "0" if (czero and ks == 0) else acc(mi, ni)
     if DTYPE == "fp4":
-        return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {acc(mi, ni)}, v{SCALE}, v{SCALE} "
+        return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {c}, v{SCALE}, v{SCALE} "
                 f"op_sel_hi:[0,0,0] cbsz:4 blgp:4")
-    return f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {acc(mi, ni)}"
+    return f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {c}"
 
 
 def read(setno, stage, j):
@@ -83,7 +86,7 @@ def dma(stage, p):
     rs = "s[64:67]" if op == "A" else "s[68:71]"
     pre = [f"s_mov_b32 m0, s{90 + 2 * stage + (0 if op == 'A' else 1)}"] if q == 0 else ["s_add_u32 m0, m0, 0x400"]
     so = "0" if q == 0 else f"s{80 + q}"
-    main = [f"buffer_load_dwordx4 %[va], {rs}, {so} offen lds"]
+    main = [f"buffer_load_dwordx4 %[va], {rs}, {so} offen{DMA_CACHE} lds"]
     if q == 7:
         lo = 64 if op == "A" else 68
         main += [f"s_add_u32 s{lo}, s{lo}, 0x80", f"s_addc_u32 s{lo + 1}, s{lo + 1}, 0"]
@@ -98,7 +101,7 @@ def read_a(setno, stage, j):
     return read(setno, stage, 0 if j == 0 else 8 + j)     # A[j]
 
 
-def tile(stage, mode, sched="one_barrier", ablate=(), wave=0):
+def tile(stage, mode, sched="one_barrier", ablate=(), wave=0, czero=False):
     """mode: 'full' (issues tile t+2), 'tail2' (tile nt-2: no DMA), 'last' (tile nt-1: no DMA, no next reads).
     sched: where the pieces go (see SCHEDULES). ablate: diagnostic builds that drop 'dma', 'read' or 'barrier'
     instructions from the loop (wrong results, right timing: what each kind of instruction costs)."""
@@ -138,7 +141,7 @@ def tile(stage, mode, sched="one_barrier", ablate=(), wave=0):
     if "barrier" in ablate:
         drop += ["s_barrier"]
     for i in range(128):
-        out.append(mfma(i))
+        out.append(mfma(i, czero))
         out += [x for x in after[i] if not any(x.startswith(d) for d in drop)]
     return out
 
@@ -177,8 +180,9 @@ def setup_lines(RB, SCALE):
     return o
 
 
-def epilogue_lines():
-    """fp32 -> bf16 and out, 16 bytes per lane and PAIR of n tiles. A lane holds 4 consecutive columns of one row per tile
+def epilogue_lines(tmp=A0):
+    """(`tmp`: first of 64 scratch registers.)
+    fp32 -> bf16 and out, 16 bytes per lane and PAIR of n tiles. A lane holds 4 consecutive columns of one row per tile
     (8 bytes); v_permlane16_swap_b32 exchanges the odd 16-lane rows of tile ni's registers with the even rows of tile
     ni+1's, after which lanes with (lane >> 4) even hold 8 consecutive columns of tile ni and the odd ones of tile ni+1:
     one buffer_store_dwordx4 per pair, 64 contiguous bytes per output row and instruction. The store tail is bound by
@@ -188,7 +192,7 @@ def epilogue_lines():
     t = 0
     for mi in range(8):
         for ni in range(0, 8, 2):
-            r = A0 + 8 * (t % 8)
+            r = tmp + 8 * (t % 8)
             x, y = 4 * (8 * mi + ni), 4 * (8 * mi + ni + 1)
             o += [f"v_accvgpr_read_b32 v{r + k}, a{x + k}" for k in range(4)]
             o += [f"v_accvgpr_read_b32 v{r + 4 + k}, a{y + k}" for k in range(4)]
@@ -205,8 +209,9 @@ def epilogue_lines():
 
 
 def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
-    global NMAJOR, DTYPE
+    global NMAJOR, DTYPE, DMA_CACHE
     NMAJOR, DTYPE = nmajor, dtype
+    DMA_CACHE = "".join(" " + x[6:] for x in ablate if x.startswith("cache:"))
     o = setup_lines(RB, SCALE)
     o += ["; ==== prologue: tiles 0 and 1 on their way, accumulators cleared meanwhile"]
     for st in (0, 1):
@@ -244,10 +249,117 @@ def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
     return o
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# Persistent kernels: one workgroup per CU walks ITS output tiles (tile b, b + grid, ..: the same tile -> XCD / round map as
+# one workgroup per tile under in-order dispatch) and treats their K tiles as ONE stream. The LDS-DMA of the last pass of
+# an output tile fetches K tiles 0 and 1 of the NEXT output tile (the descriptors are switched just before that pass),
+# and its fragment reads load the next tile's first fragments, so the epilogue -- accumulators out, 32 MB of stores per
+# round on the chip -- runs with the next tile's operands already in LDS and registers instead of in front of a cold
+# prologue whose loads queue behind those stores; workgroup launch, argument loads and set-up are paid once.
+#   table (LDS, written by the HIP part): per output tile {A rows lo, hi, B rows lo, hi, C lo, hi, -, -} (32 bytes)
+#   v[TBL]      LDS address of the next table entry;  v[TBL+3 : TBL+10]  the entry just read
+#   s[96:97] next A, s[98:99] next B, s[76:77] next C (this wave's rows: + %[dab] / %[dab] / %[dc]; s100 up are reserved)
+#   s78 output tiles left (this one included), s80 num_records of the next tile's A / B descriptors: 0 when there is no
+#   next tile (those loads then fetch nothing)
+TBL_BF16, TBL_FP8 = 177, 241
+
+
+def fetch_next(tbl):
+    e = tbl + 3
+    return ["; ---- next output tile's bases from the table",
+            f"ds_read_b128 v[{e}:{e + 3}], v{tbl}", f"ds_read_b128 v[{e + 4}:{e + 7}], v{tbl} offset:16",
+            f"v_add_u32 v{tbl}, 32, v{tbl}", "s_waitcnt lgkmcnt(0)"] + \
+           [f"v_readfirstlane_b32 s{r}, v{e + k}" for k, r in enumerate((96, 97, 98, 99, 76, 77))] + \
+           ["s_add_u32 s96, s96, %[dab]", "s_addc_u32 s97, s97, 0", "s_add_u32 s98, s98, %[dab]", "s_addc_u32 s99, s99, 0",
+            "s_add_u32 s76, s76, %[dc]", "s_addc_u32 s77, s77, 0"]
+
+
+def setup_lines_p(RB, SCALE, tbl):
+    o = ["; ==== setup (persistent)", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s67, %[ra3]", "s_mov_b32 s70, %[ra2]", "s_mov_b32 s71, %[ra3]",
+         "s_mov_b32 s74, %[rc2]", "s_mov_b32 s75, %[ra3]",
+         "s_lshl_b32 s81, %[lda], 3", "s_lshl_b32 s82, %[lda], 4", "s_add_u32 s83, s82, s81", "s_lshl_b32 s84, %[lda], 5",
+         "s_add_u32 s85, s84, s81", "s_add_u32 s86, s84, s82", "s_add_u32 s87, s86, s81",
+         "s_mov_b32 s88, %[passes]", "s_mov_b32 s78, %[ntl]",
+         "s_mov_b32 s90, %[lw]", "s_add_u32 s91, s90, 0x8000", "s_add_u32 s92, s90, 0x10000", "s_add_u32 s93, s90, 0x18000",
+         f"v_mov_b32 v{RB}, %[a0]", f"v_mov_b32 v{RB + 1}, %[a1]", f"v_mov_b32 v{RB + 2}, %[b0]", f"v_mov_b32 v{RB + 3}, %[b1]",
+         f"v_add_u32 v{RB + 4}, 0x10000, v{RB}", f"v_add_u32 v{RB + 5}, 0x10000, v{RB + 1}",
+         f"v_add_u32 v{RB + 6}, 0x10000, v{RB + 2}", f"v_add_u32 v{RB + 7}, 0x10000, v{RB + 3}",
+         f"v_mov_b32 v{SCALE}, 0x7f7f7f7f", f"v_mov_b32 v{tbl}, %[tbl]"]
+    o += fetch_next(tbl)
+    o += ["s_mov_b32 s64, s96", "s_mov_b32 s65, s97", "s_mov_b32 s68, s98", "s_mov_b32 s69, s99", "s_mov_b32 s72, s76", "s_mov_b32 s73, s77"]
+    o += next_or_none(tbl, "first")
+    return o
+
+
+def next_or_none(tbl, tag):
+    """s78 = output tiles left including the current one: fetch the next one's bases, or make its loads empty."""
+    return ["s_mov_b32 s80, %[ra2]", "s_cmp_lg_u32 s78, 1", f"s_cbranch_scc1 Lklm%=_fetch_{tag}", "s_mov_b32 s80, 0",
+            f"s_branch Lklm%=_fetched_{tag}", f"Lklm%=_fetch_{tag}:"] + fetch_next(tbl) + [f"Lklm%=_fetched_{tag}:"]
+
+
+SWITCH = ["; ---- last pass of this output tile: its DMA fetches the next output tile's K tiles 0 and 1",
+          "s_mov_b32 s64, s96", "s_mov_b32 s65, s97", "s_mov_b32 s66, s80", "s_mov_b32 s68, s98", "s_mov_b32 s69, s99", "s_mov_b32 s70, s80"]
+
+
+def body_p(dtype="bf16", sched="stagger", **kw):
+    global NMAJOR, DTYPE, DMA_CACHE
+    NMAJOR, DTYPE, DMA_CACHE = False, dtype, ""
+    fp8 = dtype == "fp8"
+    rb, scale, tbl = (FRB, FSCALE, TBL_FP8) if fp8 else (RB, SCALE, TBL_BF16)
+    o = setup_lines_p(rb, scale, tbl)
+    o += ["; ==== prologue: K tiles 0 and 1 of the first output tile on their way"]
+    for st in (0, 1):
+        for p in range(16):
+            pre, main = dma(st, p)
+            o += pre + ["s_nop 0"] + main
+    o += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    if fp8:
+        for j in range(8):
+            o += [read_fp8("a", j, 0, 0, 0), read_fp8("a", j, 1, 0, 0)]
+        for j in range(7):
+            o += [read_fp8("b", j, 0, 0), read_fp8("b", j, 1, 0)]
+    else:
+        for j in range(16):
+            o.append(read(0, 0, j))
+    o += ["s_waitcnt lgkmcnt(0)", "Lklm%=_tile:"]
+    waves = list(range(4)) if (not fp8 and sched in PER_WAVE) else [0]
+    for w in waves[1:]:
+        o += [f"s_cmp_eq_u32 %[wid], {w}", f"s_cbranch_scc1 Lklm%=_w{w}"]
+
+    def one_pass(w, first):
+        if fp8:
+            return tile_fp8(0, "full", czero=first, **kw) + tile_fp8(1, "full", **kw)
+        return tile(0, "full", sched, (), w, czero=first) + tile(1, "full", sched, (), w)
+
+    for w in waves:
+        # the first pass of an output tile starts its accumulators from the constant 0: nothing is ever cleared
+        o += [f"; ==== wave {w}, first pass of an output tile (s88 = passes left)", f"Lklm%=_w{w}:",
+              "s_cmp_lg_u32 s88, 1", f"s_cbranch_scc1 Lklm%=_f{w}"] + SWITCH + [f"Lklm%=_f{w}:"]
+        o += one_pass(w, True)
+        o += ["s_sub_u32 s88, s88, 1", "s_cmp_eq_u32 s88, 0", "s_cbranch_scc1 Lklm%=_epilogue"]
+        o += [f"; ==== wave {w}, the other passes: two K tiles each", f"Lklm%=_l{w}:",
+              "s_cmp_lg_u32 s88, 1", f"s_cbranch_scc1 Lklm%=_g{w}"] + SWITCH + [f"Lklm%=_g{w}:"]
+        o += one_pass(w, False)
+        o += ["s_sub_u32 s88, s88, 1", "s_cmp_lg_u32 s88, 0", f"s_cbranch_scc1 Lklm%=_l{w}"]
+        if w != waves[-1]:
+            o += ["s_branch Lklm%=_epilogue"]
+    o += ["Lklm%=_epilogue:"]
+    # scratch = fragment set 1 (bf16 / fp4) / the odd K tiles' A set (fp8): dead after the last MFMA, while set 0 already
+    # holds the next output tile's first fragments
+    o += epilogue_lines(tmp=A1)
+    o += ["; ---- next output tile", "s_sub_u32 s78, s78, 1", "s_cmp_eq_u32 s78, 0", "s_cbranch_scc1 Lklm%=_done",
+          "s_mov_b32 s72, s76", "s_mov_b32 s73, s77", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s70, %[ra2]", "s_mov_b32 s88, %[passes]"]
+    o += next_or_none(tbl, "loop")
+    o += ["s_branch Lklm%=_tile", "Lklm%=_done:",
+          "; the last pass's (empty) LDS-DMA must not land in LDS the CU has handed to another workgroup",
+          "s_waitcnt vmcnt(0)"]
+    return o
+
+
 def clobbers():
     c = ["memory", "scc", "vcc", "m0"]
-    c += [f"s{i}" for i in range(64, 76)] + [f"s{i}" for i in range(80, 96)]
-    c += [f"v{i}" for i in range(40, 241)]
+    c += [f"s{i}" for i in range(64, 76)] + [f"s{i}" for i in range(76, 100)]
+    c += [f"v{i}" for i in range(40, 252)]
     c += [f"a{i}" for i in range(256)]
     return c
 
@@ -297,10 +409,10 @@ def f8(base, i):
     return f"v[{base + 8 * i}:{base + 8 * i + 7}]"
 
 
-def mfma_fp8(i, aset):
+def mfma_fp8(i, aset, czero=False):
     ni, mi = i // 8, i % 8
-    return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {f8(FB, ni)}, {f8(FA[aset], mi)}, {acc(mi, ni)}, v{FSCALE}, v{FSCALE} "
-            f"op_sel_hi:[0,0,0]")
+    return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {f8(FB, ni)}, {f8(FA[aset], mi)}, {'0' if czero else acc(mi, ni)}, "
+            f"v{FSCALE}, v{FSCALE} op_sel_hi:[0,0,0]")
 
 
 def read_fp8(operand, idx, half, stage, aset=0):
@@ -311,7 +423,7 @@ def read_fp8(operand, idx, half, stage, aset=0):
     return f"ds_read_b128 v[{base}:{base + 3}], v{reg}{off}"
 
 
-def tile_fp8(t, mode, landed=46, step2=5):
+def tile_fp8(t, mode, landed=46, step2=5, czero=False):
     """`step2`: DMA spacing in half gaps (5 = every 2.5 gaps); `landed`: the gap of the wait for tile t+1."""
     stage, aset = t & 1, t & 1
     out = [f"; ---- fp8 K tile in stage {stage}, {mode}"]
@@ -342,12 +454,14 @@ def tile_fp8(t, mode, landed=46, step2=5):
         # the next tile starts on A[*] and B[0]; B[5], B[6] (the last four reads, in order) may still be in flight
         after[63].append("s_waitcnt lgkmcnt(4)")
     for i in range(64):
-        out.append(mfma_fp8(i, aset))
+        out.append(mfma_fp8(i, aset, czero))
         out += after[i]
     return out
 
 
 def body_fp8(**kw):
+    global DMA_CACHE
+    DMA_CACHE = ""
     o = setup_lines(FRB, FSCALE)
     o += ["; ==== prologue: tiles 0 and 1 on their way, accumulators cleared meanwhile"]
     for st in (0, 1):
@@ -374,7 +488,10 @@ BODIES = {"": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEB
           "_PEROP": ("per_operand", (), "bf16"),
           "_NODMA": ("spread", ("dma",), "bf16"), "_NOREAD": ("spread", ("read",), "bf16"), "_L2ONLY": ("spread", ("bump",), "bf16"),
           "_MFMAONLY": ("spread", ("dma", "read", "barrier"), "bf16"),
-          "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"), "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8")}
+          "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"), "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8"),
+          "_SC0": ("stagger", ("cache:sc0",), "bf16"), "_SC1": ("stagger", ("cache:sc1",), "bf16"), "_NT": ("stagger", ("cache:nt",), "bf16"),
+          "_SC1NT": ("stagger", ("cache:sc1", "cache:nt"), "bf16"),
+          "_P": ("persistent", (), "bf16"), "_P_FP4": ("persistent", (), "fp4"), "_P_FP8": ("persistent", (), "fp8")}
 
 
 def main():
@@ -383,7 +500,10 @@ def main():
     with open(out, "w") as f:
         f.write("// GENERATED by scripts/gen_gemm_quad_asm.py -- do not edit; the schedules are documented there.\n")
         for suffix, (sched, ablate, dtype) in BODIES.items():
-            lines = body_fp8(**dict(ablate)) if dtype == "fp8" else body(sched, ablate, dtype=dtype)
+            if sched == "persistent":
+                lines = body_p(dtype)
+            else:
+                lines = body_fp8(**dict(ablate)) if dtype == "fp8" else body(sched, ablate, dtype=dtype)
             f.write(f"#define KLM_QUAD_ASM_BODY{suffix} \\\n")
             for ln in lines:
                 f.write('  "%s\\n\\t" \\\n' % ln.replace('"', '\\"'))

@@ -95,3 +95,41 @@ def test_epilogue_pairs_tiles_and_pads_the_permlane_hazard(gen):
     for i, l in enumerate(e):
         if l.startswith("v_permlane16_swap") and not e[i - 1].startswith("v_permlane16_swap"):
             assert e[i - 1] == "s_nop 1"                                       # VALU write -> swap: two wait states
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp4", "fp8"])
+def test_persistent_body_is_one_stream_over_output_tiles(gen, dtype):
+    L = gen.body_p(dtype)
+    waves = 1 if dtype == "fp8" else 4
+    per_pass = 128 if dtype == "fp8" else 256
+    # per wave: a first pass whose first K tile starts the accumulators from the constant 0, and a loop pass
+    mf = [l for l in L if l.startswith("v_mfma")]
+    assert len(mf) == waves * 2 * per_pass
+    assert sum(l.split(", ")[3].startswith("0") for l in mf) == waves * 64
+    assert not any(l.startswith("v_accvgpr_write") for l in L)                       # nothing is ever cleared
+    # every pass may be the last of its output tile: the descriptor switch sits in front of each, skipped unless s88 == 1
+    sw = [i for i, l in enumerate(L) if l.startswith("; ---- last pass of this output tile")]
+    assert len(sw) == 2 * waves
+    for i in sw:
+        assert L[i - 2] == "s_cmp_lg_u32 s88, 1" and L[i - 1].startswith("s_cbranch_scc1")
+        assert L[i + 1: i + 7] == gen.SWITCH[1:]
+    # all wave copies run the same number of barriers per pass (they meet at every one)
+    if waves == 4:
+        marks = [i for i, l in enumerate(L) if l.startswith("; ==== wave")] + [L.index("Lklm%=_epilogue:")]
+        counts = [sum(l == "s_barrier" for l in L[a:b]) for a, b in zip(marks, marks[1:])]
+        assert len(set(counts)) == 1, counts
+    # the epilogue's scratch is fragment set 1 (set 0 already holds the next output tile's first fragments)
+    e = L[L.index("Lklm%=_epilogue:"):]
+    regs = {int(m) for l in e if l.startswith("v_accvgpr_read") for m in re.findall(r"v_accvgpr_read_b32 v(\d+)", l)}
+    assert regs and min(regs) >= gen.A1 and max(regs) < gen.A1 + 64
+    # a table entry is fetched only while another output tile follows; the kernel ends with its (empty) DMA drained
+    assert L[-1] == "s_waitcnt vmcnt(0)" and L[-3] == "Lklm%=_done:"
+    for tag in ("first", "loop"):
+        i = L.index(f"Lklm%=_fetch_{tag}:")
+        assert L[i - 4: i] == ["s_cmp_lg_u32 s78, 1", f"s_cbranch_scc1 Lklm%=_fetch_{tag}", "s_mov_b32 s80, 0", f"s_branch Lklm%=_fetched_{tag}"]
+    # no register above the architectural limits, none of the reserved scalar registers
+    for l in L:
+        for m in re.findall(r"\bs(\d+)\b", l):
+            assert int(m) < 100, l
+        for m in re.findall(r"\bv\[?(\d+)", l):
+            assert int(m) < 256, l

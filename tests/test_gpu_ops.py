@@ -21,6 +21,8 @@ def env():
                                            (3, (256, 256, 256)), (3, (512, 768, 384)), (3, (1024, 512, 4096)),
                                            (4, (256, 256, 256)), (4, (512, 768, 384)), (4, (2048, 1024, 4096)), (4, (256, 512, 4352)),
                                            (5, (512, 768, 384)), (6, (512, 768, 384)), (7, (512, 768, 384)), (5, (256, 256, 4352)),
+                                           (8, (256, 256, 256)), (8, (512, 768, 384)), (8, (2048, 1024, 4096)), (8, (256, 512, 4352)),
+                                           (44, (512, 768, 384)), (45, (512, 768, 384)), (46, (512, 768, 384)), (47, (512, 768, 384)),
                                            (None, (1024, 1024, 1024)), (None, (384, 128, 64)), (None, (256, 256, 192))])
 def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch, ops, dev = env
@@ -34,7 +36,7 @@ def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=1e-2 * K ** 0.5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_bf16_exact_on_small_integers_with_asymmetric_operands(env, variant):
     torch, ops, dev = env
     M, N, K = 512, 256, (192 if variant < 2 else 384)
@@ -52,7 +54,7 @@ def test_gemm_bf16_identity_picks_rows_not_columns(env):
     n = 256
     eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
     b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)      # asymmetric
-    for v in (0, 1, 2, 3, 4, 5, 6, 7):
+    for v in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         assert torch.equal(ops.gemm_bf16(eye, b, variant=v), b.t().contiguous())      # C = I @ B^T
 
 
@@ -61,7 +63,7 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
     a = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     b = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     c0 = ops.gemm_bf16(a, b, variant=1).clone()
-    for v in (1, 2, 3, 4, 5, 6, 7):                                   # every pipeline gives the same bits, every run
+    for v in (1, 2, 3, 4, 5, 6, 7, 8):                                # every pipeline gives the same bits, every run
         for _ in range(20):
             assert torch.equal(ops.gemm_bf16(a, b, variant=v), c0)   # a ring-buffer race would show as a rare diff
 
@@ -80,6 +82,7 @@ def test_gemm_fp8_matches_fp32_reference(env, shape):
     assert torch.equal(c, ops.gemm_fp8(a, b, variant=0)) and torch.equal(c, ops.gemm_fp8(a, b, variant=1))
     if K % 256 == 0 and K >= 512:
         assert torch.equal(c, ops.gemm_fp8(a, b, variant=2)) and torch.equal(c, ops.gemm_fp8(a, b, variant=3))
+        assert torch.equal(c, ops.gemm_fp8(a, b, variant=4))
 
 
 def test_gemm_fp8_exact_on_small_integers(env):
@@ -107,10 +110,36 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     b[:, K // 2 - 5] = (torch.arange(N, device=dev) % 239).to(torch.uint8)
     c = ops.gemm_fp4(a, b)                                                    # the hand-scheduled stream where the shape allows
     assert torch.equal(c, ops.gemm_fp4(a, b, variant=0)) and torch.equal(c, ops.gemm_fp4(a, b, variant=1))
+    if (K // 2) % 256 == 0 and K // 2 >= 512:
+        assert torch.equal(c, ops.gemm_fp4(a, b, variant=2)) and torch.equal(c, ops.gemm_fp4(a, b, variant=3))
     ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
     assert torch.equal(c, ref.float().to(torch.bfloat16))
     if hasattr(torch, "float4_e2m1fn_x2"):
         assert torch.equal(ops.gemm_fp4(a.view(torch.float4_e2m1fn_x2), b.view(torch.float4_e2m1fn_x2)), c)
+
+
+@pytest.mark.parametrize("grid", [1, 2, 3, 5, 0])
+def test_persistent_gemms_walk_several_tiles_per_workgroup(env, grid):
+    """The persistent kernels take their output tiles from a per-workgroup table and fetch the next tile's operands during
+    the current tile's last pass: with 1 / 2 / 3 / 5 workgroups for 12 tiles every workgroup walks several (unevenly
+    many), with the default (one per CU) one each. Same bits as the one-workgroup-per-tile streams."""
+    torch, ops, dev = env
+    M, N, K = 768, 1024, 1024
+    g = torch.Generator(device=dev).manual_seed(grid)
+    a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    a4 = torch.randint(0, 256, (M, K), device=dev, generator=g, dtype=torch.uint8)
+    b4 = torch.randint(0, 256, (N, K), device=dev, generator=g, dtype=torch.uint8)
+    a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+    want = ops.gemm_bf16(a, b, variant=4), ops.gemm_fp8(a8, b8, variant=2), ops.gemm_fp4(a4, b4, variant=2)
+    before = ops.gemm_persistent_grid(grid)
+    try:
+        for _ in range(3):
+            got = ops.gemm_bf16(a, b, variant=8), ops.gemm_fp8(a8, b8, variant=4), ops.gemm_fp4(a4, b4, variant=3)
+            assert all(torch.equal(x, y) for x, y in zip(got, want))
+    finally:
+        ops.gemm_persistent_grid(before)
+    torch.testing.assert_close(want[0].float(), a.float() @ b.float().t(), rtol=1.6e-2, atol=0.4)
 
 
 def test_fp4_decode_table(env):

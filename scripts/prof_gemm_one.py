@@ -12,7 +12,8 @@ arms = {"bf16_v1": lambda: ops.gemm_bf16(a, b, out=c, variant=1), "bf16_v2": lam
         "bf16_v3": lambda: ops.gemm_bf16(a, b, out=c, variant=3), "bf16_v4": lambda: ops.gemm_bf16(a, b, out=c, variant=4),
         "bf16_v5": lambda: ops.gemm_bf16(a, b, out=c, variant=5), "bf16_v43": lambda: ops.gemm_bf16(a, b, out=c, variant=43), "bf16_hipblaslt": lambda: torch.matmul(a, bt, out=c),
         "fp8_v0": lambda: ops.gemm_fp8(a8, b8, out=c, variant=0), "fp8_v1": lambda: ops.gemm_fp8(a8, b8, out=c, variant=1),
-        "fp8_v2": lambda: ops.gemm_fp8(a8, b8, out=c, variant=2),
+        "fp8_v2": lambda: ops.gemm_fp8(a8, b8, out=c, variant=2), "fp8_v4": lambda: ops.gemm_fp8(a8, b8, out=c, variant=4),
+        "bf16_v8": lambda: ops.gemm_bf16(a, b, out=c, variant=8),
         "fp8_scaled_mm": lambda: torch._scaled_mm(a8, b8t, scale_a=one, scale_b=one, out_dtype=torch.bfloat16)}
 for k in os.environ.get("KLM_ARMS", "bf16_v2,bf16_v3,bf16_hipblaslt").split(","):
     for _ in range(it):

@@ -31,7 +31,13 @@ class LinearLayerStep:
         dd = self.distributed = (world > 1) if distributed is None else bool(distributed)
         # `gemm(a, b, out)` computes out = a @ b.T; the default is the hand-written MFMA kernel.
         # CPU tests of the stream/event/all-reduce logic pass a torch.matmul stand-in.
-        self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out))
+        # Under data parallelism the stream with ONE WORKGROUP PER TILE (variant 4), not the persistent default: a persistent
+        # workgroup owns its CU for the whole GEMM and fills every SIMD's register file, so the all-reduce kernel of the
+        # communication stream could only start between GEMMs and would then keep the CUs it took away from the next
+        # GEMM's statically assigned workgroups (their tiles would run after everyone else's). With one workgroup per tile
+        # the collective gets CUs as tiles retire and the remaining tiles flow over the CUs that are left.
+        quad = size % 256 == 0 and size >= 256
+        self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out, variant=4 if (dd and quad) else None))
         self.gpu = dev.type == "cuda"
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + (dist.get_rank() if dd else 0))

@@ -90,6 +90,9 @@ static int klm_launch_quad_asm(const void* A, const void* B, void* C, int M, int
 // fetches the next tile's first two K tiles, so the epilogue's stores (32 MB per round on the chip) never sit in front of
 // a cold prologue, and launch / argument loads / set-up are paid once per CU (generator: body_p).
 // The HIP part writes this workgroup's tile table behind the two LDS stages: {A rows, B rows, C} addresses per tile.
+// Not for a GPU shared with another stream's kernels (a collective overlapping the GEMM): tiles are assigned to workgroups
+// statically, so a workgroup that finds its CU taken starts late and finishes late; models/linear_step.py uses the
+// one-workgroup-per-tile kernel under data parallelism.
 // BODY: 0 bf16, 20 fp4, 30 fp8.
 // ------------------------------------------------------------------------------------
 #define KLM_QUAD_P_MAX_TILES 512     // per workgroup: 16 KiB of table

@@ -95,6 +95,9 @@ static std::string json_escape(const std::string& in) {
   }
   return out;
 }
+// a dense row pitch (bytes) the memory channels camp on: a multiple of 2 KiB that is no power of two (the same rule as
+// ops.camping_pitch; measured in scripts/exp/gemm_stride_sweep.py, gemm_pitch_check.py)
+static bool camping_pitch(long nbytes) { return nbytes >= 4096 && nbytes % 2048 == 0 && (nbytes & (nbytes - 1)) != 0; }
 // kernels per busy window: the whole number whose run time is closest to duty * period, at least 1 when
 // duty > 0 (the same law as loadgen/burner.py::plan_window)
 static int plan_window(double duty, double period_s, double kernel_s) {
@@ -130,6 +133,10 @@ static int selftest() {
       printf("%s[%.2f,%.6g,%d]", first ? "" : ",", d, k, plan_window(d, 0.1, k));
       first = false;
     }
+  printf("]}\n");
+  printf("{\"selftest\":\"camping_pitch\",\"rows\":[");
+  const long pitches[] = {512, 4096, 6144, 8192, 12288, 16384, 20480, 24064, 24576, 28672, 32768, 49152};
+  for (size_t i = 0; i < sizeof pitches / sizeof *pitches; ++i) printf("%s[%ld,%d]", i ? "," : "", pitches[i], camping_pitch(pitches[i]) ? 1 : 0);
   printf("]}\n");
   print_report(2.0, 2700, 1.97, 2.0 * 8192.0 * 8192.0 * 8192.0, 0.0);
   print_report(2.0, 1400, 2.0, 0.0, 4294967296.0);
@@ -185,8 +192,14 @@ int main(int argc, char** argv) {
   void *A = nullptr, *B = nullptr, *C = nullptr, *X = nullptr, *Y = nullptr, *sink = nullptr;
   double flops = 0, bytes = 0;
   const size_t n2 = (size_t)a.size * a.size;
+  // Row pitch of A and B: dense, unless the hand-scheduled stream takes the shape and the dense pitch is one the memory channels
+  // camp on (a multiple of 2 KiB that is no power of two: 8192 x 8192 x 12288 bf16 runs at 1380 TFLOP/s dense, 1617 with 256
+  // bytes of padding per row; docs/KERNELS.md "row pitch"). The operands are the burner's own, so it may lay them out.
+  const int row_bytes = fp4 ? a.size / 2 : fp8 ? a.size : a.size * 2;
+  const bool stream_ok = gemm && row_bytes % 256 == 0 && row_bytes >= 512;
+  const int pitch = row_bytes + ((stream_ok && camping_pitch(row_bytes)) ? 256 : 0);
   if (gemm) {
-    const size_t abytes = fp4 ? n2 / 2 : fp8 ? n2 : n2 * 2;
+    const size_t abytes = (size_t)a.size * pitch;
     HIPCHECK(hipMalloc(&A, abytes));
     HIPCHECK(hipMalloc(&B, abytes));
     HIPCHECK(hipMalloc(&C, n2 * 2));
@@ -194,11 +207,11 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(fill_bytes_random, dim3(2048), dim3(256), 0, s, (uint8_t*)A, abytes, 1u);
       hipLaunchKernelGGL(fill_bytes_random, dim3(2048), dim3(256), 0, s, (uint8_t*)B, abytes, 2u);
     } else if (fp8) {
-      hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)A, n2, 1u);
-      hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)B, n2, 2u);
+      hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)A, abytes, 1u);
+      hipLaunchKernelGGL(fill_fp8_uniform, dim3(2048), dim3(256), 0, s, (uint8_t*)B, abytes, 2u);
     } else {
-      hipLaunchKernelGGL(fill_bf16_uniform, dim3(2048), dim3(256), 0, s, (uint16_t*)A, n2, 1u);
-      hipLaunchKernelGGL(fill_bf16_uniform, dim3(2048), dim3(256), 0, s, (uint16_t*)B, n2, 2u);
+      hipLaunchKernelGGL(fill_bf16_uniform, dim3(2048), dim3(256), 0, s, (uint16_t*)A, abytes / 2, 1u);
+      hipLaunchKernelGGL(fill_bf16_uniform, dim3(2048), dim3(256), 0, s, (uint16_t*)B, abytes / 2, 2u);
     }
     flops = 2.0 * a.size * (double)a.size * a.size;
   } else if (hbm) {
@@ -234,8 +247,10 @@ int main(int argc, char** argv) {
   }
 
   auto launch = [&]() -> int {
-    // the hand-scheduled 4-wave streams where the shape allows (bf16, fp8: any multiple of 256; fp4: of 512), else the ring kernels
     // the persistent hand-scheduled streams (bf16 8, fp8 4, fp4 3) where the size allows, else the ring kernels
+    if (pitch != row_bytes)
+      return fp4 || fp8 ? klm_gemm_mx_pitched(fp8 ? 1 : 2, A, B, C, a.size, a.size, row_bytes, pitch, 1, s)
+                        : klm_gemm_bf16_pitched(A, B, C, a.size, a.size, a.size, pitch, 1, s);
     if (fp4) return klm_gemm_fp4(A, B, C, a.size, a.size, a.size, (a.size % 512 == 0 && a.size >= 1024) ? 3 : 1, s);
     if (gemm) return fp8 ? klm_gemm_fp8(A, B, C, a.size, a.size, a.size, a.size >= 512 ? 4 : 1, s) : klm_gemm_bf16(A, B, C, a.size, a.size, a.size, 8, s);
     if (a.kind == "hbm_copy") return klm_hbm_copy(Y, X, (size_t)2 << 30, s);

@@ -53,6 +53,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         lib.klm_gemm_bf16.restype = i
         lib.klm_gemm_persistent_grid.argtypes = [i]
         lib.klm_gemm_persistent_grid.restype = i
+        lib.klm_gemm_bf16_pitched.argtypes = [vp, vp, vp, i, i, i, i, i, vp]
+        lib.klm_gemm_bf16_pitched.restype = i
+        lib.klm_gemm_mx_pitched.argtypes = [i, vp, vp, vp, i, i, i, i, i, vp]
+        lib.klm_gemm_mx_pitched.restype = i
         if hasattr(lib, "klm_gemm_fp8"):
             lib.klm_gemm_fp8.argtypes = [vp, vp, vp, i, i, i, i, vp]
             lib.klm_gemm_fp8.restype = i
@@ -104,6 +108,43 @@ def _require_cuda(*ts) -> None:
             raise KlmOpsError("klm ops need contiguous tensors")
 
 
+def _require_rows(*ts) -> None:
+    """GEMM operands: on the GPU, rows contiguous (stride 1 along K); the rows themselves may be pitched."""
+    for t in ts:
+        if not t.is_cuda:
+            raise KlmOpsError("klm ops run on the GPU only (tensor is on %s)" % t.device)
+        if t.dim() == 2 and not t.is_contiguous() and not (t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+            raise KlmOpsError("klm ops need contiguous tensors (GEMM operands: contiguous rows, optionally pitched)")
+
+
+def _pitch_bytes(a, b) -> int:
+    """0 for dense operands; the common row pitch in bytes when a / b are row-pitched views (`padded_operand`)."""
+    if a.dim() != 2 or b.dim() != 2 or (a.is_contiguous() and b.is_contiguous()):
+        return 0
+    pa, pb = a.stride(0) * a.element_size(), b.stride(0) * b.element_size()
+    if pa != pb or pa % 16:
+        raise KlmOpsError(f"pitched GEMM operands need one row pitch, a multiple of 16 bytes (got {pa} and {pb})")
+    return pa
+
+
+#: row pitches (bytes) the memory channels camp on: all rows of a 256-row panel start in the same few channels, and the
+#: GEMMs' 128-byte-wide column reads queue there (8192 x 8192 x 12288 bf16, pitch 24 KiB: 1400 TFLOP/s; 12032: 1591).
+#: Measured bad: multiples of 2 - 4 KiB that are not a power of two; 256 bytes of padding per row is enough
+#: (scripts/exp/gemm_stride_sweep.py, gemm_pitch_check.py). Power-of-two pitches are fine (the channel hash handles them).
+def camping_pitch(nbytes: int) -> bool:
+    return nbytes >= 4096 and nbytes % 2048 == 0 and (nbytes & (nbytes - 1)) != 0
+
+
+def padded_operand(rows: int, cols: int, dtype, device, pad_bytes: int = 256):
+    """An uninitialised [rows, cols] GEMM operand; when its dense row pitch is one the memory channels camp on
+    (`camping_pitch`) it is a view into a [rows, cols + pad] allocation, which the hand-scheduled GEMM streams take as is."""
+    import torch
+    es = torch.empty((), dtype=dtype).element_size()
+    if not camping_pitch(cols * es):
+        return torch.empty((rows, cols), dtype=dtype, device=device)
+    return torch.empty((rows, cols + pad_bytes // es), dtype=dtype, device=device)[:, :cols]
+
+
 def version() -> str:
     return load().klm_version().decode()
 
@@ -119,7 +160,7 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     its LDS-DMA; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
     """
     import torch
-    _require_cuda(a, b)
+    _require_rows(a, b)
     if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
         raise KlmOpsError("gemm_bf16 needs bfloat16 inputs")
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
@@ -137,9 +178,16 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
         _require_cuda(out)
         if out.shape != (M, N) or out.dtype != torch.bfloat16:
             raise KlmOpsError("gemm_bf16: bad `out`")
+    pitch = _pitch_bytes(a, b)
     with _on_device(a):
-        rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
-    _check(rc, f"klm_gemm_bf16(M={M},N={N},K={K},variant={variant})")
+        if pitch:
+            # row-pitched operands (padded_operand): the hand-scheduled streams only
+            if variant not in (4, 8):
+                raise KlmOpsError(f"gemm_bf16: pitched operands need the hand-scheduled stream (variant 4 / 8), shape {M}x{N}x{K} gives {variant}")
+            rc = load().klm_gemm_bf16_pitched(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, int(variant == 8), _stream(a))
+        else:
+            rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+    _check(rc, f"klm_gemm_bf16(M={M},N={N},K={K},variant={variant},pitch={pitch})")
     return out
 
 
@@ -156,7 +204,7 @@ def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     the ring kernel (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 2: the stream with one
     workgroup per tile; 3: another placement of stream 2."""
     import torch
-    _require_cuda(a, b)
+    _require_rows(a, b)
     if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
         raise KlmOpsError("gemm_fp8 needs float8_e4m3fn (OCP) inputs")
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
@@ -170,9 +218,15 @@ def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     lib = load()
     if not hasattr(lib, "klm_gemm_fp8"):
         raise KlmOpsError("libklm_ops.so was built without the fp8 kernel")
+    pitch = _pitch_bytes(a, b)
     with _on_device(a):
-        rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
-    _check(rc, f"klm_gemm_fp8(M={M},N={N},K={K})")
+        if pitch:
+            if variant not in (2, 4):
+                raise KlmOpsError(f"gemm_fp8: pitched operands need the hand-scheduled stream (variant 2 / 4), K={K} gives {variant}")
+            rc = lib.klm_gemm_mx_pitched(1, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, int(variant == 4), _stream(a))
+        else:
+            rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+    _check(rc, f"klm_gemm_fp8(M={M},N={N},K={K},variant={variant},pitch={pitch})")
     return out
 
 
@@ -196,7 +250,7 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     bytes and >= 512, else the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0). 2: the stream with
     one workgroup per tile."""
     import torch
-    _require_cuda(a, b)
+    _require_rows(a, b)
     ok = (torch.uint8, getattr(torch, "float4_e2m1fn_x2", torch.uint8))
     if a.dtype not in ok or b.dtype not in ok:
         raise KlmOpsError("gemm_fp4 needs packed uint8 / float4_e2m1fn_x2 inputs")
@@ -211,9 +265,15 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     lib = load()
     if not hasattr(lib, "klm_gemm_fp4"):
         raise KlmOpsError("libklm_ops.so was built without the fp4 kernel")
+    pitch = _pitch_bytes(a, b)
     with _on_device(a):
-        rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, variant, _stream(a))
-    _check(rc, f"klm_gemm_fp4(M={M},N={N},K={Kb * 2})")
+        if pitch:
+            if variant not in (2, 3):
+                raise KlmOpsError(f"gemm_fp4: pitched operands need the hand-scheduled stream (variant 2 / 3), K={Kb * 2} gives {variant}")
+            rc = lib.klm_gemm_mx_pitched(2, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb, pitch, int(variant == 3), _stream(a))
+        else:
+            rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, variant, _stream(a))
+    _check(rc, f"klm_gemm_fp4(M={M},N={N},K={Kb * 2},variant={variant},pitch={pitch})")
     return out
 
 

@@ -324,6 +324,19 @@ extern "C" int klm_gemm_persistent_grid(int grid) {
   return before;
 }
 
+// The hand-scheduled stream on operands whose rows are `ld_bytes` apart (>= 2 K, a multiple of 16; A and B alike).
+extern "C" int klm_gemm_bf16_pitched(const void* A, const void* B, void* C, int M, int N, int K, int ld_bytes, int persistent,
+                                     void* stream) {
+  if (!A || !B || !C) return KLM_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
+  if (K <= 0 || K > (1 << 29) || !klm_quad_asm_shape_ok(M, N, K * 2, ld_bytes)) return KLM_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (!klm_stream_on_current_device(s)) return KLM_ERR_ARG;
+  if (int e = persistent ? klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s, ld_bytes) : klm_launch_quad_asm<0>(A, B, C, M, N, K * 2, s, ld_bytes))
+    return e;
+  return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+}
+
 extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                              void* stream) {
   if (!A || !B || !C) return KLM_ERR_ARG;

@@ -200,6 +200,23 @@ extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N,
   return launch_mx<0>(A, B, C, M, N, K, variant, stream);
 }
 
+// The hand-scheduled MX streams on operands whose rows are `ld_bytes` apart (A and B alike). kind 1: fp8, 2: fp4;
+// Kbytes = bytes of a row's K extent (fp8: K, fp4: K / 2).
+extern "C" int klm_gemm_mx_pitched(int kind, const void* A, const void* B, void* C, int M, int N, int Kbytes, int ld_bytes,
+                                   int persistent, void* stream) {
+  if (!A || !B || !C) return KLM_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
+  if (kind != 1 && kind != 2) return KLM_ERR_VARIANT;
+  if (!klm_quad_asm_shape_ok(M, N, Kbytes, ld_bytes)) return KLM_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (!klm_stream_on_current_device(s)) return KLM_ERR_ARG;
+  int e;
+  if (kind == 1) e = persistent ? klm_launch_quad_asm_p<30>(A, B, C, M, N, Kbytes, s, ld_bytes) : klm_launch_quad_asm<30>(A, B, C, M, N, Kbytes, s, ld_bytes);
+  else e = persistent ? klm_launch_quad_asm_p<20>(A, B, C, M, N, Kbytes, s, ld_bytes) : klm_launch_quad_asm<20>(A, B, C, M, N, Kbytes, s, ld_bytes);
+  if (e) return e;
+  return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+}
+
 // K counts fp4 ELEMENTS; rows are K/2 bytes, two elements per byte.
 extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                             void* stream) {

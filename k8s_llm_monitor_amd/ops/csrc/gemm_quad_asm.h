@@ -15,9 +15,11 @@
 // (DMA from L2 only) / all of it (results meaningless: they price each kind of instruction); 14..17 stream 0 with cache-policy
 // bits sc0 / sc1 / nt / sc1 nt on its LDS-DMA (right results; an experiment); 20 the fp4 kernel; 30 the fp8 kernel.
 // Kb: the operands' row length in BYTES (bf16: 2 K, fp4: K / 2); a K tile is 128 bytes of a row in every format.
+// ld: the row PITCH of A and B in bytes (>= Kb, a multiple of 16): dense operands have ld = Kb; a burner that owns its operands
+// pads the pitch away from the strides the memory channels camp on (docs/KERNELS.md, "row pitch").
 template <int BODY>
 __global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A, const void* __restrict__ B,
-                                                     uint16_t* __restrict__ C, int M, int N, int Kb) {
+                                                     uint16_t* __restrict__ C, int M, int N, int Kb, int ld) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A,
   int tm, tn;
   tile_of_block<8>(blockIdx.x, M >> 8, N >> 8, tm, tn);
   const int brow = tm << 8, bcol = tn << 8;
-  const unsigned lda = (unsigned)Kb, ldc = (unsigned)N * 2;
+  const unsigned lda = (unsigned)ld, ldc = (unsigned)N * 2;
   // descriptors start at this WAVE's first staged row (it stages rows [64 wid, 64 wid + 64) of both operands) and at
   // its 128 x 128 part of C, so every offset inside the asm is small and wave-independent
   const uint64_t pa = reinterpret_cast<uint64_t>(A) + (uint64_t)(brow + wid * 64) * lda;
@@ -78,9 +80,10 @@ __global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A,
 }
 
 template <int BODY>
-static int klm_launch_quad_asm(const void* A, const void* B, void* C, int M, int N, int Kb, hipStream_t s) {
+static int klm_launch_quad_asm(const void* A, const void* B, void* C, int M, int N, int Kb, hipStream_t s, int ld = 0) {
   if (int e = klm_ensure_dyn_lds<gemm_quad_asm<BODY>>(KLM_QUAD_LDS_BYTES)) return e;
-  hipLaunchKernelGGL(gemm_quad_asm<BODY>, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, A, B, (uint16_t*)C, M, N, Kb);
+  hipLaunchKernelGGL(gemm_quad_asm<BODY>, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, A, B, (uint16_t*)C, M, N, Kb,
+                     ld ? ld : Kb);
   return KLM_OK;
 }
 
@@ -98,12 +101,12 @@ static int klm_launch_quad_asm(const void* A, const void* B, void* C, int M, int
 #define KLM_QUAD_P_MAX_TILES 512     // per workgroup: 16 KiB of table
 template <int BODY>
 __global__ __launch_bounds__(256) void gemm_quad_asm_p(const void* __restrict__ A, const void* __restrict__ B,
-                                                       uint16_t* __restrict__ C, int M, int N, int Kb) {
+                                                       uint16_t* __restrict__ C, int M, int N, int Kb, int ld) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
-  const unsigned lda = (unsigned)Kb, ldc = (unsigned)N * 2;
+  const unsigned lda = (unsigned)ld, ldc = (unsigned)N * 2;
   const int tiles_m = M >> 8, tiles_n = N >> 8, ntiles = tiles_m * tiles_n, grid = (int)gridDim.x;
   const int mine = (ntiles - (int)blockIdx.x + grid - 1) / grid;          // >= 1: the launcher keeps grid <= ntiles
   uint4* table = reinterpret_cast<uint4*>(smem + KLM_QUAD_LDS_BYTES);
@@ -173,19 +176,22 @@ static int klm_quad_p_grid(int ntiles) {
 }
 
 template <int BODY>
-static int klm_launch_quad_asm_p(const void* A, const void* B, void* C, int M, int N, int Kb, hipStream_t s) {
+static int klm_launch_quad_asm_p(const void* A, const void* B, void* C, int M, int N, int Kb, hipStream_t s, int ld = 0) {
   const int ntiles = (M >> 8) * (N >> 8), grid = klm_quad_p_grid(ntiles);
   if (grid <= 0) return KLM_ERR_HIP;
   const int lds = KLM_QUAD_LDS_BYTES + 32 * KLM_QUAD_P_MAX_TILES;
   if (int e = klm_ensure_dyn_lds<gemm_quad_asm_p<BODY>>(lds)) return e;
   const int per = (ntiles + grid - 1) / grid;
-  hipLaunchKernelGGL(gemm_quad_asm_p<BODY>, dim3(grid), dim3(256), KLM_QUAD_LDS_BYTES + 32 * per, s, A, B, (uint16_t*)C, M, N, Kb);
+  hipLaunchKernelGGL(gemm_quad_asm_p<BODY>, dim3(grid), dim3(256), KLM_QUAD_LDS_BYTES + 32 * per, s, A, B, (uint16_t*)C, M, N, Kb,
+                     ld ? ld : Kb);
   return KLM_OK;
 }
 
 // shapes the hand-scheduled kernels take: whole 256 x 256 tiles, an even number of K tiles >= 4, 32-bit descriptor ranges
-static inline bool klm_quad_asm_shape_ok(int M, int N, int Kb) {
-  return M > 0 && N > 0 && !(M & 255) && !(N & 255) && !(Kb & 255) && Kb >= 512 && (size_t)Kb * 64 <= 0x7fffffffull &&
-         (size_t)N * 2 * 128 <= 0x7fffffffull;
+static inline bool klm_quad_asm_shape_ok(int M, int N, int Kb, int ld = 0) {
+  if (!ld) ld = Kb;
+  return M > 0 && N > 0 && !(M & 255) && !(N & 255) && !(Kb & 255) && Kb >= 512 && ld >= Kb && !(ld & 15) &&
+         (size_t)ld * 256 <= 0x7fffffffull && (size_t)N * 2 * 128 <= 0x7fffffffull;
 }
+
 

@@ -46,6 +46,14 @@ int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int
 int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                  void* stream);
 
+// The hand-scheduled streams on ROW-PITCHED operands: rows of A and B are `ld_bytes` apart (>= the K extent in bytes, a multiple
+// of 16, the same for both). Shapes as for the streams (M, N % 256 == 0; K extent a multiple of 256 bytes, >= 512).
+// A burner that owns its operands pads the pitch away from strides the memory channels camp on (docs/KERNELS.md).
+int klm_gemm_bf16_pitched(const void* A, const void* B, void* C, int M, int N, int K, int ld_bytes, int persistent, void* stream);
+// kind 1: fp8 (Kbytes = K), 2: fp4 (Kbytes = K / 2)
+int klm_gemm_mx_pitched(int kind, const void* A, const void* B, void* C, int M, int N, int Kbytes, int ld_bytes, int persistent,
+                        void* stream);
+
 // Persistent GEMM variants (bf16 variant 8, fp8 variant 4, fp4 variant 3): one workgroup per CU walks its output tiles.
 // Tests: set a fixed workgroup count (0 = one per CU; < 0 = only read); returns the previous setting.
 int klm_gemm_persistent_grid(int grid);

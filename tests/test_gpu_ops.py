@@ -142,6 +142,46 @@ def test_persistent_gemms_walk_several_tiles_per_workgroup(env, grid):
     torch.testing.assert_close(want[0].float(), a.float() @ b.float().t(), rtol=1.6e-2, atol=0.4)
 
 
+@pytest.mark.parametrize("pad_bytes", [256, 1024])
+def test_gemm_streams_take_row_pitched_operands(env, pad_bytes):
+    """Operands in a padded allocation (the burner's answer to row pitches the memory channels camp on): same bits as dense."""
+    torch, ops, dev = env
+    M, N, K = 512, 768, 1536
+    g = torch.Generator(device=dev).manual_seed(pad_bytes)
+    a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+
+    def padded(t):
+        p = torch.full((t.shape[0], t.shape[1] + pad_bytes // t.element_size()), 3, dtype=torch.uint8 if t.dtype == torch.uint8 else torch.float32,
+                       device=dev).to(t.dtype)[:, :t.shape[1]]          # the padding holds values that would show in a sum
+        p.copy_(t)
+        assert not p.is_contiguous()
+        return p
+
+    want = ops.gemm_bf16(a, b, variant=4)
+    for v in (4, 8, None):
+        assert torch.equal(ops.gemm_bf16(padded(a), padded(b), variant=v), want)
+    a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+    want8 = ops.gemm_fp8(a8, b8, variant=2)
+    for v in (2, 4, None):
+        assert torch.equal(ops.gemm_fp8(padded(a8), padded(b8), variant=v), want8)
+    a4 = torch.randint(0, 256, (M, K), device=dev, generator=g, dtype=torch.uint8)
+    b4 = torch.randint(0, 256, (N, K), device=dev, generator=g, dtype=torch.uint8)
+    want4 = ops.gemm_fp4(a4, b4, variant=2)
+    for v in (2, 3, None):
+        assert torch.equal(ops.gemm_fp4(padded(a4), padded(b4), variant=v), want4)
+    # what cannot take a pitch says so instead of reading the wrong rows
+    with pytest.raises(ops.KlmOpsError, match="pitched"):
+        ops.gemm_bf16(padded(a), padded(b), variant=2)
+    with pytest.raises(ops.KlmOpsError, match="one row pitch"):
+        ops.gemm_bf16(padded(a), b, variant=8)
+    with pytest.raises(ops.KlmOpsError, match="contiguous"):
+        ops.gemm_bf16(a.t(), b.t())
+    # padded_operand pads exactly the camping pitches
+    assert ops.padded_operand(256, 12288, torch.bfloat16, dev).stride(0) == 12288 + 128
+    assert ops.padded_operand(256, 8192, torch.bfloat16, dev).is_contiguous() and ops.padded_operand(256, 12032, torch.bfloat16, dev).is_contiguous()
+
+
 def test_fp4_decode_table(env):
     torch, ops, dev = env
     codes = torch.arange(256, device=dev, dtype=torch.uint8).reshape(1, 256)

@@ -160,5 +160,11 @@ def test_burner_selftest_planner_matches_the_python_planner(asan_bins):
     assert len(rows) == 28
     for duty, kernel_s, n in rows:
         assert n == plan_window(duty, lines[0]["period_s"], kernel_s), (duty, kernel_s, n)
-    assert lines[1]["tflops"] == pytest.approx(2 * 8192 ** 3 * 2700 / 1.97 / 1e12, rel=1e-4) and lines[2]["TBps"] == pytest.approx(3.006, abs=1e-3)
-    assert lines[3]["kind"] == 'gemm"bf16\\\n' and lines[3]["hbm_hold_gib"] == 3.0 and lines[3]["duty_achieved"] == 98.5
+    # which dense row pitches get padded: the same rule in both burners
+    from k8s_llm_monitor_amd.ops import camping_pitch
+    assert lines[1]["selftest"] == "camping_pitch" and len(lines[1]["rows"]) == 12
+    for nbytes, bad in lines[1]["rows"]:
+        assert bool(bad) == camping_pitch(nbytes), nbytes
+    assert camping_pitch(24576) and camping_pitch(20480) and not camping_pitch(16384) and not camping_pitch(24064)
+    assert lines[2]["tflops"] == pytest.approx(2 * 8192 ** 3 * 2700 / 1.97 / 1e12, rel=1e-4) and lines[3]["TBps"] == pytest.approx(3.006, abs=1e-3)
+    assert lines[4]["kind"] == 'gemm"bf16\\\n' and lines[4]["hbm_hold_gib"] == 3.0 and lines[4]["duty_achieved"] == 98.5

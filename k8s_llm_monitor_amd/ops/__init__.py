@@ -155,7 +155,9 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream in its persistent
     form (8: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue) for whole
     256 x 256 tiles and an even number of K tiles >= 4, else the 8-wave ring kernel (2, or 1 for an odd tile count), else
-    the 128x128 one (0). 4: the same stream, one workgroup per tile; 3: the compiler-scheduled 4-wave kernel
+    the 128x128 one (0). 4: the same stream, one workgroup per tile; 9: 8 with C stored past the caches (`sc1 nt`: +1.6 - 2.7 %
+    when one 8192^3 GEMM repeats on the same operands, which then stay in the Infinity Cache; -0.8 % in the training step,
+    -12 % at K = 1024: not a default); 48 / 49: 8 without its stores / epilogue (diagnostic); 3: the compiler-scheduled 4-wave kernel
     (gemm_quad128.h); 5..7: earlier placements of the hand-scheduled stream; 44..47: stream 4 with cache-policy bits on
     its LDS-DMA; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
     """
@@ -182,9 +184,9 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     with _on_device(a):
         if pitch:
             # row-pitched operands (padded_operand): the hand-scheduled streams only
-            if variant not in (4, 8):
-                raise KlmOpsError(f"gemm_bf16: pitched operands need the hand-scheduled stream (variant 4 / 8), shape {M}x{N}x{K} gives {variant}")
-            rc = load().klm_gemm_bf16_pitched(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, int(variant == 8), _stream(a))
+            if variant not in (4, 8, 9):
+                raise KlmOpsError(f"gemm_bf16: pitched operands need the hand-scheduled stream (variant 4 / 8 / 9), shape {M}x{N}x{K} gives {variant}")
+            rc = load().klm_gemm_bf16_pitched(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, {4: 0, 8: 1, 9: 2}[variant], _stream(a))
         else:
             rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
     _check(rc, f"klm_gemm_bf16(M={M},N={N},K={K},variant={variant},pitch={pitch})")
@@ -202,7 +204,7 @@ def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the MX-scaled MFMA.
     variant None: the hand-scheduled 4-wave stream in its persistent form (4) when K is a multiple of 256 and >= 512, else
     the ring kernel (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 2: the stream with one
-    workgroup per tile; 3: another placement of stream 2."""
+    workgroup per tile; 3: another placement of stream 2; 5: 4 with C stored past the caches (see gemm_bf16, variant 9)."""
     import torch
     _require_rows(a, b)
     if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
@@ -221,9 +223,9 @@ def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     pitch = _pitch_bytes(a, b)
     with _on_device(a):
         if pitch:
-            if variant not in (2, 4):
-                raise KlmOpsError(f"gemm_fp8: pitched operands need the hand-scheduled stream (variant 2 / 4), K={K} gives {variant}")
-            rc = lib.klm_gemm_mx_pitched(1, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, int(variant == 4), _stream(a))
+            if variant not in (2, 4, 5):
+                raise KlmOpsError(f"gemm_fp8: pitched operands need the hand-scheduled stream (variant 2 / 4 / 5), K={K} gives {variant}")
+            rc = lib.klm_gemm_mx_pitched(1, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, {2: 0, 4: 1, 5: 2}[variant], _stream(a))
         else:
             rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
     _check(rc, f"klm_gemm_fp8(M={M},N={N},K={K},variant={variant},pitch={pitch})")
@@ -248,7 +250,7 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2].
     variant None: the hand-scheduled 4-wave stream in its persistent form (3) when the packed row is a multiple of 256
     bytes and >= 512, else the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0). 2: the stream with
-    one workgroup per tile."""
+    one workgroup per tile; 4: 3 with C stored past the caches."""
     import torch
     _require_rows(a, b)
     ok = (torch.uint8, getattr(torch, "float4_e2m1fn_x2", torch.uint8))
@@ -268,9 +270,9 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     pitch = _pitch_bytes(a, b)
     with _on_device(a):
         if pitch:
-            if variant not in (2, 3):
-                raise KlmOpsError(f"gemm_fp4: pitched operands need the hand-scheduled stream (variant 2 / 3), K={Kb * 2} gives {variant}")
-            rc = lib.klm_gemm_mx_pitched(2, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb, pitch, int(variant == 3), _stream(a))
+            if variant not in (2, 3, 4):
+                raise KlmOpsError(f"gemm_fp4: pitched operands need the hand-scheduled stream (variant 2 / 3 / 4), K={Kb * 2} gives {variant}")
+            rc = lib.klm_gemm_mx_pitched(2, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb, pitch, {2: 0, 3: 1, 4: 2}[variant], _stream(a))
         else:
             rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, variant, _stream(a))
     _check(rc, f"klm_gemm_fp4(M={M},N={N},K={Kb * 2},variant={variant},pitch={pitch})")

@@ -332,7 +332,10 @@ extern "C" int klm_gemm_bf16_pitched(const void* A, const void* B, void* C, int 
   if (K <= 0 || K > (1 << 29) || !klm_quad_asm_shape_ok(M, N, K * 2, ld_bytes)) return KLM_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (!klm_stream_on_current_device(s)) return KLM_ERR_ARG;
-  if (int e = persistent ? klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s, ld_bytes) : klm_launch_quad_asm<0>(A, B, C, M, N, K * 2, s, ld_bytes))
+  // persistent: 0 one workgroup per tile, 1 persistent, 2 persistent with C streamed past the caches (sc1 nt)
+  if (int e = persistent == 2   ? klm_launch_quad_asm_p<1>(A, B, C, M, N, K * 2, s, ld_bytes)
+              : persistent == 1 ? klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s, ld_bytes)
+                                : klm_launch_quad_asm<0>(A, B, C, M, N, K * 2, s, ld_bytes))
     return e;
   return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
 }
@@ -355,10 +358,16 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     if (int e = klm_ensure_dyn_lds<gemm_bf16_quad>(KLM_QUAD_LDS_BYTES)) return e;
     hipLaunchKernelGGL(gemm_bf16_quad, dim3((M >> 8) * (N >> 8)), dim3(256), KLM_QUAD_LDS_BYTES, s, (const uint16_t*)A,
                        (const uint16_t*)B, (uint16_t*)C, M, N, K);
-  } else if (variant == 8) {
-    // the persistent form of stream 4: one workgroup per CU, the next output tile's operands fetched under the epilogue
+  } else if (variant == 9) {
+    // persistent, C stored with `sc1 nt` (streamed past the caches)
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
-    if (int e = klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s)) return e;
+    if (int e = klm_launch_quad_asm_p<1>(A, B, C, M, N, K * 2, s)) return e;
+  } else if (variant == 8 || variant == 48 || variant == 49) {
+    // the persistent form of stream 4: one workgroup per CU, the next output tile's operands fetched under the epilogue
+    // (48 / 49: diagnostic, without the stores / without the epilogue -- C is NOT written)
+    if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
+    if (int e = variant == 8 ? klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s)
+              : variant == 48 ? klm_launch_quad_asm_p<10>(A, B, C, M, N, K * 2, s) : klm_launch_quad_asm_p<11>(A, B, C, M, N, K * 2, s)) return e;
   } else if ((variant >= 4 && variant <= 7) || (variant >= 40 && variant <= 47)) {
     // hand-scheduled streams (gemm_quad_asm.h): 4 the kernel; 5..7 earlier placements; 40..43 diagnostic, results meaningless
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;

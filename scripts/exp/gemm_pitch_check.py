@@ -16,7 +16,7 @@ def padded(t, pad_bytes):
     return p
 
 
-for K in (8192, 10240, 12288, 14336, 20480, 24576):
+for K in [int(x) for x in os.environ.get("KLM_KS", "8192,10240,12288,14336,20480,24576").split(",")]:
     a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
     b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
     c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

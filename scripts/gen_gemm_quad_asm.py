@@ -47,6 +47,7 @@ def frag(base, i):
 NMAJOR = False      # True: consecutive MFMAs share the B fragment (the instruction's FIRST source) instead of the A fragment
 DTYPE = "bf16"      # or "fp4": same 16-byte fragments and K tile of 128 bytes per row, the MX-scaled MFMA with unit scales
 SCALE = 176         # fp4: VGPR holding four E8M0 scales of 2^0
+STORE_CACHE = ""    # cache-policy bits on the epilogue's stores (" nt": streaming)
 DMA_CACHE = ""      # cache-policy bits on the LDS-DMA (" sc0", " sc1", " nt", ..): experiment bodies only
 
 
@@ -200,7 +201,7 @@ def epilogue_lines(tmp=A0):
                   f"v_cvt_pk_bf16_f32 v{r + 2}, v{r + 4}, v{r + 5}", f"v_cvt_pk_bf16_f32 v{r + 3}, v{r + 6}, v{r + 7}",
                   "s_nop 1",                                   # VALU write -> permlane swap read: 2 wait states
                   f"v_permlane16_swap_b32 v{r}, v{r + 2}", f"v_permlane16_swap_b32 v{r + 1}, v{r + 3}",
-                  f"buffer_store_dwordx4 v[{r}:{r + 3}], %[vc], s[72:75], s94 offen offset:{ni * 32}"]
+                  f"buffer_store_dwordx4 v[{r}:{r + 3}], %[vc], s[72:75], s94 offen offset:{ni * 32}{STORE_CACHE}"]
             t += 1
         o.append("s_add_u32 s94, s94, s95")
     # no wait for the stores: the wave may end with them in flight (the memory system owns them), and the CU gets its LDS
@@ -301,7 +302,7 @@ SWITCH = ["; ---- last pass of this output tile: its DMA fetches the next output
           "s_mov_b32 s64, s96", "s_mov_b32 s65, s97", "s_mov_b32 s66, s80", "s_mov_b32 s68, s98", "s_mov_b32 s69, s99", "s_mov_b32 s70, s80"]
 
 
-def body_p(dtype="bf16", sched="stagger", **kw):
+def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
     global NMAJOR, DTYPE, DMA_CACHE
     NMAJOR, DTYPE, DMA_CACHE = False, dtype, ""
     fp8 = dtype == "fp8"
@@ -346,7 +347,15 @@ def body_p(dtype="bf16", sched="stagger", **kw):
     o += ["Lklm%=_epilogue:"]
     # scratch = fragment set 1 (bf16 / fp4) / the odd K tiles' A set (fp8): dead after the last MFMA, while set 0 already
     # holds the next output tile's first fragments
-    o += epilogue_lines(tmp=A1)
+    global STORE_CACHE
+    STORE_CACHE = "".join(" " + x[8:] for x in ablate if x.startswith("stcache:"))
+    epi = epilogue_lines(tmp=A1)
+    STORE_CACHE = ""
+    if "store" in ablate:          # diagnostic: what the stores cost (C is never written)
+        epi = [l for l in epi if not l.startswith("buffer_store")]
+    if "epilogue" in ablate:       # diagnostic: what the whole epilogue costs
+        epi = []
+    o += epi
     o += ["; ---- next output tile", "s_sub_u32 s78, s78, 1", "s_cmp_eq_u32 s78, 0", "s_cbranch_scc1 Lklm%=_done",
           "s_mov_b32 s72, s76", "s_mov_b32 s73, s77", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s70, %[ra2]", "s_mov_b32 s88, %[passes]"]
     o += next_or_none(tbl, "loop")
@@ -491,6 +500,10 @@ BODIES = {"": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEB
           "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"), "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8"),
           "_SC0": ("stagger", ("cache:sc0",), "bf16"), "_SC1": ("stagger", ("cache:sc1",), "bf16"), "_NT": ("stagger", ("cache:nt",), "bf16"),
           "_SC1NT": ("stagger", ("cache:sc1", "cache:nt"), "bf16"),
+          "_P_NOSTORE": ("persistent", ("store",), "bf16"), "_P_NOEPI": ("persistent", ("epilogue",), "bf16"),
+          # _ST: C stored with `sc1 nt` (written through, not kept): for shapes whose operands just fit the 256 MB Infinity Cache
+          "_P_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "bf16"), "_P_FP4_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp4"),
+          "_P_FP8_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp8"),
           "_P": ("persistent", (), "bf16"), "_P_FP4": ("persistent", (), "fp4"), "_P_FP8": ("persistent", (), "fp8")}
 
 
@@ -501,7 +514,7 @@ def main():
         f.write("// GENERATED by scripts/gen_gemm_quad_asm.py -- do not edit; the schedules are documented there.\n")
         for suffix, (sched, ablate, dtype) in BODIES.items():
             if sched == "persistent":
-                lines = body_p(dtype)
+                lines = body_p(dtype, ablate=ablate)
             else:
                 lines = body_fp8(**dict(ablate)) if dtype == "fp8" else body(sched, ablate, dtype=dtype)
             f.write(f"#define KLM_QUAD_ASM_BODY{suffix} \\\n")

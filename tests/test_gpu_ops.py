@@ -22,6 +22,7 @@ def env():
                                            (4, (256, 256, 256)), (4, (512, 768, 384)), (4, (2048, 1024, 4096)), (4, (256, 512, 4352)),
                                            (5, (512, 768, 384)), (6, (512, 768, 384)), (7, (512, 768, 384)), (5, (256, 256, 4352)),
                                            (8, (256, 256, 256)), (8, (512, 768, 384)), (8, (2048, 1024, 4096)), (8, (256, 512, 4352)),
+                                           (9, (512, 768, 384)), (9, (2048, 1024, 4096)),
                                            (44, (512, 768, 384)), (45, (512, 768, 384)), (46, (512, 768, 384)), (47, (512, 768, 384)),
                                            (None, (1024, 1024, 1024)), (None, (384, 128, 64)), (None, (256, 256, 192))])
 def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
@@ -82,7 +83,7 @@ def test_gemm_fp8_matches_fp32_reference(env, shape):
     assert torch.equal(c, ops.gemm_fp8(a, b, variant=0)) and torch.equal(c, ops.gemm_fp8(a, b, variant=1))
     if K % 256 == 0 and K >= 512:
         assert torch.equal(c, ops.gemm_fp8(a, b, variant=2)) and torch.equal(c, ops.gemm_fp8(a, b, variant=3))
-        assert torch.equal(c, ops.gemm_fp8(a, b, variant=4))
+        assert torch.equal(c, ops.gemm_fp8(a, b, variant=4)) and torch.equal(c, ops.gemm_fp8(a, b, variant=5))
 
 
 def test_gemm_fp8_exact_on_small_integers(env):
@@ -112,6 +113,7 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     assert torch.equal(c, ops.gemm_fp4(a, b, variant=0)) and torch.equal(c, ops.gemm_fp4(a, b, variant=1))
     if (K // 2) % 256 == 0 and K // 2 >= 512:
         assert torch.equal(c, ops.gemm_fp4(a, b, variant=2)) and torch.equal(c, ops.gemm_fp4(a, b, variant=3))
+        assert torch.equal(c, ops.gemm_fp4(a, b, variant=4))
     ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
     assert torch.equal(c, ref.float().to(torch.bfloat16))
     if hasattr(torch, "float4_e2m1fn_x2"):
@@ -159,7 +161,7 @@ def test_gemm_streams_take_row_pitched_operands(env, pad_bytes):
         return p
 
     want = ops.gemm_bf16(a, b, variant=4)
-    for v in (4, 8, None):
+    for v in (4, 8, 9, None):
         assert torch.equal(ops.gemm_bf16(padded(a), padded(b), variant=v), want)
     a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
     want8 = ops.gemm_fp8(a8, b8, variant=2)

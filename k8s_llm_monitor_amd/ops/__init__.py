@@ -201,10 +201,12 @@ def gemm_persistent_grid(grid: int = -1) -> int:
 
 
 def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
-    """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the MX-scaled MFMA.
+    """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the f8f6f4 MFMA (16x16x128).
     variant None: the hand-scheduled 4-wave stream in its persistent form (4) when K is a multiple of 256 and >= 512, else
     the ring kernel (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 2: the stream with one
-    workgroup per tile; 3: another placement of stream 2; 5: 4 with C stored past the caches (see gemm_bf16, variant 9)."""
+    workgroup per tile; 3: another placement of stream 2; 5: 4 with C stored past the caches (see gemm_bf16, variant 9);
+    6: 4 on the block-scaled MFMA with unit scales (the streams use the plain v_mfma_f32_16x16x128_f8f6f4: same bits, one
+    instruction word instead of two, +1.6 %; the ring kernels keep the block-scaled form)."""
     import torch
     _require_rows(a, b)
     if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
@@ -250,7 +252,8 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2].
     variant None: the hand-scheduled 4-wave stream in its persistent form (3) when the packed row is a multiple of 256
     bytes and >= 512, else the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0). 2: the stream with
-    one workgroup per tile; 4: 3 with C stored past the caches."""
+    one workgroup per tile; 4: 3 with C stored past the caches; 5: 3 on the block-scaled MFMA with unit scales (same bits,
+    -3.3 %)."""
     import torch
     _require_rows(a, b)
     ok = (torch.uint8, getattr(torch, "float4_e2m1fn_x2", torch.uint8))

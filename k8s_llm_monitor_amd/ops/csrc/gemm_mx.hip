@@ -184,7 +184,7 @@ static int check_mx(const void* A, const void* B, const void* C, int M, int N, i
 
 extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                             void* stream) {
-  if (variant == 2 || variant == 3 || variant == 4 || variant == 5) {
+  if (variant >= 2 && variant <= 6) {
     // the hand-scheduled 4-wave stream (gemm_quad_asm.h, generator: body_fp8); 3: another placement, for the A/B record;
     // 4: the persistent form (one workgroup per CU, generator: body_p)
     if (!A || !B || !C) return KLM_ERR_ARG;
@@ -194,7 +194,8 @@ extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N,
     if (int e = variant == 2   ? klm_launch_quad_asm<30>(A, B, C, M, N, K, (hipStream_t)stream)
                 : variant == 3 ? klm_launch_quad_asm<31>(A, B, C, M, N, K, (hipStream_t)stream)
                 : variant == 4 ? klm_launch_quad_asm_p<30>(A, B, C, M, N, K, (hipStream_t)stream)
-                               : klm_launch_quad_asm_p<31>(A, B, C, M, N, K, (hipStream_t)stream)) return e;   // 5: 4 with C streamed (sc1 nt)
+                : variant == 5 ? klm_launch_quad_asm_p<31>(A, B, C, M, N, K, (hipStream_t)stream)    // 5: 4 with C streamed (sc1 nt)
+                               : klm_launch_quad_asm_p<32>(A, B, C, M, N, K, (hipStream_t)stream)) return e;   // 6: 4 on the block-scaled MFMA with unit scales (what 4 used before: same bits, slower)
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
   if (int e = check_mx(A, B, C, M, N, K, variant)) return e;
@@ -229,7 +230,7 @@ extern "C" int klm_gemm_mx_pitched(int kind, const void* A, const void* B, void*
 extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                             void* stream) {
   if (K <= 0 || (K & 1)) return KLM_ERR_SHAPE;
-  if (variant == 2 || variant == 3 || variant == 4) {
+  if (variant >= 2 && variant <= 5) {
     // the hand-scheduled 4-wave stream (gemm_quad_asm.h): same fragments and K tile as bf16, the MX MFMA with unit scales;
     // 3: its persistent form; 4: 3 with C streamed (sc1 nt)
     if (!A || !B || !C) return KLM_ERR_ARG;
@@ -238,7 +239,8 @@ extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N,
     if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
     if (int e = variant == 2   ? klm_launch_quad_asm<20>(A, B, C, M, N, K >> 1, (hipStream_t)stream)
                 : variant == 3 ? klm_launch_quad_asm_p<20>(A, B, C, M, N, K >> 1, (hipStream_t)stream)
-                               : klm_launch_quad_asm_p<21>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;
+                : variant == 4 ? klm_launch_quad_asm_p<21>(A, B, C, M, N, K >> 1, (hipStream_t)stream)
+                               : klm_launch_quad_asm_p<22>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;   // 5: 3 on the block-scaled MFMA with unit scales (same bits, slower)
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
   if (int e = check_mx(A, B, C, M, N, K >> 1, variant)) return e;

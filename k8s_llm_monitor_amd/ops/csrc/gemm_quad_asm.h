@@ -96,7 +96,7 @@ static int klm_launch_quad_asm(const void* A, const void* B, void* C, int M, int
 // Not for a GPU shared with another stream's kernels (a collective overlapping the GEMM): tiles are assigned to workgroups
 // statically, so a workgroup that finds its CU taken starts late and finishes late; models/linear_step.py uses the
 // one-workgroup-per-tile kernel under data parallelism.
-// BODY: 0 bf16, 20 fp4, 30 fp8; + 1: C stored with `sc1 nt` (klm_quad_stream_c); 10 / 11: bf16 without its stores / without its
+// BODY: 0 bf16, 20 fp4, 30 fp8; + 1: C stored with `sc1 nt`; + 2 (fp4, fp8): on the block-scaled MFMA with unit scales (the A/B record); 10 / 11: bf16 without its stores / without its
 // epilogue (diagnostic: C is not written).
 // ------------------------------------------------------------------------------------
 #define KLM_QUAD_P_MAX_TILES 512     // per workgroup: 16 KiB of table
@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void gemm_quad_asm_p(const void* __restrict__ 
   else if constexpr (BODY == 1) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_ST);
   else if constexpr (BODY == 20) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP4);
   else if constexpr (BODY == 21) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP4_ST);
+  else if constexpr (BODY == 22) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP4_SC);
   else if constexpr (BODY == 30) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP8);
-  else KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP8_ST);
+  else if constexpr (BODY == 31) KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP8_ST);
+  else KLM_QUAD_ASM_P(KLM_QUAD_ASM_BODY_P_FP8_SC);
 #undef KLM_QUAD_ASM_P
 }
 

@@ -45,8 +45,11 @@ def frag(base, i):
 
 
 NMAJOR = False      # True: consecutive MFMAs share the B fragment (the instruction's FIRST source) instead of the A fragment
-DTYPE = "bf16"      # or "fp4": same 16-byte fragments and K tile of 128 bytes per row, the MX-scaled MFMA with unit scales
+DTYPE = "bf16"      # or "fp4": same 16-byte fragments and K tile of 128 bytes per row, the f8f6f4 MFMA
 SCALE = 176         # fp4: VGPR holding four E8M0 scales of 2^0
+# fp8 / fp4: the plain v_mfma_f32_16x16x128_f8f6f4 (one instruction word; scales are 2^0 by definition) -- or, True, the
+# block-scaled v_mfma_scale_* with unit scales in v[SCALE] (two words: same bits, fp8 -1.6 %, fp4 -3.3 %; scripts/exp/mx_noscale.py)
+MX_SCALED = False
 STORE_CACHE = ""    # cache-policy bits on the epilogue's stores (" nt": streaming)
 DMA_CACHE = ""      # cache-policy bits on the LDS-DMA (" sc0", " sc1", " nt", ..): experiment bodies only
 
@@ -60,6 +63,8 @@ def mfma(i, czero=False):
     a, b = (A0, B0) if ks == 0 else (A1, B1)
     c = "0" if (czero and ks == 0) else acc(mi, ni)
     if DTYPE == "fp4":
+        if not MX_SCALED:
+            return f"v_mfma_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {c} cbsz:4 blgp:4"
         return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {c}, v{SCALE}, v{SCALE} "
                 f"op_sel_hi:[0,0,0] cbsz:4 blgp:4")
     return f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {frag(b, ni)}, {frag(a, mi)}, {c}"
@@ -303,8 +308,9 @@ SWITCH = ["; ---- last pass of this output tile: its DMA fetches the next output
 
 
 def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
-    global NMAJOR, DTYPE, DMA_CACHE
+    global NMAJOR, DTYPE, DMA_CACHE, MX_SCALED
     NMAJOR, DTYPE, DMA_CACHE = False, dtype, ""
+    MX_SCALED = "scaled" in ablate
     fp8 = dtype == "fp8"
     rb, scale, tbl = (FRB, FSCALE, TBL_FP8) if fp8 else (RB, SCALE, TBL_BF16)
     o = setup_lines_p(rb, scale, tbl)
@@ -359,6 +365,7 @@ def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
     o += ["; ---- next output tile", "s_sub_u32 s78, s78, 1", "s_cmp_eq_u32 s78, 0", "s_cbranch_scc1 Lklm%=_done",
           "s_mov_b32 s72, s76", "s_mov_b32 s73, s77", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s70, %[ra2]", "s_mov_b32 s88, %[passes]"]
     o += next_or_none(tbl, "loop")
+    MX_SCALED = False
     o += ["s_branch Lklm%=_tile", "Lklm%=_done:",
           "; the last pass's (empty) LDS-DMA must not land in LDS the CU has handed to another workgroup",
           "s_waitcnt vmcnt(0)"]
@@ -420,6 +427,8 @@ def f8(base, i):
 
 def mfma_fp8(i, aset, czero=False):
     ni, mi = i // 8, i % 8
+    if not MX_SCALED:
+        return f"v_mfma_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {f8(FB, ni)}, {f8(FA[aset], mi)}, {'0' if czero else acc(mi, ni)}"
     return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {f8(FB, ni)}, {f8(FA[aset], mi)}, {'0' if czero else acc(mi, ni)}, "
             f"v{FSCALE}, v{FSCALE} op_sel_hi:[0,0,0]")
 
@@ -504,6 +513,7 @@ BODIES = {"": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEB
           # _ST: C stored with `sc1 nt` (written through, not kept): for shapes whose operands just fit the 256 MB Infinity Cache
           "_P_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "bf16"), "_P_FP4_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp4"),
           "_P_FP8_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp8"),
+          "_P_FP4_SC": ("persistent", ("scaled",), "fp4"), "_P_FP8_SC": ("persistent", ("scaled",), "fp8"),
           "_P": ("persistent", (), "bf16"), "_P_FP4": ("persistent", (), "fp4"), "_P_FP8": ("persistent", (), "fp8")}
 
 

@@ -84,6 +84,7 @@ def test_gemm_fp8_matches_fp32_reference(env, shape):
     if K % 256 == 0 and K >= 512:
         assert torch.equal(c, ops.gemm_fp8(a, b, variant=2)) and torch.equal(c, ops.gemm_fp8(a, b, variant=3))
         assert torch.equal(c, ops.gemm_fp8(a, b, variant=4)) and torch.equal(c, ops.gemm_fp8(a, b, variant=5))
+        assert torch.equal(c, ops.gemm_fp8(a, b, variant=6))       # the streams use the plain f8f6f4 MFMA, 6 and the ring kernels the block-scaled one
 
 
 def test_gemm_fp8_exact_on_small_integers(env):
@@ -113,7 +114,7 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     assert torch.equal(c, ops.gemm_fp4(a, b, variant=0)) and torch.equal(c, ops.gemm_fp4(a, b, variant=1))
     if (K // 2) % 256 == 0 and K // 2 >= 512:
         assert torch.equal(c, ops.gemm_fp4(a, b, variant=2)) and torch.equal(c, ops.gemm_fp4(a, b, variant=3))
-        assert torch.equal(c, ops.gemm_fp4(a, b, variant=4))
+        assert torch.equal(c, ops.gemm_fp4(a, b, variant=4)) and torch.equal(c, ops.gemm_fp4(a, b, variant=5))
     ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
     assert torch.equal(c, ref.float().to(torch.bfloat16))
     if hasattr(torch, "float4_e2m1fn_x2"):

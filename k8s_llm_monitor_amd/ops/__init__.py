@@ -72,6 +72,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
             lib.klm_hbm_copy_ex.restype = i
             lib.klm_hbm_fill_ex.argtypes = [vp, sz, u32, i, i, vp]
             lib.klm_hbm_fill_ex.restype = i
+        if hasattr(lib, "klm_hbm_read_ex"):
+            lib.klm_hbm_read_ex.argtypes = [vp, sz, vp, i, i, vp]
+            lib.klm_hbm_read_ex.restype = i
         lib.klm_hbm_read.argtypes = [vp, sz, vp, vp]
         lib.klm_hbm_read.restype = i
         lib.klm_hbm_checksum.argtypes = [vp, sz, vp, vp]
@@ -318,6 +321,14 @@ def hbm_fill_ex(t, pattern: int = 0xA5A5A5A5, flags: int = 2, grid: int = 0):
     with _on_device(t):
         _check(load().klm_hbm_fill_ex(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, flags, grid, _stream(t)), "klm_hbm_fill_ex")
     return t
+
+
+def hbm_read_ex(src, sink, flags: int = 1, grid: int = 0):
+    """Tuning variant of hbm_read (see klm_ops.h)."""
+    _require_cuda(src, sink)
+    with _on_device(src):
+        _check(load().klm_hbm_read_ex(src.data_ptr(), _nbytes(src), sink.data_ptr(), flags, grid, _stream(src)), "klm_hbm_read_ex")
+    return sink
 
 
 def hbm_read(src, sink):

@@ -2,12 +2,13 @@
 // stream, checksum and a traffic-free spin. SURVEY.md 2.4 N3 (HBM fill / exhaustion
 // injector) and N4 (HBM bandwidth burner); no reference counterpart.
 //
-// 256 threads per block (4 waves of 64), 4 independent 16-byte accesses in flight per lane.
-// Block -> data mapping and cache hints were picked by a sweep on MI355X
-// (scripts/hbm_sweep.py, profiles/r1_prof/hbm_sweep_*.log):
-//   fill  plain stores, one contiguous chunk per block, 16384 blocks     6.1 TB/s
-//   copy  one 16 KiB tile per block, nontemporal loads and stores        5.7 TB/s (read+write)
-//   read  grid-stride, nontemporal loads, 2048 blocks                    6.1 TB/s
+// 256 threads per block (4 waves of 64). Block -> data mapping and cache hints were picked by sweeps on MI355X
+// (scripts/hbm_sweep.py, profiles/r1_prof/hbm_sweep_*.log; scripts/exp/hbm_one_shot.py, profiles/r2_prof/hbm_one_shot.json).
+// What ships is the ONE-SHOT form with ONE 16-byte access per thread: no loop, a workgroup touches 4 KiB and retires, so
+// the order workgroups are dispatched in IS the address order and every memory channel sees the same steady stream:
+//   fill  plain stores                          6.9 TB/s   (looping forms, 4 stores in flight per lane: 5.9 - 6.15)
+//   copy  nontemporal loads and stores          6.4 TB/s   read + write   (16 KiB tile per block: 5.65; torch copy_: 4.6)
+//   read  nontemporal loads                     7.1 TB/s   (grid-stride loop over 2048 blocks: 6.1)
 // (the first version, a 2048-block grid-stride loop with nontemporal stores, wrote 4.6-4.7).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -125,17 +126,18 @@ __global__ __launch_bounds__(kBlock) void hbm_fill_ex_kernel(u32x4* __restrict__
   for (; i < end; i += stride) dst[i] = v;
 }
 
-// One-shot form: no loop, one 16 KiB tile (kBlock x kUnroll x 16 B) per block, grid = tiles.
-template <bool NTL, bool NTS>
+// One-shot form: no loop, one tile of kBlock x U x 16 bytes per block (U = 4: 16 KiB; U = 1: one 16-byte access per thread,
+// the shape of torch's vectorized fill, which writes 6.9 TB/s where every looping form stays at 6.1), grid = tiles.
+template <bool NTL, bool NTS, int U>
 __global__ __launch_bounds__(kBlock) void hbm_copy_tile_kernel(u32x4* __restrict__ dst,
                                                                const u32x4* __restrict__ src, size_t n16) {
-  const size_t base = (size_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x;
-  if (base + (kUnroll - 1) * kBlock < n16) {
-    u32x4 v[kUnroll];
+  const size_t base = (size_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if (base + (U - 1) * kBlock < n16) {
+    u32x4 v[U];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) v[u] = NTL ? __builtin_nontemporal_load(src + base + u * kBlock) : src[base + u * kBlock];
+    for (int u = 0; u < U; ++u) v[u] = NTL ? __builtin_nontemporal_load(src + base + u * kBlock) : src[base + u * kBlock];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (NTS) __builtin_nontemporal_store(v[u], dst + base + u * kBlock);
       else dst[base + u * kBlock] = v[u];
     }
@@ -144,13 +146,13 @@ __global__ __launch_bounds__(kBlock) void hbm_copy_tile_kernel(u32x4* __restrict
   }
 }
 
-template <bool NTS>
+template <bool NTS, int U>
 __global__ __launch_bounds__(kBlock) void hbm_fill_tile_kernel(u32x4* __restrict__ dst, size_t n16, uint32_t pattern) {
   const u32x4 v = {pattern, pattern, pattern, pattern};
-  const size_t base = (size_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x;
-  if (base + (kUnroll - 1) * kBlock < n16) {
+  const size_t base = (size_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  if (base + (U - 1) * kBlock < n16) {
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (NTS) __builtin_nontemporal_store(v, dst + base + u * kBlock);
       else dst[base + u * kBlock] = v;
     }
@@ -159,7 +161,22 @@ __global__ __launch_bounds__(kBlock) void hbm_fill_tile_kernel(u32x4* __restrict
   }
 }
 
-static inline size_t tiles_for(size_t n16) { return (n16 + kBlock * kUnroll - 1) / (kBlock * kUnroll); }
+// one-shot read: every thread loads U x 16 bytes; the store never happens (see hbm_read_kernel)
+template <bool NTL, int U>
+__global__ __launch_bounds__(kBlock) void hbm_read_tile_kernel(const u32x4* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
+  const size_t base = (size_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+  if (base + (U - 1) * kBlock < n16) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= NTL ? __builtin_nontemporal_load(src + base + u * kBlock) : src[base + u * kBlock];
+  } else {
+    for (size_t i = base; i < n16; i += kBlock) acc ^= src[i];
+  }
+  const uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+  if (x == 0xA5C3F00Du) sink[0] = x;
+}
+
+static inline size_t tiles_for(size_t n16, int u = kUnroll) { return (n16 + (size_t)kBlock * u - 1) / ((size_t)kBlock * u); }
 
 static inline int check(const void* a, const void* b, size_t bytes) {
   if (!a) return KLM_ERR_ARG;
@@ -170,19 +187,13 @@ static inline int check(const void* a, const void* b, size_t bytes) {
 
 static inline int done() { return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP; }
 
-static inline int chunk_grid(size_t n16) {
-  // one contiguous chunk per block; 16384 blocks measured best (profiles/r1_prof/hbm_sweep_2.log)
-  const size_t per_block = (size_t)kBlock * kUnroll;
-  size_t g = (n16 + per_block - 1) / per_block;
-  if (g < 1) g = 1;
-  if (g > 16384) g = 16384;
-  return (int)g;
-}
-
 extern "C" int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream) {
   if (int e = check(dst, nullptr, bytes)) return e;
   const size_t n16 = bytes >> 4;
-  hipLaunchKernelGGL((hbm_fill_ex_kernel<false, true>), dim3(chunk_grid(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+  const size_t tiles = tiles_for(n16, 1);
+  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+  // one 16-byte store per thread: 6.9 TB/s (the chunked loop over 16384 blocks wrote 6.15)
+  hipLaunchKernelGGL((hbm_fill_tile_kernel<false, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
                      (u32x4*)dst, n16, pattern);
   return done();
 }
@@ -191,10 +202,10 @@ extern "C" int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stre
   if (!src) return KLM_ERR_ARG;
   if (int e = check(dst, src, bytes)) return e;
   const size_t n16 = bytes >> 4;
-  const size_t tiles = tiles_for(n16);
+  const size_t tiles = tiles_for(n16, 1);
   if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
-  // one-shot 16 KiB tiles, nontemporal loads and stores: 5.66 TB/s vs 4.74 for the strided loop
-  hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
+  // one 16-byte load + store per thread, both nontemporal: 6.44 TB/s (16 KiB tiles: 5.65; the strided loop: 4.74)
+  hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
                      (u32x4*)dst, (const u32x4*)src, n16);
   return done();
 }
@@ -202,22 +213,26 @@ extern "C" int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stre
 extern "C" int klm_hbm_copy_ex(void* dst, const void* src, size_t bytes, int flags, int grid, void* stream) {
   if (!src) return KLM_ERR_ARG;
   if (int e = check(dst, src, bytes)) return e;
-  if (grid < 0 || grid > 1 << 20 || flags < 0 || flags > 15) return KLM_ERR_ARG;
+  if (grid < 0 || grid > 1 << 20 || flags < 0 || flags > 31) return KLM_ERR_ARG;
   const size_t n16 = bytes >> 4;
   const dim3 g(grid ? grid : grid_for(n16)), b(kBlock);
   hipStream_t s = (hipStream_t)stream;
   u32x4* d = (u32x4*)dst;
   const u32x4* r = (const u32x4*)src;
-  if (flags & 8) {
-    const size_t tiles = tiles_for(n16);
+  if (flags & 24) {      // one-shot tiles: 8 -> 4 accesses per thread, 16 -> 1, 24 -> 2
+    const int u = (flags & 24) == 8 ? 4 : (flags & 24) == 16 ? 1 : 2;
+    const size_t tiles = tiles_for(n16, u);
     if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
     const dim3 gt((unsigned)tiles);
-    switch (flags & 3) {
-      case 0: hipLaunchKernelGGL((hbm_copy_tile_kernel<false, false>), gt, b, 0, s, d, r, n16); break;
-      case 1: hipLaunchKernelGGL((hbm_copy_tile_kernel<true, false>), gt, b, 0, s, d, r, n16); break;
-      case 2: hipLaunchKernelGGL((hbm_copy_tile_kernel<false, true>), gt, b, 0, s, d, r, n16); break;
-      default: hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true>), gt, b, 0, s, d, r, n16); break;
+#define KLM_COPY_TILE(U)                                                                                  \
+    switch (flags & 3) {                                                                                  \
+      case 0: hipLaunchKernelGGL((hbm_copy_tile_kernel<false, false, U>), gt, b, 0, s, d, r, n16); break; \
+      case 1: hipLaunchKernelGGL((hbm_copy_tile_kernel<true, false, U>), gt, b, 0, s, d, r, n16); break;  \
+      case 2: hipLaunchKernelGGL((hbm_copy_tile_kernel<false, true, U>), gt, b, 0, s, d, r, n16); break;  \
+      default: hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true, U>), gt, b, 0, s, d, r, n16); break;  \
     }
+    if (u == 4) { KLM_COPY_TILE(4) } else if (u == 1) { KLM_COPY_TILE(1) } else { KLM_COPY_TILE(2) }
+#undef KLM_COPY_TILE
     return done();
   }
   switch (flags) {
@@ -235,16 +250,20 @@ extern "C" int klm_hbm_copy_ex(void* dst, const void* src, size_t bytes, int fla
 
 extern "C" int klm_hbm_fill_ex(void* dst, size_t bytes, uint32_t pattern, int flags, int grid, void* stream) {
   if (int e = check(dst, nullptr, bytes)) return e;
-  if (grid < 0 || grid > 1 << 20 || flags < 0 || flags > 15) return KLM_ERR_ARG;
+  if (grid < 0 || grid > 1 << 20 || flags < 0 || flags > 31) return KLM_ERR_ARG;
   const size_t n16 = bytes >> 4;
   const dim3 g(grid ? grid : grid_for(n16)), b(kBlock);
   hipStream_t s = (hipStream_t)stream;
   u32x4* d = (u32x4*)dst;
-  if (flags & 8) {
-    const size_t tiles = tiles_for(n16);
+  if (flags & 24) {      // one-shot tiles: 8 -> 4 stores per thread, 16 -> 1, 24 -> 2
+    const int u = (flags & 24) == 8 ? 4 : (flags & 24) == 16 ? 1 : 2;
+    const size_t tiles = tiles_for(n16, u);
     if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
-    if (flags & 2) hipLaunchKernelGGL((hbm_fill_tile_kernel<true>), dim3((unsigned)tiles), b, 0, s, d, n16, pattern);
-    else hipLaunchKernelGGL((hbm_fill_tile_kernel<false>), dim3((unsigned)tiles), b, 0, s, d, n16, pattern);
+    const dim3 gt((unsigned)tiles);
+    const bool nts = flags & 2;
+    if (u == 4) { if (nts) hipLaunchKernelGGL((hbm_fill_tile_kernel<true, 4>), gt, b, 0, s, d, n16, pattern); else hipLaunchKernelGGL((hbm_fill_tile_kernel<false, 4>), gt, b, 0, s, d, n16, pattern); }
+    else if (u == 1) { if (nts) hipLaunchKernelGGL((hbm_fill_tile_kernel<true, 1>), gt, b, 0, s, d, n16, pattern); else hipLaunchKernelGGL((hbm_fill_tile_kernel<false, 1>), gt, b, 0, s, d, n16, pattern); }
+    else { if (nts) hipLaunchKernelGGL((hbm_fill_tile_kernel<true, 2>), gt, b, 0, s, d, n16, pattern); else hipLaunchKernelGGL((hbm_fill_tile_kernel<false, 2>), gt, b, 0, s, d, n16, pattern); }
     return done();
   }
   const bool nts = flags & 2, chunk = flags & 4;
@@ -259,8 +278,36 @@ extern "C" int klm_hbm_read(const void* src, size_t bytes, void* sink8, void* st
   if (!sink8) return KLM_ERR_ARG;
   if (int e = check(src, nullptr, bytes)) return e;
   const size_t n16 = bytes >> 4;
-  hipLaunchKernelGGL(hbm_read_kernel, dim3(grid_for(n16)), dim3(kBlock), 0, (hipStream_t)stream,
+  const size_t tiles = tiles_for(n16, 1);
+  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+  // one nontemporal 16-byte load per thread: 7.07 TB/s (the grid-stride loop: 6.09)
+  hipLaunchKernelGGL((hbm_read_tile_kernel<true, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
                      (const u32x4*)src, n16, (uint32_t*)sink8);
+  return done();
+}
+
+// Tuning variants of the read stream: flags bit 0 nontemporal loads; bits 3-4 one-shot tiles (8: 4 loads per thread, 16: 1, 24: 2),
+// else the grid-stride loop over `grid` blocks (0 = default).
+extern "C" int klm_hbm_read_ex(const void* src, size_t bytes, void* sink8, int flags, int grid, void* stream) {
+  if (!sink8) return KLM_ERR_ARG;
+  if (int e = check(src, nullptr, bytes)) return e;
+  if (grid < 0 || grid > 1 << 20 || flags < 0 || flags > 31) return KLM_ERR_ARG;
+  const size_t n16 = bytes >> 4;
+  hipStream_t s = (hipStream_t)stream;
+  const u32x4* r = (const u32x4*)src;
+  uint32_t* k = (uint32_t*)sink8;
+  if (!(flags & 24)) {
+    hipLaunchKernelGGL(hbm_read_kernel, dim3(grid ? grid : grid_for(n16)), dim3(kBlock), 0, s, r, n16, k);
+    return done();
+  }
+  const int u = (flags & 24) == 8 ? 4 : (flags & 24) == 16 ? 1 : 2;
+  const size_t tiles = tiles_for(n16, u);
+  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+  const dim3 gt((unsigned)tiles), b(kBlock);
+  const bool ntl = flags & 1;
+  if (u == 4) { if (ntl) hipLaunchKernelGGL((hbm_read_tile_kernel<true, 4>), gt, b, 0, s, r, n16, k); else hipLaunchKernelGGL((hbm_read_tile_kernel<false, 4>), gt, b, 0, s, r, n16, k); }
+  else if (u == 1) { if (ntl) hipLaunchKernelGGL((hbm_read_tile_kernel<true, 1>), gt, b, 0, s, r, n16, k); else hipLaunchKernelGGL((hbm_read_tile_kernel<false, 1>), gt, b, 0, s, r, n16, k); }
+  else { if (ntl) hipLaunchKernelGGL((hbm_read_tile_kernel<true, 2>), gt, b, 0, s, r, n16, k); else hipLaunchKernelGGL((hbm_read_tile_kernel<false, 2>), gt, b, 0, s, r, n16, k); }
   return done();
 }
 

@@ -66,6 +66,8 @@ int klm_hbm_read(const void* src, size_t bytes, void* sink8, void* stream);  // 
 // contiguous chunk per block; grid = number of 256-thread blocks (0 = the default cap).
 int klm_hbm_copy_ex(void* dst, const void* src, size_t bytes, int flags, int grid, void* stream);
 int klm_hbm_fill_ex(void* dst, size_t bytes, uint32_t pattern, int flags, int grid, void* stream);
+// flags bits 3-4 (copy, fill, read): one-shot tiles instead of a loop, 8: 4 accesses of 16 bytes per thread, 16: 1, 24: 2.
+int klm_hbm_read_ex(const void* src, size_t bytes, void* sink8, int flags, int grid, void* stream);
 // Sums 32-bit words of [src, src+bytes) into *sum64 (device memory, must be zeroed by the
 // caller on the same stream). Used to check that a filled region holds its pattern.
 int klm_hbm_checksum(const void* src, size_t bytes, void* sum64, void* stream);

@@ -158,7 +158,7 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream in its persistent
     form (8: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue) for whole
     256 x 256 tiles and an even number of K tiles >= 4, else the 8-wave ring kernel (2, or 1 for an odd tile count), else
-    the 128x128 one (0). 4: the same stream, one workgroup per tile; 9: 8 with C stored past the caches (`sc1 nt`: +1.6 - 2.7 %
+    the 128x128 one (0; also for shapes of at most 32 tiles of 256 x 256, which would leave most CUs idle). 4: the same stream, one workgroup per tile; 9: 8 with C stored past the caches (`sc1 nt`: +1.6 - 2.7 %
     when one 8192^3 GEMM repeats on the same operands, which then stay in the Infinity Cache; -0.8 % in the training step,
     -12 % at K = 1024: not a default); 48 / 49: 8 without its stores / epilogue (diagnostic); 3: the compiler-scheduled 4-wave kernel
     (gemm_quad128.h); 5..7: earlier placements of the hand-scheduled stream; 44..47: stream 4 with cache-policy bits on
@@ -172,8 +172,13 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
         raise KlmOpsError(f"gemm_bf16 shapes {tuple(a.shape)} x {tuple(b.shape)}^T do not match")
     M, K = a.shape
     N = b.shape[0]
+    pitch = _pitch_bytes(a, b)
     if variant is None:
-        if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
+        if pitch:
+            variant = 8        # row-pitched operands: the streams are the kernels that take a pitch
+        elif (M // 256) * (N // 256) <= 32 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
+            variant = 0        # a handful of 256 x 256 tiles leaves most CUs idle: 1024^3 runs at 127 TFLOP/s on 128 x 128 tiles, 101 on 256 x 256
+        elif M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
             variant = 8 if (K % 128 == 0 and K >= 256) else 1      # an even number of K tiles >= 4, else the ring's schedule 0
         else:
             variant = 0
@@ -183,7 +188,6 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
         _require_cuda(out)
         if out.shape != (M, N) or out.dtype != torch.bfloat16:
             raise KlmOpsError("gemm_bf16: bad `out`")
-    pitch = _pitch_bytes(a, b)
     with _on_device(a):
         if pitch:
             # row-pitched operands (padded_operand): the hand-scheduled streams only

@@ -19,7 +19,10 @@ is fixed. The shipped bf16 / fp4 schedule ("stagger", see SCHEDULES for the othe
     126                s_waitcnt lgkmcnt(0)
   An M0 write sits one gap before the DMA that uses it (SALU write of M0 -> LDS-DMA needs a wait state).
   Epilogue: fp32 -> bf16, v_permlane16_swap_b32 pairs n tiles so every store is 16 bytes per lane (epilogue_lines).
-  fp8 has its own register plan and tile (tile_fp8).
+  fp8 has its own register plan and tile (tile_fp8); fp8 and fp4 use the plain v_mfma_f32_16x16x128_f8f6f4 (MX_SCALED).
+  Bodies come in two shapes: one output tile per workgroup (body, body_fp8) and the persistent form (body_p: one workgroup
+  per CU walks its tiles as one stream of K tiles; the default kernels). BODIES lists every macro the .inc defines,
+  experiments and diagnostic streams included.
 
 Registers (fixed, all on the asm statement's clobber list):
   a[0:255]        accumulators, tile (mi, ni) at a[4 (8 mi + ni)]

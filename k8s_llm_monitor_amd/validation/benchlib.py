@@ -103,7 +103,40 @@ def vendor_comparison(torch, ops, dev, size: int, rounds: int = 5, iters: int = 
         out["fp8_klm_over_scaled_mm"] = round(med["fp8_klm"] / med["fp8_scaled_mm"], 4)
     if err:
         out["errors"] = err
+    del a, b, a8, b8, c
+    try:
+        out["hbm"] = hbm_vendor_comparison(torch, ops, dev)
+    except Exception as e:
+        out["hbm"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def hbm_vendor_comparison(torch, ops, dev, gib: int = 2, rounds: int = 3, iters: int = 10) -> Dict[str, Any]:
+    """The HBM kernels next to what the framework offers for the same job on the same buffers: ``Tensor.fill_`` (an
+    elementwise kernel) and ``Tensor.copy_`` (the runtime's copy kernel). TB/s, median round; copy counts read + write."""
+    n = gib << 30
+    x = torch.empty(n, dtype=torch.uint8, device=dev)
+    y = torch.empty(n, dtype=torch.uint8, device=dev)
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    ops.hbm_fill(x, 0x01020304)
+    cands = {"fill_klm": (lambda: ops.hbm_fill(y, 0x5A5A5A5A), n), "fill_torch": (lambda: y.fill_(7), n),
+             "copy_klm": (lambda: ops.hbm_copy(y, x), 2 * n), "copy_torch": (lambda: y.copy_(x), 2 * n),
+             "read_klm": (lambda: ops.hbm_read(x, sink), n)}
+    runs: Dict[str, list] = {k: [] for k in cands}
+    for r in range(rounds + 1):
+        for name, (fn, nbytes) in cands.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            if r:
+                runs[name].append(nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    med = {k: round(sorted(v)[len(v) // 2], 2) for k, v in runs.items()}
+    return {"buffer_GiB": gib, "TBps_median": med, "fill_klm_over_torch": round(med["fill_klm"] / med["fill_torch"], 3),
+            "copy_klm_over_torch": round(med["copy_klm"] / med["copy_torch"], 3)}
 
 
 def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:

@@ -161,8 +161,7 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     the 128x128 one (0; also for shapes of at most 32 tiles of 256 x 256, which would leave most CUs idle). 4: the same stream, one workgroup per tile; 9: 8 with C stored past the caches (`sc1 nt`: +1.6 - 2.7 %
     when one 8192^3 GEMM repeats on the same operands, which then stay in the Infinity Cache; -0.8 % in the training step,
     -12 % at K = 1024: not a default); 48 / 49: 8 without its stores / epilogue (diagnostic); 3: the compiler-scheduled 4-wave kernel
-    (gemm_quad128.h); 5..7: earlier placements of the hand-scheduled stream; 44..47: stream 4 with cache-policy bits on
-    its LDS-DMA; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
+    (gemm_quad128.h); 5..7: earlier placements of the hand-scheduled stream; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
     """
     import torch
     _require_rows(a, b)

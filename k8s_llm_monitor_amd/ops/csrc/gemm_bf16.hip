@@ -368,7 +368,7 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
     if (int e = variant == 8 ? klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s)
               : variant == 48 ? klm_launch_quad_asm_p<10>(A, B, C, M, N, K * 2, s) : klm_launch_quad_asm_p<11>(A, B, C, M, N, K * 2, s)) return e;
-  } else if ((variant >= 4 && variant <= 7) || (variant >= 40 && variant <= 47)) {
+  } else if ((variant >= 4 && variant <= 7) || (variant >= 40 && variant <= 43)) {
     // hand-scheduled streams (gemm_quad_asm.h): 4 the kernel; 5..7 earlier placements; 40..43 diagnostic, results meaningless
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
     int e = KLM_OK;
@@ -380,11 +380,7 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
       case 40: e = klm_launch_quad_asm<10>(A, B, C, M, N, K * 2, s); break;
       case 41: e = klm_launch_quad_asm<11>(A, B, C, M, N, K * 2, s); break;
       case 42: e = klm_launch_quad_asm<12>(A, B, C, M, N, K * 2, s); break;
-      case 43: e = klm_launch_quad_asm<13>(A, B, C, M, N, K * 2, s); break;
-      case 44: e = klm_launch_quad_asm<14>(A, B, C, M, N, K * 2, s); break;   // 44..47: cache bits on the LDS-DMA
-      case 45: e = klm_launch_quad_asm<15>(A, B, C, M, N, K * 2, s); break;
-      case 46: e = klm_launch_quad_asm<16>(A, B, C, M, N, K * 2, s); break;
-      default: e = klm_launch_quad_asm<17>(A, B, C, M, N, K * 2, s); break;
+      default: e = klm_launch_quad_asm<13>(A, B, C, M, N, K * 2, s); break;
     }
     if (e) return e;
   } else if (variant == 1 || variant == 2) {

@@ -12,8 +12,7 @@
 
 // BODY: 0 the bf16 kernel (schedule "stagger"); 1..3 earlier placements of the same instructions (spread, one_barrier,
 // per_operand), kept for the A/B record; 10..13 diagnostic streams without the loop's DMA / fragment reads / K advance
-// (DMA from L2 only) / all of it (results meaningless: they price each kind of instruction); 14..17 stream 0 with cache-policy
-// bits sc0 / sc1 / nt / sc1 nt on its LDS-DMA (right results; an experiment); 20 the fp4 kernel; 30 the fp8 kernel.
+// (DMA from L2 only) / all of it (results meaningless: they price each kind of instruction); 20 the fp4 kernel; 30 the fp8 kernel.
 // Kb: the operands' row length in BYTES (bf16: 2 K, fp4: K / 2); a K tile is 128 bytes of a row in every format.
 // ld: the row PITCH of A and B in bytes (>= Kb, a multiple of 16): dense operands have ld = Kb; a burner that owns its operands
 // pads the pitch away from the strides the memory channels camp on (docs/KERNELS.md, "row pitch").
@@ -69,10 +68,6 @@ __global__ __launch_bounds__(256) void gemm_quad_asm(const void* __restrict__ A,
   else if constexpr (BODY == 11) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_NOREAD);
   else if constexpr (BODY == 12) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_L2ONLY);
   else if constexpr (BODY == 13) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_MFMAONLY);
-  else if constexpr (BODY == 14) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_SC0);
-  else if constexpr (BODY == 15) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_SC1);
-  else if constexpr (BODY == 16) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_NT);
-  else if constexpr (BODY == 17) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_SC1NT);
   else if constexpr (BODY == 20) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_FP4);
   else if constexpr (BODY == 30) KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_FP8);
   else KLM_QUAD_ASM(KLM_QUAD_ASM_BODY_FP8B);

@@ -1,4 +1,5 @@
-"""Cache-policy bits on the GEMM's LDS-DMA (sc0 / sc1 / nt / sc1 nt): every operand byte is used by exactly one wave of
+"""(Historic: needs the _SC0 / _SC1 / _NT / _SC1NT bodies, which the generator no longer emits -- re-add them to BODIES and the
+dispatchers (variants 44..47) to rerun.) Cache-policy bits on the GEMM's LDS-DMA (sc0 / sc1 / nt / sc1 nt): every operand byte is used by exactly one wave of
 a CU, so the vector L1 holds nothing worth keeping. Right results in every arm; interleaved timing at 8192^3."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -510,8 +510,8 @@ BODIES = {"": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEB
           "_NODMA": ("spread", ("dma",), "bf16"), "_NOREAD": ("spread", ("read",), "bf16"), "_L2ONLY": ("spread", ("bump",), "bf16"),
           "_MFMAONLY": ("spread", ("dma", "read", "barrier"), "bf16"),
           "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"), "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8"),
-          "_SC0": ("stagger", ("cache:sc0",), "bf16"), "_SC1": ("stagger", ("cache:sc1",), "bf16"), "_NT": ("stagger", ("cache:nt",), "bf16"),
-          "_SC1NT": ("stagger", ("cache:sc1", "cache:nt"), "bf16"),
+          # ("cache:sc0" / "cache:sc1" / "cache:nt" in the ablation tuple put cache-policy bits on the LDS-DMA; measured: sc0 / sc1 no
+          #  change, nt -10 %, profiles/r2_prof/dma_cache_bits.json -- the bodies are no longer generated)
           "_P_NOSTORE": ("persistent", ("store",), "bf16"), "_P_NOEPI": ("persistent", ("epilogue",), "bf16"),
           # _ST: C stored with `sc1 nt` (written through, not kept): for shapes whose operands just fit the 256 MB Infinity Cache
           "_P_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "bf16"), "_P_FP4_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp4"),

@@ -23,7 +23,6 @@ def env():
                                            (5, (512, 768, 384)), (6, (512, 768, 384)), (7, (512, 768, 384)), (5, (256, 256, 4352)),
                                            (8, (256, 256, 256)), (8, (512, 768, 384)), (8, (2048, 1024, 4096)), (8, (256, 512, 4352)),
                                            (9, (512, 768, 384)), (9, (2048, 1024, 4096)),
-                                           (44, (512, 768, 384)), (45, (512, 768, 384)), (46, (512, 768, 384)), (47, (512, 768, 384)),
                                            (None, (1024, 1024, 1024)), (None, (384, 128, 64)), (None, (256, 256, 192))])
 def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch, ops, dev = env

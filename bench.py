@@ -116,6 +116,9 @@ def launch_ranks(a, argv) -> int:
 
 def main():
     a = parse_args()
+    # RCCL and tensor sharing between processes need dmabuf IPC on this driver (without it: hipIpcGetMemHandle: invalid
+    # argument). The variable is exported on the build and GPU boxes; set it for the ranks wherever it is not.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and a.gpus > 1:
         raise SystemExit(launch_ranks(a, sys.argv[1:]))

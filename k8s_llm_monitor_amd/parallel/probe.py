@@ -168,7 +168,10 @@ def run_native(n_gpus: int, dtype: str = "bf16", min_bytes: int = 1024, max_byte
     cmd = [exe, "--gpus", str(n_gpus), "--dtype", dtype, "--min", str(min_bytes), "--max", str(max_bytes),
            "--factor", str(factor), "--warmup", str(warmup), "--iters", str(iters)]
     run = runner or subprocess.run
-    r = run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    # several devices in one process share buffers through dmabuf IPC on this driver (see bench.py)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True, env=env)
     parsed = parse_probe_output(r.stdout)
     if r.returncode != 0 or parsed["errors"] or not parsed["points"]:
         raise RuntimeError(f"rccl probe failed (rc={r.returncode}): {parsed['errors'] or r.stderr[-400:]}")

@@ -184,6 +184,33 @@ def test_gemm_streams_take_row_pitched_operands(env, pad_bytes):
     assert ops.padded_operand(256, 8192, torch.bfloat16, dev).is_contiguous() and ops.padded_operand(256, 12032, torch.bfloat16, dev).is_contiguous()
 
 
+def test_default_dispatch_over_random_shapes(env):
+    """`variant=None` over random tile-aligned shapes (every kernel family gets picked: 128 x 128, ring, persistent stream,
+    padded operands): bf16 against the fp32 product, fp8 / fp4 against their ring kernels bit for bit."""
+    import random
+    torch, ops, dev = env
+    rnd = random.Random(1234)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    for _ in range(24):
+        M, N = 128 * rnd.randint(1, 20), 128 * rnd.randint(1, 20)
+        K = 64 * rnd.randint(2, 40)
+        a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        c = ops.gemm_bf16(a, b)
+        torch.testing.assert_close(c.float(), a.float() @ b.float().t(), rtol=1.6e-2, atol=6e-3 * K ** 0.5, msg=lambda m: f"{M}x{N}x{K}: {m}")
+        if M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and K >= 256:
+            a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+            assert torch.equal(ops.gemm_fp8(a8, b8), ops.gemm_fp8(a8, b8, variant=1)), (M, N, K)
+            a4 = torch.randint(0, 256, (M, K), device=dev, generator=g, dtype=torch.uint8)
+            b4 = torch.randint(0, 256, (N, K), device=dev, generator=g, dtype=torch.uint8)
+            assert torch.equal(ops.gemm_fp4(a4, b4), ops.gemm_fp4(a4, b4, variant=1)), (M, N, K)
+            # the same operands in padded allocations
+            pa, pb = ops.padded_operand(M, K, torch.bfloat16, dev, pad_bytes=256), ops.padded_operand(N, K, torch.bfloat16, dev, pad_bytes=256)
+            pa.copy_(a); pb.copy_(b)
+            if not pa.is_contiguous():
+                assert torch.equal(ops.gemm_bf16(pa, pb), ops.gemm_bf16(a, b, variant=4)), (M, N, K)
+
+
 def test_fp4_decode_table(env):
     torch, ops, dev = env
     codes = torch.arange(256, device=dev, dtype=torch.uint8).reshape(1, 256)

@@ -194,7 +194,10 @@ class TPGroup:
             self.comm = None
 
     def describe(self) -> dict:
-        d = {"world": self.world, "rank": self.rank, "backend": self.backend}
+        d = {"world": self.world, "rank": self.rank, "backend": self.backend,
+             # the start-up self-test of the mesh kernels (every schedule + an all-gather with known operands), as `/stats` shows it
+             "self_test": ("passed" if self.comm is not None else
+                           f"failed, fell back to RCCL: {self.self_test_error}" if self.self_test_error else "not run (no mesh kernels in this group)")}
         if self.comm is not None:
             d["xgmi"] = self.comm.describe()
         return d

@@ -67,7 +67,7 @@ def test_tensor_parallel_model_and_engine_two_ranks_on_one_gpu():
     sharded argmax run on the mesh kernels (also inside the decode hipGraphs), the engine runs in lock-step."""
     res = run_ranks("tp_worker.py", 2, ["--gpu", "--model", "small"], timeout=380)
     for r in res:
-        assert r["tp"]["backend"] == "xgmi" and r["tp"]["xgmi"]["world"] == 2
+        assert r["tp"]["backend"] == "xgmi" and r["tp"]["xgmi"]["world"] == 2 and r["tp"]["self_test"] == "passed"
         assert r["local_shapes"] == [8, 2, 4096, 16000]
         assert r["model_max_abs_err"] < 0.04 * max(1.0, r["model_logit_scale"]), r          # bf16 partial sums
         assert r["sharded_argmax_agrees"] and r["loop_ok"], r
@@ -121,6 +121,7 @@ def test_serve_llm_tp_cli_two_ranks_share_the_gpu():
         assert all(len(o["choices"][0]["token_ids"]) == 24 for o in outs)
         st = json.loads(urllib.request.urlopen(url + "/stats", timeout=5).read())["engine"]
         assert st["tensor_parallel"]["backend"] == "xgmi" and st["tensor_parallel"]["world"] == 2 and st["graphs"], st
+        assert st["tensor_parallel"]["self_test"] == "passed"
         assert st["errors"] == 0 and st["step_counts"]["decode"] >= 69
         text = urllib.request.urlopen(url + "/metrics", timeout=5).read().decode()
         assert "vllm:generation_tokens_total" in text

@@ -211,6 +211,33 @@ def test_default_dispatch_over_random_shapes(env):
                 assert torch.equal(ops.gemm_bf16(pa, pb), ops.gemm_bf16(a, b, variant=4)), (M, N, K)
 
 
+def test_ops_follow_the_tensors_device_not_the_current_one(env):
+    """A process whose current device is 0 launches on device 1 (per-device kernel attributes, the persistent kernels' CU count,
+    the launch itself all act on the CURRENT device: the wrappers make that the tensor's). Needs two GPUs."""
+    torch, ops, dev = env
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    d1 = torch.device("cuda:1")
+    assert torch.cuda.current_device() == 0
+    a = torch.randn(512, 1024, device=d1, dtype=torch.bfloat16)
+    b = torch.randn(768, 1024, device=d1, dtype=torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    for v in (None, 8, 4, 2, 0):
+        torch.testing.assert_close(ops.gemm_bf16(a, b, variant=v).float(), ref, rtol=1.6e-2, atol=0.4)
+    a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+    assert torch.equal(ops.gemm_fp8(a8, b8), ops.gemm_fp8(a8, b8, variant=1))
+    x = torch.empty(1 << 26, dtype=torch.uint8, device=d1)
+    y = torch.empty_like(x)
+    ops.hbm_fill(x, 0x01020304)
+    ops.hbm_copy(y, x)
+    torch.cuda.synchronize(d1)
+    assert torch.equal(x, y) and int(y.view(torch.int32)[12345]) == 0x01020304
+    assert torch.cuda.current_device() == 0
+    from k8s_llm_monitor_amd.loadgen.burner import Burner
+    o = Burner("gemm_bf16", size=2048, duty=100.0, device=1).run(0.5)
+    assert o["kernels"] > 0 and o["tflops_busy"] > 50
+
+
 def test_fp4_decode_table(env):
     torch, ops, dev = env
     codes = torch.arange(256, device=dev, dtype=torch.uint8).reshape(1, 256)

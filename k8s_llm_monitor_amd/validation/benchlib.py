@@ -105,10 +105,36 @@ def vendor_comparison(torch, ops, dev, size: int, rounds: int = 5, iters: int = 
         out["errors"] = err
     del a, b, a8, b8, c
     try:
+        out["training_step"] = step_vendor_comparison(torch, ops, dev, size)
+    except Exception as e:
+        out["training_step"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
         out["hbm"] = hbm_vendor_comparison(torch, ops, dev)
     except Exception as e:
         out["hbm"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def step_vendor_comparison(torch, ops, dev, size: int, rounds: int = 3, steps: int = 15) -> Dict[str, Any]:
+    """The bench's own step (fwd, dgrad, wgrad of one linear layer: three GEMMs on six different operand matrices, one GPU)
+    on the hand-written kernel and on hipBLASLt (``torch.matmul``), alternating, median round."""
+    from ..models.linear_step import LinearLayerStep
+    arms = {"klm": LinearLayerStep(torch, None, ops, dev, 1, size),
+            "hipblaslt": LinearLayerStep(torch, None, ops, dev, 1, size, gemm=lambda a, b, out: torch.matmul(a, b.t(), out=out))}
+    runs: Dict[str, list] = {k: [] for k in arms}
+    for r in range(rounds + 1):
+        for name, st in arms.items():
+            st.step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                st.step()
+            e1.record()
+            e1.synchronize()
+            if r:
+                runs[name].append(st.flops * steps / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    med = {k: round(sorted(v)[len(v) // 2], 1) for k, v in runs.items()}
+    return {"tflops_median": med, "klm_over_hipblaslt": round(med["klm"] / med["hipblaslt"], 4)}
 
 
 def hbm_vendor_comparison(torch, ops, dev, gib: int = 2, rounds: int = 3, iters: int = 10) -> Dict[str, Any]:

@@ -58,6 +58,7 @@ doc["checks"] = {"gfx_mean_during_burner": sum(r["gfx"] for r in mid) / len(mid)
                  "hbm_alert_seen": any("gpu/0/hbm" in sum(r["alerts"].values(), []) for r in timeline if r["phase"] == "burner50+hbm72"),
                  "hbm_alert_cleared": not any("gpu/0/hbm" in sum(r["alerts"].values(), []) for r in timeline[-2:]),
                  "sse_realtime_events": events["realtime"], "sse_alert_events": events["alerts"]}
+os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
 json.dump(doc, open(out_path, "w"), indent=1)
 print(json.dumps(doc["checks"])); print(json.dumps(timeline[-1])); print("saved", out_path)
 assert abs(doc["checks"]["gfx_mean_during_burner"] - burn["duty_achieved"]) < 3.0 and doc["checks"]["hbm_alert_seen"] and doc["checks"]["hbm_alert_cleared"]

@@ -196,6 +196,15 @@ def derive(c: Dict[str, float], n_cu: int = 256, simd_per_cu: int = 4, n_xcd: in
     return out
 
 
+#: substrings of the bf16 burner's kernel names over the rounds: gemm_bf16_128 / gemm_bf16_256_t (ring), gemm_bf16_quad
+#: (compiler-scheduled), gemm_quad_asm / gemm_quad_asm_p (the hand-scheduled streams, shared with fp8 / fp4)
+BURNER_GEMM_NAMES = ("gemm_bf16", "gemm_quad_asm")
+
+
+def is_burner_gemm(name: str) -> bool:
+    return any(k in name for k in BURNER_GEMM_NAMES)
+
+
 def burner_cmd(kind: str = "gemm_bf16", duty: float = 50.0, seconds: float = 4.0, size: int = 8192) -> List[str]:
     """The program rocprofv3 runs: python itself, no env/shell hop in front of it."""
     return [sys.executable, "-m", "k8s_llm_monitor_amd", "burner", "--kind", kind, "--duty", str(duty),
@@ -208,7 +217,7 @@ def cross_check_duty(outdir: str, duties: Sequence[float] = (25.0, 50.0, 75.0), 
     rows = []
     for d in duties:
         res = kernel_trace(burner_cmd(duty=d, seconds=seconds), os.path.join(outdir, f"duty{int(d)}"))
-        gemm = [r for r in res["rows"] if "gemm_bf16" in r["name"]]
+        gemm = [r for r in res["rows"] if is_burner_gemm(r["name"])]
         # skip the calibration launches: measure over the duty-cycled part only
         gemm.sort(key=lambda r: r["start"])
         tail = gemm[13:] if len(gemm) > 40 else gemm
@@ -223,9 +232,11 @@ def cross_check_duty(outdir: str, duties: Sequence[float] = (25.0, 50.0, 75.0), 
     return rows
 
 
-def kernel_durations(rows: Iterable[Dict[str, Any]], name_contains: str, skip: int = 16) -> List[float]:
-    """Durations (us) of the matching dispatches in start order, without the first `skip` (calibration, cold clocks)."""
-    ks = sorted((r for r in rows if name_contains in r["name"]), key=lambda r: r["start"])
+def kernel_durations(rows: Iterable[Dict[str, Any]], name_contains, skip: int = 16) -> List[float]:
+    """Durations (us) of the matching dispatches in start order, without the first `skip` (calibration, cold clocks).
+    `name_contains`: a substring, or a predicate on the kernel name."""
+    match = name_contains if callable(name_contains) else (lambda n: name_contains in n)
+    ks = sorted((r for r in rows if match(r["name"])), key=lambda r: r["start"])
     return [(r["end"] - r["start"]) / 1e3 for r in ks[skip:]]
 
 
@@ -239,8 +250,8 @@ def overhead_kernel_trace(outdir: str, repeats: int = 3, seconds: float = 5.0, s
         for leg in ("off", "on"):
             cmd = burner_cmd(duty=100.0, seconds=seconds, size=size) + (["--monitored", "--monitor-period", str(monitor_period)] if leg == "on" else [])
             res = kernel_trace(cmd, os.path.join(outdir, f"{leg}{i}"))
-            d = kernel_durations(res["rows"], "gemm_bf16")
-            ks = sorted((r for r in res["rows"] if "gemm_bf16" in r["name"]), key=lambda r: r["start"])[16:]
+            d = kernel_durations(res["rows"], is_burner_gemm)
+            ks = sorted((r for r in res["rows"] if is_burner_gemm(r["name"])), key=lambda r: r["start"])[16:]
             med = sorted(d)[len(d) // 2] if d else 0.0
             # kernels that took more than twice the median: when in the window, and how long
             outliers = [{"at_s": round((r["start"] - ks[0]["start"]) / 1e9, 3), "us": round((r["end"] - r["start"]) / 1e3, 1)}

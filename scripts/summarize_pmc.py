@@ -13,7 +13,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     per = rocprof.read_counters(files[0])
     for k, c in per.items():
         short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        names = sys.argv[2].split(",") if len(sys.argv) > 2 else ("gemm_bf16", "gemm_fp8", "gemm_mx", "hbm_")
+        names = sys.argv[2].split(",") if len(sys.argv) > 2 else ("gemm_bf16", "gemm_fp8", "gemm_mx", "gemm_quad_asm", "Cijk", "hbm_")
         if not any(s in short for s in names):
             continue
         n = c.get("dispatches", 1) or 1

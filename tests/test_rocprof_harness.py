@@ -48,6 +48,17 @@ def test_read_csvs_and_derive(tmp_path):
     assert d["hbm_read_bytes"] == pytest.approx(2 * 2 ** 30, rel=1e-4) and d["hbm_write_bytes"] == pytest.approx(2 * 2 ** 30, rel=1e-4)
 
 
+def test_burner_kernels_are_recognised_under_every_name_they_had():
+    names = ["void gemm_bf16_256_t<false, false, 1>(...)", "gemm_bf16_128(...)", "void gemm_quad_asm<0>(void const*, ...)",
+             "void gemm_quad_asm_p<0>(void const*, void const*, unsigned short*, int, int, int, int)"]
+    assert all(rocprof.is_burner_gemm(n) for n in names)
+    assert not rocprof.is_burner_gemm("void hbm_fill_tile_kernel<false, 1>(...)") and not rocprof.is_burner_gemm("Cijk_Alik_Bljk_BBS")
+    rows = [{"name": names[3], "start": 1000 * i, "end": 1000 * i + 700} for i in range(40)] + [{"name": "other", "start": 5, "end": 9}]
+    d = rocprof.kernel_durations(rows, rocprof.is_burner_gemm, skip=16)
+    assert len(d) == 24 and d[0] == 0.7
+    assert rocprof.kernel_durations(rows, "other", skip=0) == [0.004]
+
+
 def test_burner_cmd_has_no_shell_or_env_hop():
     cmd = rocprof.burner_cmd(duty=50)
     assert cmd[0].endswith("python") or "python" in cmd[0]

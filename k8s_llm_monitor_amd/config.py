@@ -39,7 +39,9 @@ class PeriodsConfig:
     history_step: float = 30.0       # monitor_server.js:119 ('30s')
     history_window: str = "30m"      # monitor_server.js:119 ('30m')
     alert_hold: float = 30.0         # how long an edge-triggered pod alert stays visible
-    page_alert_poll: float = 5.0     # the page's /api/alerts poll; the reference polls every 10 s (monitor.html:608)
+    # the page's /api/alerts poll (its fallback path; /api/events pushes alerts as they appear). The reference polls every
+    # 10 s (monitor.html:608); 4 s keeps the poll path alone under the 10 s target: realtime 5 s + tick + 4 s < 10 s
+    page_alert_poll: float = 4.0
     probe: float = 0.0               # RCCL probe re-run period, 0 = only on demand
     peers: float = 5.0               # cluster view: peer poll period
 
@@ -162,7 +164,8 @@ class CompatConfig:
     reference_defaults: bool = False # ONE switch for a side-by-side run: everything below set to the reference's behaviour
 
 
-#: what ``compat.reference_defaults`` sets (explicit values in the same file / env still win where listed after it)
+#: what ``compat.reference_defaults`` sets: applied UNDER the file, the environment and the overrides (`load_config`),
+#: so a value the operator wrote explicitly wins over the preset
 REFERENCE_PRESET = {
     "compat": {"cpu_percent": "load", "cpu_cores": 8,                     # load_1min / 8 (monitor_server.js:76)
                "gpu0_only_alerts": True,                                  # :178
@@ -262,6 +265,9 @@ def validate(cfg: Config) -> None:
     for name in ("realtime", "pods", "vllm", "history_step"):
         if getattr(cfg.periods, name) <= 0:
             raise ConfigError(f"periods.{name} must be > 0")
+    # the page substitutes this into setInterval(fetchAlerts, ms): 0 or a negative value would hammer /api/alerts
+    if cfg.periods.page_alert_poll < 0.25:
+        raise ConfigError(f"periods.page_alert_poll must be >= 0.25 s (got {cfg.periods.page_alert_poll})")
     if cfg.notify.min_tier not in ("minor", "serious", "critical"):
         raise ConfigError("notify.min_tier must be minor, serious or critical")
     if cfg.notify.debounce_s < 0:
@@ -279,10 +285,14 @@ def validate(cfg: Config) -> None:
 
 def load_config(path: Optional[str] = None, env: Optional[Mapping[str, str]] = None,
                 overrides: Optional[Mapping[str, Any]] = None) -> Config:
-    """Defaults <- file <- environment <- explicit overrides (a nested dict)."""
+    """Defaults <- [reference preset] <- file <- environment <- explicit overrides (a nested dict).
+
+    ``compat.reference_defaults`` (set in any of the three) puts REFERENCE_PRESET UNDER them: the preset replaces this
+    project's defaults with the reference's, and every value the operator wrote explicitly (a custom gpu_temp threshold,
+    a language) still wins over it."""
     env = os.environ if env is None else env
-    cfg = Config()
     path = path or env.get("KLM_CONFIG")
+    data: Mapping[str, Any] = {}
     if path:
         p = Path(path)
         text = p.read_text(encoding="utf-8")
@@ -293,12 +303,21 @@ def load_config(path: Optional[str] = None, env: Optional[Mapping[str, str]] = N
             data = json.loads(text or "{}")
         if not isinstance(data, Mapping):
             raise ConfigError(f"{path}: top level must be a mapping")
-        _apply(cfg, data, str(path))
-    _apply_env(cfg, env)
-    if overrides:
-        _apply(cfg, overrides, "overrides")
+
+    def layered(preset: bool) -> Config:
+        cfg = Config()
+        if preset:
+            _apply(cfg, REFERENCE_PRESET, "compat.reference_defaults")
+        if data:
+            _apply(cfg, data, str(path))
+        _apply_env(cfg, env)
+        if overrides:
+            _apply(cfg, overrides, "overrides")
+        return cfg
+
+    cfg = layered(False)
     if cfg.compat.reference_defaults:
-        _apply(cfg, REFERENCE_PRESET, "compat.reference_defaults")
+        cfg = layered(True)
     validate(cfg)
     return cfg
 

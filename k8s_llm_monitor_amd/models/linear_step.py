@@ -26,7 +26,7 @@ class LinearLayerStep:
     2*size^2-byte all-reduce per step.
     """
 
-    def __init__(self, torch, dist, ops, dev, world: int, size: int, gemm=None, distributed=None):
+    def __init__(self, torch, dist, ops, dev, world: int, size: int, gemm=None, distributed=None, dp_kernel=None):
         self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
         dd = self.distributed = (world > 1) if distributed is None else bool(distributed)
         # `gemm(a, b, out)` computes out = a @ b.T; the default is the hand-written MFMA kernel.
@@ -36,8 +36,14 @@ class LinearLayerStep:
         # communication stream could only start between GEMMs and would then keep the CUs it took away from the next
         # GEMM's statically assigned workgroups (their tiles would run after everyone else's). With one workgroup per tile
         # the collective gets CUs as tiles retire and the remaining tiles flow over the CUs that are left.
+        # `dp_kernel=True` forces that stream without a process group: the one-GPU point of a scaling curve measured on the
+        # kernel the N > 1 points run (bench.py's `value_dp_kernel`), so that scaling efficiency compares like with like.
         quad = size % 256 == 0 and size >= 256
-        self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out, variant=4 if (dd and quad) else None))
+        use_dp = dd if dp_kernel is None else bool(dp_kernel)
+        variant = 4 if (use_dp and quad) else None
+        #: the bf16 kernel variant every GEMM of the step runs (None: a caller-supplied `gemm`)
+        self.gemm_variant = None if gemm is not None else (variant if variant is not None else ops.pick_bf16_variant(size, size, size))
+        self.gemm = gemm or (lambda a, b, out: ops.gemm_bf16(a, b, out=out, variant=variant))
         self.gpu = dev.type == "cuda"
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + (dist.get_rank() if dd else 0))

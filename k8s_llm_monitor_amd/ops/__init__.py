@@ -152,6 +152,17 @@ def version() -> str:
     return load().klm_version().decode()
 
 
+def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0) -> int:
+    """The kernel `gemm_bf16(variant=None)` runs for a shape (pure: no device, no library)."""
+    if pitch:
+        return 8               # row-pitched operands: the streams are the kernels that take a pitch
+    if (M // 256) * (N // 256) <= 32 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
+        return 0               # a handful of 256 x 256 tiles leaves most CUs idle: 1024^3 runs at 127 TFLOP/s on 128 x 128 tiles, 101 on 256 x 256
+    if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
+        return 8 if (K % 128 == 0 and K >= 256) else 1      # an even number of K tiles >= 4, else the ring's schedule 0
+    return 0
+
+
 def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
 
@@ -173,14 +184,7 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     N = b.shape[0]
     pitch = _pitch_bytes(a, b)
     if variant is None:
-        if pitch:
-            variant = 8        # row-pitched operands: the streams are the kernels that take a pitch
-        elif (M // 256) * (N // 256) <= 32 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
-            variant = 0        # a handful of 256 x 256 tiles leaves most CUs idle: 1024^3 runs at 127 TFLOP/s on 128 x 128 tiles, 101 on 256 x 256
-        elif M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
-            variant = 8 if (K % 128 == 0 and K >= 256) else 1      # an even number of K tiles >= 4, else the ring's schedule 0
-        else:
-            variant = 0
+        variant = pick_bf16_variant(M, N, K, pitch)
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     else:

@@ -12,8 +12,14 @@
 // Output: JSON lines on stdout (parallel/probe.py parses them):
 //   {"type":"header",...}  {"type":"point",...}*  {"type":"summary",...}   or {"type":"error",...}
 //
-// busBW = algBW * 2(n-1)/n (nccl-tests convention). n = 1 has no link traffic: RCCL does a
-// device-local copy, reported as algBW with busBW 0.
+// busBW = algBW * 2(n-1)/n (nccl-tests convention). n = 1 has no link traffic, and an IN-PLACE all-reduce on
+// a one-rank communicator is a no-op (bytes / time of nothing): at n = 1 the probe therefore always runs OUT OF
+// PLACE, which RCCL serves with a real device-local copy; the curve is labelled "local_copy" and carries algBW
+// with busBW 0 ("no traffic; report local copy rate separately").
+//
+// Every point is held against a physical bound before it is printed: nothing on this card moves more than
+// 8 TB/s locally, and no all-reduce can beat the full mesh ((n-1) links x 153 GB/s, +10 % for the link rate's
+// own uncertainty). A point above its bound gets check "implausible" (the parser marks the curve unverified).
 //
 // Data check: each rank's buffer holds (rank + 1) before the first all-reduce of a size; the
 // sum must be n(n+1)/2 in EVERY element of every rank's buffer (exact in bf16 and fp32 for
@@ -55,7 +61,7 @@ struct Args {
   std::string dtype = "bf16";
   size_t min_bytes = 1024, max_bytes = (size_t)1 << 30;
   int factor = 4, warmup = 5, iters = 20;
-  bool check = true, in_place = true, selftest = false;
+  bool check = true, in_place = true, selftest = false, selftest_bounds = false;
 };
 
 static bool parse(int argc, char** argv, Args& a) {
@@ -78,6 +84,7 @@ static bool parse(int argc, char** argv, Args& a) {
     else if (k == "--no-check") a.check = false;
     else if (k == "--out-of-place") a.in_place = false;
     else if (k == "--selftest") a.selftest = true;
+    else if (k == "--selftest-bounds") a.selftest = a.selftest_bounds = true;
     else if (k == "--help" || k == "-h") return false;
     else {
       printf("{\"type\":\"error\",\"error\":\"unknown argument %s\"}\n", k.c_str());
@@ -133,12 +140,18 @@ static std::vector<size_t> sweep_sizes(size_t min_bytes, size_t max_bytes, int f
   sizes.push_back(max_bytes - max_bytes % esz);
   return sizes;
 }
+// the physical bounds of a point, GB/s: local copy rate at n = 1, bus bandwidth of the full mesh beyond
+static const double kLocalBoundGBps = 8000.0, kLinkGBps = 153.0, kLinkSlack = 1.1;
+static double bound_GBps(int n) { return n > 1 ? (n - 1) * kLinkGBps * kLinkSlack : kLocalBoundGBps; }
+static bool plausible(int n, double alg, double bus) { return (n > 1 ? bus : alg) <= bound_GBps(n); }
+
 static void print_header(const Args& a, int n, int ver, const char* device, const char* arch) {
   printf("{\"type\":\"header\",\"n_gpus\":%d,\"dtype\":\"%s\",\"op\":\"allreduce\",\"warmup\":%d,\"iters\":%d,"
          "\"rccl_version\":%d,\"device\":\"%s\",\"arch\":\"%s\",\"min_bytes\":%zu,\"max_bytes\":%zu,\"factor\":%d,"
-         "\"in_place\":%s,\"timing\":\"event pair per rank, max over ranks\",\"check\":\"%s\"}\n",
+         "\"in_place\":%s,\"mode\":\"%s\",\"bound_GBps\":%.1f,\"timing\":\"event pair per rank, max over ranks\",\"check\":\"%s\"}\n",
          n, json_escape(a.dtype).c_str(), a.warmup, a.iters, ver, json_escape(device).c_str(), json_escape(arch).c_str(),
-         a.min_bytes, a.max_bytes, a.factor, a.in_place ? "true" : "false", a.check ? "every element, device compare" : "off");
+         a.min_bytes, a.max_bytes, a.factor, a.in_place ? "true" : "false", n > 1 ? "allreduce" : "local_copy", bound_GBps(n),
+         a.check ? "every element, device compare" : "off");
   fflush(stdout);
 }
 struct Point {
@@ -153,6 +166,7 @@ static Point make_point(size_t bytes, int n, int iters, float ms_max, float ms_r
   return p;
 }
 static void print_point(const Args& a, int n, size_t bytes, const Point& p, const char* check, size_t checked, unsigned long long mismatched) {
+  if (!plausible(n, p.alg, p.bus) && strcmp(check, "MISMATCH") != 0) check = "implausible";
   printf("{\"type\":\"point\",\"n_gpus\":%d,\"bytes\":%zu,\"dtype\":\"%s\",\"op\":\"allreduce\",\"time_us\":%.3f,"
          "\"time_us_max_rank\":%.3f,\"time_us_rank0\":%.3f,\"algbw_GBps\":%.4f,\"busbw_GBps\":%.4f,\"check\":\"%s\","
          "\"elements_checked\":%zu,\"elements_mismatched\":%llu}\n",
@@ -181,6 +195,14 @@ static int selftest(Args a) {
     print_point(a, 8, bytes, p, "ok", bytes / 2 * 8, 0);
   }
   print_summary(a, 8, peak_bus, peak_alg, peak_bytes);
+  if (!a.selftest_bounds) return 0;
+  // --selftest-bounds, the bound itself: a one-rank "copy" of 256 MiB in 0.436 us (what an in-place no-op once read as) and an
+  // 8-rank point above the mesh ceiling must both come out "implausible"; one just under each bound stays "ok"
+  const size_t mib256 = (size_t)256 << 20;
+  print_point(a, 1, mib256, make_point(mib256, 1, 1, 0.000436f, 0.000436f), "ok", mib256 / 2, 0);
+  print_point(a, 1, mib256, make_point(mib256, 1, 1, (float)(mib256 / 7.9e12 * 1e3), (float)(mib256 / 7.9e12 * 1e3)), "ok", mib256 / 2, 0);
+  print_point(a, 8, mib256, make_point(mib256, 8, 1, (float)(mib256 * 1.75 / 1200e9 * 1e3), 0.3f), "ok", mib256 * 4, 0);
+  print_point(a, 8, mib256, make_point(mib256, 8, 1, (float)(mib256 * 1.75 / 1150e9 * 1e3), 0.3f), "ok", mib256 * 4, 0);
   return 0;
 }
 
@@ -188,7 +210,7 @@ int main(int argc, char** argv) {
   Args a;
   if (!parse(argc, argv, a)) {
     fprintf(stderr, "usage: klm_rccl_probe [--gpus N] [--dtype bf16|fp32] [--min B] [--max B] [--factor F] "
-                    "[--warmup W] [--iters I] [--no-check] [--out-of-place] | --selftest\n");
+                    "[--warmup W] [--iters I] [--no-check] [--out-of-place] | --selftest | --selftest-bounds\n");
     return 0;
   }
   const bool is_bf16 = a.dtype == "bf16";
@@ -210,6 +232,7 @@ int main(int argc, char** argv) {
     return 4;
   }
   const int n = a.gpus;
+  if (n == 1) a.in_place = false;      // one rank: in place is a no-op; out of place is the device-local copy the point reports
   std::vector<int> devs(n);
   for (int i = 0; i < n; ++i) devs[i] = i;
   std::vector<ncclComm_t> comms(n);
@@ -259,6 +282,11 @@ int main(int argc, char** argv) {
       if (is_bf16) hipLaunchKernelGGL(fill16, dim3(grid), dim3(256), 0, streams[i], (uint16_t*)send[i], count, bf16_bits((float)(i + 1)));
       else hipLaunchKernelGGL(fill32, dim3(grid), dim3(256), 0, streams[i], (float*)send[i], count, (float)(i + 1));
     }
+    if (!a.in_place)       // the check must see what the collective wrote, not what the buffer held before
+      for (int i = 0; i < n; ++i) {
+        HIPCHECK(hipSetDevice(i));
+        HIPCHECK(hipMemsetAsync(recv[i], 0, bytes, streams[i]));
+      }
     sync_all();
     const char* check = "skipped";
     round(count);

@@ -36,7 +36,11 @@ def _sync(torch, dev) -> None:
 
 
 def run_op(dist, op: str, x, y, world: int, group=None):
-    if op == "allreduce":
+    if op == "allreduce" and world == 1:
+        # one rank: the collective is a no-op on the in-place buffer torch.distributed hands it. The n = 1 point is the
+        # device-local copy rate, so move the bytes for real, out of place.
+        y.copy_(x)
+    elif op == "allreduce":
         dist.all_reduce(x, group=group)
     elif op == "allgather":
         dist.all_gather_into_tensor(y, x[: x.numel() // world], group=group)
@@ -52,7 +56,9 @@ def sweep(dev, sizes: Optional[Sequence[int]] = None, dtype: str = "bf16", op: s
           warmup: int = 5, iters: int = 20, check: bool = True, group=None) -> Optional[Dict[str, Any]]:
     """Run the size sweep on `group` (default: the default process group); every member of the group
     calls it. Returns the curve on the group's rank 0, None elsewhere. The buffer is reduced IN PLACE
-     and the data check covers every element."""
+     and the data check covers every element. A one-rank group has no traffic to time: its
+    curve is the out-of-place device-local copy rate, labelled mode "local_copy"; every point is held against
+    `probe.bound_GBps` and a curve with an implausible point comes back unverified."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -62,7 +68,7 @@ def sweep(dev, sizes: Optional[Sequence[int]] = None, dtype: str = "bf16", op: s
     gran = esz * world
     max_b = max(sizes)
     x = torch.empty(max_b // esz, dtype=tdt, device=dev)
-    y = torch.empty(max_b // esz, dtype=tdt, device=dev) if op != "allreduce" else None
+    y = torch.empty(max_b // esz, dtype=tdt, device=dev) if (op != "allreduce" or world == 1) else None
     pts: List[Dict[str, Any]] = []
     for nbytes in sizes:
         nbytes -= nbytes % gran
@@ -78,6 +84,11 @@ def sweep(dev, sizes: Optional[Sequence[int]] = None, dtype: str = "bf16", op: s
             _sync(torch, dev)
             want = world * (world + 1) / 2.0            # exact in bf16 up to 22 ranks
             verdict = "ok" if bool((xv == want).all().item()) else "MISMATCH"
+            if world == 1:                              # ... and the copy the timed rounds run lands every element
+                yv.zero_()
+                run_op(dist, op, xv, yv, world, group)
+                _sync(torch, dev)
+                verdict = "ok" if verdict == "ok" and bool((yv == want).all().item()) else "MISMATCH"
         xv.fill_(1.0 / world if op == "allreduce" else 1.0)      # keeps repeated sums finite
         for _ in range(warmup):
             run_op(dist, op, xv, yv, world, group)

@@ -23,6 +23,8 @@ import time
 from typing import Any, Callable, Dict, Iterable, List, Mapping, Optional, Sequence
 
 XGMI_LINK_GBPS = 153.0
+LOCAL_BOUND_GBPS = 8000.0      # nothing on one MI355X moves more than 8 TB/s (HBM3E peak); a copy's algBW is half its traffic
+LINK_SLACK = 1.1               # the per-link figure is itself approximate
 DTYPE_BYTES = {"bf16": 2, "fp16": 2, "fp32": 4, "fp8": 1}
 
 
@@ -59,24 +61,49 @@ def ceilings(n: int, link_gbps: float = XGMI_LINK_GBPS) -> Dict[str, Optional[fl
     return {"mesh_GBps": (n - 1) * link_gbps, "ring_GBps": link_gbps}
 
 
+def bound_GBps(n: int, link_gbps: float = XGMI_LINK_GBPS) -> float:
+    """The physical bound a point is held against: the local copy rate at n = 1, the full mesh's bus bandwidth beyond."""
+    return (n - 1) * link_gbps * LINK_SLACK if n > 1 else LOCAL_BOUND_GBPS
+
+
+def plausible(n: int, algbw: float, busbw: float, link_gbps: float = XGMI_LINK_GBPS) -> bool:
+    return (busbw if n > 1 else algbw) <= bound_GBps(n, link_gbps)
+
+
+def judged(p: Mapping[str, Any], link_gbps: float = XGMI_LINK_GBPS) -> Dict[str, Any]:
+    """The point with check "implausible" when it is faster than the hardware can be (an in-place all-reduce on a
+    one-rank communicator is a no-op and once read as 615 678 GB/s with check "ok")."""
+    q = dict(p)
+    if q.get("check") != "MISMATCH" and not plausible(int(q.get("n_gpus", 1)), float(q.get("algbw_GBps") or 0.0),
+                                                        float(q.get("busbw_GBps") or 0.0), link_gbps):
+        q["check"] = "implausible"
+    return q
+
+
 def point(n: int, nbytes: int, seconds: float, dtype: str = "bf16", op: str = "allreduce",
           check: Optional[str] = None) -> Dict[str, Any]:
     alg = nbytes / seconds / 1e9 if seconds > 0 else 0.0
-    return {"type": "point", "n_gpus": n, "bytes": int(nbytes), "dtype": dtype, "op": op,
-            "time_us": seconds * 1e6, "algbw_GBps": alg, "busbw_GBps": alg * bus_factor(n, op),
-            "check": check}
+    return judged({"type": "point", "n_gpus": n, "bytes": int(nbytes), "dtype": dtype, "op": op,
+                   "time_us": seconds * 1e6, "algbw_GBps": alg, "busbw_GBps": alg * bus_factor(n, op),
+                   "check": check})
 
 
 def curve(n: int, points: Sequence[Mapping[str, Any]], dtype: str = "bf16", verified: bool = True,
           executor: str = "native", link_gbps: float = XGMI_LINK_GBPS) -> Dict[str, Any]:
-    pts = sorted((dict(p) for p in points), key=lambda p: p["bytes"])
-    peak = max(pts, key=lambda p: p["busbw_GBps"] if n > 1 else p["algbw_GBps"]) if pts else None
+    pts = sorted((judged(p, link_gbps) for p in points), key=lambda p: p["bytes"])
+    bad = [p["bytes"] for p in pts if p.get("check") not in (None, "ok", "skipped")]
+    # the peak is taken over the points that passed: an implausible point must not become the headline
+    good = [p for p in pts if p.get("check") in (None, "ok", "skipped")] or pts
+    peak = max(good, key=lambda p: p["busbw_GBps"] if n > 1 else p["algbw_GBps"]) if good else None
     c = ceilings(n, link_gbps)
-    out = {"n_gpus": n, "dtype": dtype, "executor": executor, "verified": verified, "points": pts,
+    out = {"n_gpus": n, "dtype": dtype, "executor": executor, "verified": bool(verified and not bad), "points": pts,
+           "mode": "allreduce" if n > 1 else "local_copy", "bound_GBps": bound_GBps(n, link_gbps),
            "peak_busbw_GBps": peak["busbw_GBps"] if peak else None,
-           "peak_algbw_GBps": max((p["algbw_GBps"] for p in pts), default=None),
+           "peak_algbw_GBps": max((p["algbw_GBps"] for p in good), default=None),
            "peak_bytes": peak["bytes"] if peak else None,
            "ceiling_mesh_GBps": c["mesh_GBps"], "ceiling_ring_GBps": c["ring_GBps"]}
+    if bad:
+        out["failed_bytes"] = bad
     if peak and c["mesh_GBps"]:
         out["mesh_efficiency"] = peak["busbw_GBps"] / c["mesh_GBps"]
         # a peak near one link's rate at n>2 means RCCL ran a single ring (SURVEY 5.1)
@@ -93,6 +120,7 @@ def brief(c: Mapping[str, Any]) -> Dict[str, Any]:
            "peak_bytes": c.get("peak_bytes"), "ceiling_mesh_GBps": c.get("ceiling_mesh_GBps"),
            "ceiling_ring_GBps": c.get("ceiling_ring_GBps"), "verified": c.get("verified"),
            "executor": c.get("executor"), "ranks_seen": c.get("ranks_seen", (c.get("header") or {}).get("n_gpus")),
+           "mode": c.get("mode"),
            "curve_key": key, "curve": [[p["bytes"], round(p[key], 4)] for p in c.get("points", [])]}
     for k in ("mesh_efficiency", "single_ring_suspected"):
         if k in c:
@@ -105,7 +133,8 @@ def results_doc(curves: Iterable[Mapping[str, Any]], note: str = "") -> Dict[str
     return {"timestamp": time.time(), "link_GBps": XGMI_LINK_GBPS, "note": note, "curves": cs,
             "scaling": [{"n_gpus": c["n_gpus"], "dtype": c["dtype"], "peak_busbw_GBps": c["peak_busbw_GBps"],
                          "peak_algbw_GBps": c["peak_algbw_GBps"], "ceiling_mesh_GBps": c["ceiling_mesh_GBps"],
-                         "verified": c["verified"]} for c in cs]}
+                         "verified": c["verified"], "mode": c.get("mode") or ("allreduce" if c["n_gpus"] > 1 else "local_copy")}
+                        for c in cs]}
 
 
 def merge_results(old: Optional[Mapping[str, Any]], new: Mapping[str, Any]) -> Dict[str, Any]:
@@ -176,6 +205,8 @@ def run_native(n_gpus: int, dtype: str = "bf16", min_bytes: int = 1024, max_byte
     if r.returncode != 0 or parsed["errors"] or not parsed["points"]:
         raise RuntimeError(f"rccl probe failed (rc={r.returncode}): {parsed['errors'] or r.stderr[-400:]}")
     ok = all(p.get("check") in (None, "ok") for p in parsed["points"])
+    if n_gpus == 1 and parsed["header"].get("in_place") is not False:
+        ok = False                # a one-rank in-place all-reduce moves nothing: not a measurement (an older binary)
     c = curve(n_gpus, parsed["points"], dtype, verified=ok, executor="native")
     c["header"] = parsed["header"]
     return c

@@ -420,9 +420,13 @@ class AlertBook:
         self.history: List[Dict[str, Any]] = []     # bounded log of alert begin/end events
         self.max_history = 500
 
-    def update(self, alerts: Alerts, now: float) -> Alerts:
+    def update(self, alerts: Alerts, now: float, keep_prefixes: Sequence[str] = ()) -> Alerts:
+        """`keep_prefixes`: key prefixes whose source has not reported yet (the sampler passes "pod/" until the first
+        pod list is in): known alerts under them are neither ended nor re-announced by this evaluation."""
         out = empty_alerts()
         live = set()
+        if keep_prefixes:
+            live.update(k for k in self._since if k.startswith(tuple(keep_prefixes)))
         for tier in TIERS:
             for a in alerts[tier]:
                 key = a.get("key") or a["title"]

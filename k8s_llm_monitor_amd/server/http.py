@@ -114,8 +114,8 @@ class MonitorServer:
         self.static_dir = static
         # like the reference, the page is read once at start-up and a missing file is fatal (:241)
         self.html = (static / "monitor.html").read_bytes()
-        # the page's alert poll period is configuration (reference: 10 s, monitor.html:608; default here 5 s)
-        self.html = self.html.replace(b"/*ALERT_POLL_MS*/5000", b"%d" % int(self.cfg.periods.page_alert_poll * 1000))
+        # the page's alert poll period is configuration (reference: 10 s, monitor.html:608; default here 4 s)
+        self.html = self.html.replace(b"/*ALERT_POLL_MS*/4000", b"%d" % int(self.cfg.periods.page_alert_poll * 1000))
         self._cache: Dict[str, Tuple[int, Tuple[int, str, bytes]]] = {}
         self._head_cors = ("Access-Control-Allow-Origin: %s\r\nAccess-Control-Allow-Methods: GET, OPTIONS\r\n"
                            % self.cfg.server.cors_origin).encode("latin-1")

@@ -282,18 +282,35 @@ class Monitor:
     def _evaluate(self, now: float) -> None:
         with self._lock:
             s = self._snap
-            if not (s["t_host"] and s["t_pods"]):
-                # not every source has reported yet (start-up, or right after a restart): an evaluation on half a
-                # snapshot would "end" every restored alert of the missing half and announce it again a moment later
-                return
-            alerts, self._alert_state = check_alerts(s["host"], s["gpus"], s["pods"], self._alert_state, self.cfg,
-                                                     s["vllm"] if s["vllm"].get("available") else None)
-            shown = self.book.update(alerts, now)
-            before = {a.get("key") for t in s["alerts"].values() for a in t}
+            if not s["t_host"]:
+                return                                       # nothing sampled yet
+            pods_known = bool(s["t_pods"])
+            # The first pods tick can take the kubectl / API-server timeout on a node whose API server is unreachable.
+            # Host and GPU rules (HBM, temperature, ECC) do not wait for it: they are evaluated as soon as the realtime
+            # sources have reported. Until the pod list is in, the pod half is left exactly as it was: the engine's pod
+            # table is carried over unchanged, and the book keeps (neither ends nor re-announces) the pod alerts it
+            # restored, instead of "ending" them on half a snapshot and announcing them again a moment later.
+            # The same for the vLLM scrape: "an endpoint that answered before the restart no longer does" can only be
+            # said once the scrape has run.
+            vllm_known = bool(s["t_vllm"])
+            st = self._alert_state
+            if not vllm_known and st.vllm_endpoints:
+                import dataclasses
+                st = dataclasses.replace(st, vllm_endpoints=0)
+            alerts, nxt = check_alerts(s["host"], s["gpus"], s["pods"] if pods_known else [], st, self.cfg,
+                                       s["vllm"] if s["vllm"].get("available") else None)
+            if not pods_known:
+                nxt.pods = self._alert_state.pods
+            if not vllm_known:
+                nxt.vllm_endpoints = max(nxt.vllm_endpoints, self._alert_state.vllm_endpoints)
+            self._alert_state = nxt
+            shown = self.book.update(alerts, now, keep_prefixes=(() if pods_known else ("pod/",)) + (() if vllm_known else ("vllm/",)))
+            before = {(a.get("key"), t) for t, xs in s["alerts"].items() for a in xs}
             s["alerts"], s["t_alerts"] = shown, now
             self.version += 1
-            new = [a for t in shown.values() for a in t if a.get("key") not in before]
-        if new:
+            # pushed to /api/events when the visible set changed: a new alert, a tier change, or one that cleared
+            changed = {(a.get("key"), t) for t, xs in shown.items() for a in xs} != before
+        if changed:
             self._emit("alerts", shown)
 
     def _emit(self, kind: str, payload: Any) -> None:

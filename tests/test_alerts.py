@@ -236,3 +236,19 @@ def test_reference_defaults_is_one_switch():
     # the default configuration keeps this project's wording and rules
     d, _ = check_alerts(host, gpus, [], AlertState(), load_config(env={}))
     assert any(x["title"].startswith("GPU 0 HBM") for x in d["serious"]) and any(x.get("signal") == "ecc" for x in d["critical"])
+
+
+def test_explicit_values_win_over_the_reference_preset_and_poll_period_is_validated(tmp_path):
+    """the preset used to be applied last and silently overwrote what the operator had written."""
+    import pytest
+    from k8s_llm_monitor_amd.config import ConfigError, load_config
+    f = tmp_path / "klm.json"
+    f.write_text('{"compat": {"reference_defaults": true, "language": "en"}, "thresholds": {"gpu_temp": [-1.0, 80.0, 90.0]}}')
+    cfg = load_config(str(f), env={"KLM_PERIODS_PAGE_ALERT_POLL": "7.5"}, overrides={"compat": {"cpu_cores": 32}})
+    assert cfg.thresholds.gpu_temp == [-1.0, 80.0, 90.0] and cfg.compat.language == "en"          # from the file
+    assert cfg.periods.page_alert_poll == 7.5 and cfg.compat.cpu_cores == 32                       # env, overrides
+    assert cfg.compat.gpu0_only_alerts and cfg.compat.reference_text and cfg.compat.alerts_per_request   # the rest of the preset
+    for bad in ("0", "-3", "0.1"):
+        with pytest.raises(ConfigError, match="page_alert_poll"):
+            load_config(env={"KLM_PERIODS_PAGE_ALERT_POLL": bad})
+    assert load_config(env={}).periods.page_alert_poll == 4.0

@@ -123,3 +123,52 @@ def test_live_alert_is_not_announced_twice_across_a_restart(tmp_path, clock):
     m3.tick_all()
     assert m3.alerts_public()["critical"] == [] and [e["event"] for e in m3.book.history] == ["begin", "end"]
     m3.stop()
+
+
+def test_gpu_alerts_do_not_wait_for_a_slow_kube_source(tmp_path, clock):
+    """the first pods tick can block for the kubectl / API-server timeout; host and GPU rules (HBM, temperature,
+    ECC) must fire meanwhile, and a restored pod alert must neither end nor be announced again before the pod list is in."""
+    from k8s_llm_monitor_amd.fakes.gpu import GpuState
+
+    m1 = make(clock, tmp_path, kube="pending")
+    m1.tick_all()
+    clock.advance(5)
+    m1.tick_all()
+    assert [a["key"] for a in m1.alerts_public()["serious"]] == ["pod/llm/vllm-llama3-405b-tp8-0/pending"]
+    m1.stop()
+
+    def hot(t, i):
+        return GpuState(hbm_frac=0.97 if i == 0 else 0.30)
+
+    cfg = demo_config(server={"state_dir": str(tmp_path)}, periods={"history_step": 5.0})
+    m2 = Monitor(cfg, gpu=GpuSource(FakeGpuReader(2, scenario=hot, clock=clock)), kube=FakeKube("pending", clock=clock), clock=clock)
+    events = []
+    m2.book.on_event = events.append
+    pods_before = dict(m2._alert_state.pods)
+    assert pods_before and m2.get("t_pods") == 0.0
+    m2.tick_realtime()                                      # the pods tick is still stuck in its first call
+    assert [a["key"] for a in m2.alerts_public()["critical"]] == ["gpu/0/hbm"]          # not suppressed
+    assert m2._alert_state.pods == pods_before              # the restored pod table is untouched
+    assert [(e["event"], e["key"]) for e in events] == [("begin", "gpu/0/hbm")]          # the pod alert was not "ended"
+    m2.tick_pods()                                          # ... and now the pod list arrives: same alert, same `since`, no new begin
+    assert [a["key"] for a in m2.alerts_public()["serious"]] == ["pod/llm/vllm-llama3-405b-tp8-0/pending"]
+    assert [(e["event"], e["key"]) for e in events] == [("begin", "gpu/0/hbm")]
+    m2.stop()
+
+
+def test_sse_is_told_when_an_alert_clears(clock):
+    from k8s_llm_monitor_amd.fakes.gpu import GpuState
+    level = {"hbm": 0.97}
+    cfg = demo_config()
+    m = Monitor(cfg, gpu=GpuSource(FakeGpuReader(1, scenario=lambda t, i: GpuState(hbm_frac=level["hbm"]), clock=clock)),
+                kube=FakeKube("steady", clock=clock), clock=clock)
+    pushed = []
+    m.listeners.append(lambda kind, payload: pushed.append((kind, sorted(a["key"] for t in payload.values() for a in t))) if kind == "alerts" else None)
+    m.tick_all()
+    clock.advance(5)
+    m.tick_all()                                            # unchanged: nothing pushed again
+    level["hbm"] = 0.30
+    clock.advance(5)
+    m.tick_all()
+    assert pushed == [("alerts", ["gpu/0/hbm"]), ("alerts", [])]
+    m.stop()

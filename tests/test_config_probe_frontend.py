@@ -74,7 +74,8 @@ def test_results_roundtrip_and_merge(tmp_path):
     d1 = probe.results_doc([probe.curve(1, [probe.point(1, 1024, 1e-6)]), probe.curve(8, [], verified=False, executor="none")])
     probe.save_results(d1, p)
     assert probe.load_results(p)["scaling"][1] == {"n_gpus": 8, "dtype": "bf16", "peak_busbw_GBps": None, "peak_algbw_GBps": None,
-                                                   "ceiling_mesh_GBps": 1071.0, "verified": False}
+                                                   "ceiling_mesh_GBps": 1071.0, "verified": False, "mode": "allreduce"}
+    assert probe.load_results(p)["scaling"][0]["mode"] == "local_copy"
     d2 = probe.merge_results(probe.load_results(p), probe.results_doc([probe.curve(8, [probe.point(8, 1 << 30, 2e-3)])]))
     assert [c["n_gpus"] for c in d2["curves"]] == [1, 8] and d2["curves"][1]["verified"]
     assert probe.load_results(str(tmp_path / "none.json")) is None
@@ -95,6 +96,18 @@ def test_native_probe_driver_with_a_stub_runner():
         return subprocess.CompletedProcess(cmd, 1, json.dumps({"type": "error", "error": "need 2 devices, have 1"}), "")
     with pytest.raises(RuntimeError, match="need 2 devices"):
         probe.run_native(2, exe="/x", runner=failing)
+
+    # n = 1: only an out-of-place run (a real local copy) is a measurement; an in-place header (an older binary's no-op
+    # timing) and a point faster than 8 TB/s both leave the curve unverified
+    def one(in_place, seconds):
+        out = "\n".join([json.dumps({"type": "header", "n_gpus": 1, "in_place": in_place, "mode": "local_copy"}),
+                         json.dumps(dict(probe.point(1, 1 << 28, seconds), check="ok"))])
+        return lambda cmd, **kw: subprocess.CompletedProcess(cmd, 0, out, "")
+    good = probe.run_native(1, exe="/x", runner=one(False, (1 << 28) / 3.1e12))
+    assert good["verified"] and good["mode"] == "local_copy" and good["peak_algbw_GBps"] == pytest.approx(3100.0)
+    assert not probe.run_native(1, exe="/x", runner=one(True, (1 << 28) / 3.1e12))["verified"]
+    noop = probe.run_native(1, exe="/x", runner=one(False, 0.436e-6))
+    assert not noop["verified"] and noop["points"][0]["check"] == "implausible" and noop["failed_bytes"] == [1 << 28]
 
 
 # ---- frontend ------------------------------------------------------------------------------

@@ -63,7 +63,7 @@ def test_real_demo_payloads_render_every_panel(tmp_path, demo_payloads):
     o = run_page(tmp_path, demo_payloads)
     assert o["errors"] == [], o["errors"]
     assert set(ROUTES) <= set(o["fetched"])
-    assert sorted(o["intervals"]) == sorted([5000, 30000, 10000, 5000, 5000, 60000, 10000, 60000, 1000])     # reference loops 5/30/10 s + additions
+    assert sorted(o["intervals"]) == sorted([5000, 30000, 10000, 4000, 5000, 60000, 10000, 60000, 1000])     # reference loops 5/30/10 s + additions
     host, gpus = demo_payloads["/api/host/metrics"], demo_payloads["/api/gpu/metrics"]
     assert o["text"]["cpuValue"] == host["cpu"]["percent"] + "%" and o["text"]["memValue"] == host["memory"]["percent"] + "%"
     assert o["text"]["gpuLabel"].startswith("8 卡 · ") and o["text"]["gpuLabel"].endswith(" MB")
@@ -150,3 +150,19 @@ def test_single_gpu_without_named_peers_shows_the_reason(tmp_path, demo_payloads
     o = run_page(tmp_path, dict(demo_payloads, **{"/api/gpu/metrics": g}))
     assert o["errors"] == [] and o["rows"]["xgmiMatrixBody"] == []
     assert "not visible" in o["text"]["xgmiMatrixNote"] and o["text"]["gpuValue"].endswith("%") and " 卡" not in o["text"]["gpuLabel"]
+
+
+def test_unverified_one_gpu_probe_point_prints_na_not_a_number(tmp_path, demo_payloads):
+    """an in-place all-reduce on a one-rank communicator is a no-op and read as 615 678 GB/s; the probe
+    now judges such a point implausible, and the page shows n/a for an unverified n = 1 curve and does not draw the point."""
+    noop = [probe.point(1, b, 0.436e-6, check="ok") for b in (1024, 1 << 24, 1 << 28)]
+    assert [p["check"] for p in noop] == ["ok", "implausible", "implausible"]          # 1 KiB in 0.436 us is 2.3 GB/s: fine
+    c1 = probe.curve(1, noop)
+    assert c1["verified"] is False and c1["failed_bytes"] == [1 << 24, 1 << 28] and c1["peak_algbw_GBps"] < 8000
+    doc = probe.results_doc([c1, probe.curve(2, [probe.point(2, b, b / 120e9) for b in (1024, 1 << 24, 1 << 28)])])
+    o = run_page(tmp_path, dict(demo_payloads, **{"/api/rccl/probe": doc}))
+    assert o["errors"] == [], o["errors"]
+    note = o["text"]["rcclNote"]
+    assert "1 GPU: n/a" in note and "615" not in note and "2 GPU: 120" in note
+    d = o["evals"]["rccl_data"]
+    assert d[0][0] == pytest.approx(1024 / 0.436e-6 / 1e9) and d[0][1:] == [None, None] and d[1][2] == pytest.approx(120.0)

@@ -3,6 +3,7 @@ burner's duty control, the HBM hold, the native RCCL probe at n = 1, and the who
 HBM alert on real memory. Short on purpose; the long measurements live in
 ``python -m k8s_llm_monitor_amd validate``."""
 import json
+import os
 import subprocess
 import time
 
@@ -140,9 +141,28 @@ def test_hbm_hold_moves_the_amdsmi_reading_and_releases(torch_dev):
 
 def test_native_rccl_probe_single_gpu(torch_dev):
     from k8s_llm_monitor_amd.parallel import probe
-    c = probe.run_native(1, max_bytes=1 << 26, iters=5, warmup=2, timeout=120)
-    assert c["verified"] and c["n_gpus"] == 1 and c["peak_busbw_GBps"] == 0.0 and c["peak_algbw_GBps"] > 50.0
-    assert c["header"]["arch"].startswith("gfx950")
+    c = probe.run_native(1, max_bytes=1 << 28, iters=5, warmup=2, timeout=120)
+    assert c["verified"] and c["n_gpus"] == 1 and c["peak_busbw_GBps"] == 0.0
+    # a REAL device-local copy (out of place; in place was a no-op that read as 615 678 GB/s): between 0.5 and 8 TB/s
+    assert c["mode"] == "local_copy" and c["header"]["in_place"] is False and c["header"]["mode"] == "local_copy"
+    assert 500.0 < c["peak_algbw_GBps"] < 8000.0, c["peak_algbw_GBps"]
+    assert all(p["check"] == "ok" for p in c["points"]) and c["header"]["arch"].startswith("gfx950")
+
+
+def test_dist_probe_one_rank_is_a_local_copy(torch_dev, tmp_path):
+    """The torch.distributed executor at n = 1 (one RCCL rank in a child process): an out-of-place copy, bounded, never a
+    no-op timing."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "probe.json"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", "-m", "k8s_llm_monitor_amd.parallel.dist_probe", "--max-bytes", str(1 << 28), "--factor", "16",
+                        "--iters", "5", "--warmup", "2", "--out", str(out)], cwd=root, capture_output=True, text=True, timeout=200,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    c = json.loads(out.read_text())["curves"][0]
+    assert c["verified"] and c["mode"] == "local_copy" and c["executor"] == "torch.distributed/nccl"
+    assert 500.0 < c["peak_algbw_GBps"] < 8000.0, c["peak_algbw_GBps"]
 
 
 def test_real_hbm_crossing_raises_the_alert_over_http(torch_dev):

@@ -144,6 +144,15 @@ def test_probe_selftest_output_feeds_the_curve_builder(asan_bins):
         assert p["busbw_GBps"] == pytest.approx(p["algbw_GBps"] * 2 * 7 / 8, rel=1e-3)
     c = probe.curve(8, parsed["points"], "bf16", verified=True, executor="native")
     assert c["peak_bytes"] == 1 << 28 and 300 < c["peak_busbw_GBps"] < 400
+    assert h["mode"] == "allreduce" and h["bound_GBps"] == pytest.approx(7 * 153.0 * 1.1)
+    # the physical bound: a 0.436 us "copy" of 256 MiB and a point above the mesh ceiling are implausible
+    r = run([str(asan_bins["klm_rccl_probe"]), "--selftest-bounds", "--max", "4096"])
+    assert r.returncode == 0 and _clean(r), r.stderr[-1500:]
+    extra = probe.parse_probe_output(r.stdout)["points"][-4:]
+    assert [(p["n_gpus"], p["check"]) for p in extra] == [(1, "implausible"), (1, "ok"), (8, "implausible"), (8, "ok")]
+    assert extra[0]["algbw_GBps"] > 600000 and [probe.judged(dict(p, check="ok"))["check"] for p in extra] == [p["check"] for p in extra]
+    c = probe.curve(1, extra[:2], "bf16", verified=True, executor="native")
+    assert c["verified"] is False and c["mode"] == "local_copy" and c["peak_algbw_GBps"] == pytest.approx(7900.0, rel=1e-3)
     # an odd max and a factor whose product would overflow size_t end the list at max without looping
     r = run([str(asan_bins["klm_rccl_probe"]), "--selftest", "--min", "3", "--max", str((1 << 63) + 5), "--factor", "1000000"])
     assert r.returncode == 0 and _clean(r), r.stderr[-1500:]

@@ -12,11 +12,20 @@ iteration of exactly that load, on every rank, with the telemetry sampler runnin
     2. for N > 1: the data-parallel gradient all-reduce (RCCL, sum, bf16, 128 MiB of dW) on a
        communication stream, overlapped with the next step's fwd and dgrad (dW double-buffered).
 
-``value`` is the whole-job burner rate in TFLOP/s (sum over ranks, weak scaling); the
-JSON line also carries the all-reduce bus bandwidth and, from short phases outside the
-timed region, the monitor's own figures: sampling overhead (burner rate with the sampler
-on vs off), telemetry error (HBM used vs. the allocator's ground truth, GFX activity vs.
-the known duty cycle) and alert latency (HBM threshold crossing -> alert visible).
+``value`` is the whole-job burner rate in TFLOP/s (sum over ranks, weak scaling), taken at steady
+state: the warm-up is ``--warmup`` steps and at least two seconds of steps, so the figure does not
+move with ``--steps``. From short phases outside the timed region come the monitor's own figures,
+which are BASELINE.json's metric: telemetry error (HBM used vs. the allocator's ground truth, GFX
+activity vs. the known duty cycle, power gauge vs. energy counter), sampling overhead (burner rate
+with the whole product on vs. off), alert latency (threshold crossing -> alert visible, per delivery
+path) and the power-cap / throttle alerts firing on real hardware.
+
+Output contract: the LAST line of stdout is ONE compact JSON object (< 4 KB): the required keys, the
+BASELINE.json metric as flat scalars, ``gemm_variant``, ``rccl_ranks_seen`` and the peak bus bandwidth
+per n. Everything else (per-phase rows, the full curves, llm_serving, vendor_comparison) goes to
+``bench_detail.json`` (its path is in the line as ``detail``) and, as progress, to stderr.
+``--time-budget S`` (default 540) sheds sections and validation phases, longest first, rather than
+overrunning; what was shed is listed in the line (``shed``).
 
 Launch: ``python bench.py --gpus N`` starts its own N ranks (one process per GPU under
 ``torch.distributed.run``, as a CHILD of a parent that never touches the GPU), or launch the ranks
@@ -33,8 +42,10 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+T_PROCESS_START = time.time()
 
 
 def parse_args():
@@ -62,6 +73,14 @@ def parse_args():
                     help="self-launched runs only: skip the C++ probe (klm_rccl_probe, one process driving n devices) "
                          "that the GPU-free parent runs for every n after the ranks have exited")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launched runs: limit for the ranks, s")
+    ap.add_argument("--time-budget", type=float, default=540.0,
+                    help="wall-clock budget of the whole run in s (0 = unlimited): sections outside the timed region and "
+                         "validation phases that do not fit are shed, longest first, instead of overrunning")
+    ap.add_argument("--min-warmup-seconds", type=float, default=2.0,
+                    help="warm up for at least this long (on top of --warmup steps) so that `value` is a steady-state figure")
+    ap.add_argument("--detail-out", default="", help="where the full result goes (default: bench_detail.json next to bench.py)")
+    ap.add_argument("--rehearsal-phases", default="",
+                    help="--cpu-rehearsal only: stand-in validation phases 'name:priced_s:actual_s,...' (tests of the time budget)")
     return ap.parse_args()
 
 
@@ -89,7 +108,8 @@ def launch_ranks(a, argv) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
     print(f"[bench] launching {a.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
-    env = dict(os.environ, KLM_BENCH_LAUNCHER="self")
+    env = dict(os.environ, KLM_BENCH_LAUNCHER="self", KLM_BENCH_T0=str(time.time()))
+    t_start = time.monotonic()
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, timeout=a.launch_timeout)
     except subprocess.TimeoutExpired:
@@ -100,16 +120,37 @@ def launch_ranks(a, argv) -> int:
         sys.stderr.write((r.stdout or "")[-2000:])
         print(f"[bench] ranks failed: rc={r.returncode}, result line {'missing' if res is None else 'present'}", file=sys.stderr)
         return r.returncode or 1
+    from k8s_llm_monitor_amd.validation import benchlib
     res["launcher"] = "bench.py self-launch (child torch.distributed.run)"
-    if not (a.cpu_rehearsal or a.no_probe or a.no_native_probe):
+    spent = time.monotonic() - t_start
+    left = None if not a.time_budget else a.time_budget - spent
+    if not (a.cpu_rehearsal or a.no_probe or a.no_native_probe) and (left is None or left > 60.0):
         # the same curve from the other executor, with no rank process left on the devices
+        native = None
         try:
             from k8s_llm_monitor_amd.parallel import probe
             counts = [n for n in (1, 2, 4, 8) if n <= a.gpus]
-            doc = probe.run_sweep(counts, available=a.gpus, max_bytes=a.probe_max_bytes, warmup=3, iters=10, timeout=240.0)
-            res["rccl_curves_native"] = {str(c["n_gpus"]): probe.brief(c) for c in doc["curves"] if c.get("executor") == "native"}
+            per = 240.0 if left is None else max(20.0, (left - 15.0) / len(counts))
+            doc = probe.run_sweep(counts, available=a.gpus, max_bytes=a.probe_max_bytes, warmup=3, iters=10, timeout=min(240.0, per))
+            native = {str(c["n_gpus"]): probe.brief(c) for c in doc["curves"] if c.get("executor") == "native"}
         except Exception as e:
-            res["rccl_curves_native"] = {"error": f"{type(e).__name__}: {e}"}
+            native = {"error": f"{type(e).__name__}: {e}"}
+        # the full curves join the detail file; the line gets the peak per n
+        detail = res.get("detail")
+        full = None
+        if detail:
+            try:
+                with open(detail, "r", encoding="utf-8") as f:
+                    full = json.load(f)
+            except (OSError, ValueError):
+                full = None
+        if full is not None:
+            full["rccl_curves_native"] = native
+            full["launcher"] = res["launcher"]
+            benchlib.write_detail(full, detail)
+        res.update({k: v for k, v in benchlib.compact({"rccl_curves_native": native}).items() if k.startswith(("peak_busbw", "rccl_curves_native"))})
+    elif not (a.cpu_rehearsal or a.no_probe or a.no_native_probe):
+        res.setdefault("shed", []).append("native_probe")
     print(json.dumps(res), flush=True)
     return 0
 
@@ -155,12 +196,26 @@ def main():
             # host-side control group: ranks that sit out a sub-communicator sweep wait here, off the GPU
             a.ctrl_group = dist.new_group(backend="gloo")
 
-    from k8s_llm_monitor_amd.validation import benchlib
+    from k8s_llm_monitor_amd.validation import benchlib, phases
+    # the budget's clock starts where the run started: at this process's start, or at the self-launching parent's
+    spent = max(0.0, time.time() - float(os.environ.get("KLM_BENCH_T0", T_PROCESS_START)))
+    a.budget = phases.Budget(a.time_budget if a.time_budget > 0 else None, t0=time.monotonic() - spent)
+    if os.environ.get("KLM_BENCH_LAUNCHER") == "self" and a.budget.seconds is not None and not (a.no_probe or a.no_native_probe or a.cpu_rehearsal):
+        a.budget.reserve_s += 25.0 * len([n for n in (1, 2, 4, 8) if n <= a.gpus])      # the parent's native probe comes after the ranks
     result = benchlib.run(a, rank=rank, world=world, dev=dev, ops=ops)
     if rank == 0:
         result.setdefault("launcher", "torch.distributed.run" if env_world is not None and
                           os.environ.get("KLM_BENCH_LAUNCHER") != "self" else "single process")
-        print(json.dumps(result), flush=True)
+        path = benchlib.detail_path(a)
+        try:
+            benchlib.write_detail(result, path)
+        except OSError as e:
+            print(f"[bench] could not write {path}: {e}", file=sys.stderr)
+            path = ""
+        # the detail for a reader of the log; the contract's line is the last thing on stdout
+        print("[bench] detail: " + json.dumps({k: result[k] for k in ("validation", "wall_seconds", "shed", "rccl_curves") if k in result})[:6000],
+              file=sys.stderr, flush=True)
+        print(json.dumps(benchlib.compact(result, path)), flush=True)
     if distributed:
         dist.barrier(group=a.ctrl_group)
         dist.destroy_process_group()

@@ -17,6 +17,7 @@ Usage::
 from __future__ import annotations
 
 import argparse
+import hashlib
 import os
 import shutil
 import subprocess
@@ -41,11 +42,39 @@ class Target:
     extra: List[str] = field(default_factory=list)
     deps: List[Path] = field(default_factory=list)  # headers etc. for staleness
 
+    def source_hash(self) -> str:
+        """sha256 over what the artefact is made from: kind, extra flags, and the CONTENT of every source and header.
+        Passed to the compiler as KLM_SRC_HASH and embedded in the binary (marker ``KLM_SRC_HASH=<hash>``)."""
+        h = hashlib.sha256()
+        h.update(("%s|%s|%s" % (self.kind, ARCH, " ".join(self.extra))).encode())
+        for p in sorted([*self.sources, *self.deps], key=lambda q: q.name):
+            h.update(b"\0" + p.name.encode() + b"\0")
+            if p.exists():
+                h.update(p.read_bytes())
+        return h.hexdigest()[:16]
+
     def stale(self) -> bool:
-        if not self.out.exists():
-            return True
-        t = self.out.stat().st_mtime
-        return any(p.exists() and p.stat().st_mtime > t for p in [*self.sources, *self.deps])
+        """Stale = the binary does not carry the hash of the tree's sources. Content, not mtimes: a snapshot copy or a
+        `git checkout` rewrites every mtime, and a `.so` older or newer than its sources proves nothing either way."""
+        return not self.out.exists() or embedded_hash(self.out) != self.source_hash()
+
+
+HASH_MARKER = b"KLM_SRC_HASH="
+
+
+def embedded_hash(path: Path) -> Optional[str]:
+    """The hash a built artefact carries (None: built by other means, or before hashes existed)."""
+    try:
+        data = path.read_bytes()
+    except OSError:
+        return None
+    i = data.find(HASH_MARKER)
+    while i >= 0:
+        tail = data[i + len(HASH_MARKER): i + len(HASH_MARKER) + 16]
+        if len(tail) == 16 and all(c in b"0123456789abcdef" for c in tail):
+            return tail.decode()
+        i = data.find(HASH_MARKER, i + 1)
+    return None
 
 
 def hipcc() -> Optional[str]:
@@ -92,13 +121,13 @@ def _cmd(t: Target) -> List[str]:
         if cc is None:
             raise RuntimeError("hipcc not found (set HIPCC or ROCM_PATH)")
         base = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function",
-                "-x", "hip"]
+                f'-DKLM_SRC_HASH="{t.source_hash()}"', "-x", "hip"]
         if t.kind == "hip-shared":
             base += ["-shared", "-fPIC"]
         return [*base, *srcs, "-o", str(t.out), *t.extra]
     if t.kind == "cxx-exe":
         cxx = shutil.which("g++") or shutil.which("c++") or "g++"
-        return [cxx, "-O2", "-std=c++17", "-Wall", *srcs, "-o", str(t.out), *t.extra]
+        return [cxx, "-O2", "-std=c++17", "-Wall", f'-DKLM_SRC_HASH="{t.source_hash()}"', *srcs, "-o", str(t.out), *t.extra]
     raise ValueError(t.kind)
 
 
@@ -162,7 +191,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     a = ap.parse_args(argv)
     if a.list:
         for t in targets():
-            print(f"{t.name:22s} {t.kind:10s} {'stale' if t.stale() else 'ok':5s} {t.out}")
+            print(f"{t.name:22s} {t.kind:10s} {'stale' if t.stale() else 'ok':5s} src:{t.source_hash()} built:{embedded_hash(t.out)} {t.out}")
         return 0
     built = build_all(force=a.force, only=a.targets or None)
     if a.sanitize:

@@ -532,15 +532,20 @@ class NativeSamplerReader(GpuReader):
     at a high internal rate and emits one aggregated line per period (mean and peak)."""
     kind = "native"
 
+    #: raw keys the in-process reader emits and the sampler does not, on purpose: `xgmi_nearest` comes from the Python
+    #: bindings' topology helper (amdsmi_get_link_topology_nearest per link type), which only orders peers the link slots
+    #: already name; nothing downstream of the normaliser reads it for alerts or panels other than the matrix tooltip
+    RAW_KEYS_NOT_EMITTED = frozenset({"xgmi_nearest"})
+
     def __init__(self, exe: str = "", period: float = 1.0, hz: float = 20.0,
-                 argv: Optional[Sequence[str]] = None):
+                 argv: Optional[Sequence[str]] = None, processes: bool = False):
         if not exe:
             from ..build import artifact
             exe = str(artifact("klm_amdsmi_sampler"))
         if argv is None and not os.path.exists(exe):
             raise FileNotFoundError(exe)
         self.exe = exe
-        cmd = list(argv) if argv is not None else [exe, "--period", str(period), "--hz", str(hz)]
+        cmd = list(argv) if argv is not None else [exe, "--period", str(period), "--hz", str(hz)] + (["--processes"] if processes else [])
         self._p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                    text=True, bufsize=1)
         self._latest: List[Dict[str, Any]] = []
@@ -642,7 +647,8 @@ def open_gpu_source(kind: str = "auto", cfg=None) -> GpuSource:
     if kind == "native":
         exe = getattr(getattr(cfg, "sources", None), "native_sampler", "") if cfg is not None else ""
         period = getattr(getattr(cfg, "periods", None), "realtime", 1.0) if cfg is not None else 1.0
-        return GpuSource(NativeSamplerReader(exe=exe, period=min(period, 1.0)))
+        procs = bool(getattr(getattr(cfg, "sources", None), "gpu_processes", False)) if cfg is not None else False
+        return GpuSource(NativeSamplerReader(exe=exe, period=min(period, 1.0), processes=procs))
     if kind == "exporter":
         from .exporter import ExporterGpuReader
         ex = getattr(cfg, "exporter", None)

@@ -28,6 +28,12 @@
 #include <thread>
 #include <vector>
 
+// the hash of the sources this binary was built from (build.py passes KLM_SRC_HASH and finds the marker to decide staleness)
+#ifndef KLM_SRC_HASH
+#define KLM_SRC_HASH "unhashed"
+#endif
+extern "C" __attribute__((used)) const char klm_src_hash_marker[] = "KLM_SRC_HASH=" KLM_SRC_HASH;
+
 static volatile sig_atomic_t g_stop = 0;
 static void on_signal(int) { g_stop = 1; }
 
@@ -117,13 +123,17 @@ struct Gpu {
   std::string topo_note, xgmi_err = "unknown";
   bool xgmi_err_supported = true;
   double cap_w = NAN, energy_res_uj = NAN;
-  Gauge gfx, umc, power, temp, temp_mem, clk;
+  Gauge gfx, umc, power, temp, temp_mem, temp_edge, clk;
   amdsmi_gpu_metrics_t m;
   bool have_m = false;
   amdsmi_vram_usage_t vram{};
   bool have_vram = false;
   amdsmi_error_count_t ecc{};
   bool have_ecc = false;
+  // --processes: the per-process VRAM table (slow call, off by default like the Python reader's)
+  struct Proc { uint32_t pid; std::string name; uint64_t vram; };
+  std::vector<Proc> procs;
+  bool have_procs = false;
 };
 
 template <class T>
@@ -207,6 +217,36 @@ static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, d
       r.opt("xgmi_link_width", m.xgmi_link_width);
       r.opt("xgmi_link_speed", m.xgmi_link_speed);
       r.opt("pcie_bandwidth_inst", m.pcie_bandwidth_inst);
+      // PCIe link health and shape (collectors/gpu.py metrics_to_raw: the replay alert and the link card read these)
+      r.opt("pcie_bandwidth_acc", m.pcie_bandwidth_acc);
+      r.opt("pcie_link_speed", m.pcie_link_speed);
+      r.opt("pcie_link_width", m.pcie_link_width);
+      r.opt("pcie_replay_acc", m.pcie_replay_count_acc);
+      r.opt("pcie_replay_rollover_acc", m.pcie_replay_rover_count_acc);
+      r.opt("pcie_l0_recovery_acc", m.pcie_l0_to_recov_count_acc);
+      r.opt("pcie_nak_sent_acc", m.pcie_nak_sent_count_acc);
+      r.opt("pcie_nak_rcvd_acc", m.pcie_nak_rcvd_count_acc);
+      // per-XCD busy accumulators and gauges: the populated entries of every compute partition's row, in order (one row of
+      // 8 in SPX mode, 8 rows of 1 in CPX) -- `_flatten_ints` on the Python side
+      {
+        std::string acc = "[", inst = "[";
+        bool any_acc = false, any_inst = false;
+        for (int p = 0; p < AMDSMI_MAX_NUM_XCP; ++p)
+          for (int x = 0; x < AMDSMI_MAX_NUM_XCC; ++x) {
+            if (ok(m.xcp_stats[p].gfx_busy_acc[x])) {
+              if (any_acc) acc += ',';
+              acc += std::to_string(m.xcp_stats[p].gfx_busy_acc[x]);
+              any_acc = true;
+            }
+            if (ok(m.xcp_stats[p].gfx_busy_inst[x])) {
+              if (any_inst) inst += ',';
+              inst += std::to_string(m.xcp_stats[p].gfx_busy_inst[x]);
+              any_inst = true;
+            }
+          }
+        if (any_acc) { r.key("xcd_busy_acc"); r.s += acc + "]"; }
+        if (any_inst) { r.key("xcd_busy_inst"); r.s += inst + "]"; }
+      }
       auto arr64 = [&](const char* k, const uint64_t* a) {
         r.key(k);
         r.s += '[';
@@ -233,8 +273,25 @@ static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, d
       p.num("power_w", g.power.max());
       p.num("temp_hotspot", g.temp.max());
       p.num("temp_mem", g.temp_mem.max());
+      p.num("temp_edge", g.temp_edge.max());
       p.s += '}';
       r.s += p.s;
+    }
+    if (g.have_procs) {
+      r.u64("processes", g.procs.size());
+      r.key("process_list");
+      r.s += '[';
+      for (size_t k = 0; k < g.procs.size(); ++k) {
+        if (k) r.s += ',';
+        Json q;
+        q.s = "{";
+        q.u64("pid", g.procs[k].pid);
+        q.str("name", g.procs[k].name.c_str());
+        q.u64("vramBytes", g.procs[k].vram);
+        q.s += '}';
+        r.s += q.s;
+      }
+      r.s += ']';
     }
     r.s += '}';
     j.s += r.s;
@@ -243,6 +300,7 @@ static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, d
     g.power.reset();
     g.temp.reset();
     g.temp_mem.reset();
+    g.temp_edge.reset();
     g.clk.reset();
   }
   j.s += "]}";
@@ -359,6 +417,22 @@ static int selftest() {
     g.m.xgmi_link_width = 16;
     g.m.xgmi_link_speed = 38;
     g.m.pcie_bandwidth_inst = 18;
+    g.m.pcie_bandwidth_acc = 123456789ull;
+    g.m.pcie_link_speed = 320;                        // 0.1 GT/s: Gen5
+    g.m.pcie_link_width = 16;
+    g.m.pcie_replay_count_acc = 7 + i;
+    g.m.pcie_replay_rover_count_acc = 0;
+    g.m.pcie_l0_to_recov_count_acc = 2;
+    g.m.pcie_nak_sent_count_acc = 0;                  // pcie_nak_rcvd_count_acc stays all-ones: unsupported -> null
+    for (int x = 0; x < AMDSMI_MAX_NUM_XCC; ++x) {    // SPX: partition 0 carries all eight XCDs, the other rows stay unsupported
+      g.m.xcp_stats[0].gfx_busy_acc[x] = 1000000ull * (x + 1) + i;
+      g.m.xcp_stats[0].gfx_busy_inst[x] = 10 * x;
+    }
+    if (i == 1) {
+      g.procs.push_back({4242u, "python3 \"vllm\"", 17179869184ull});
+      g.procs.push_back({4243u, "klm_burner", 2147483648ull});
+      g.have_procs = true;
+    }
     for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
       const bool self = (size_t)l == i;
       g.m.xgmi_read_data_acc[l] = self ? 0 : 43353304ull + l;
@@ -396,7 +470,7 @@ static int selftest() {
 
 int main(int argc, char** argv) {
   double period = 1.0, hz = 20.0;
-  bool once = false;
+  bool once = false, processes = false;
   long max_lines = 0;
   for (int i = 1; i < argc; ++i) {
     std::string k = argv[i];
@@ -404,9 +478,10 @@ int main(int argc, char** argv) {
     else if (k == "--hz" && i + 1 < argc) hz = atof(argv[++i]);
     else if (k == "--lines" && i + 1 < argc) max_lines = atol(argv[++i]);
     else if (k == "--once") once = true;
+    else if (k == "--processes") processes = true;
     else if (k == "--selftest") return selftest();
     else {
-      fprintf(stderr, "usage: klm_amdsmi_sampler [--period S] [--hz H] [--lines N] [--once] [--selftest]\n");
+      fprintf(stderr, "usage: klm_amdsmi_sampler [--period S] [--hz H] [--lines N] [--once] [--processes] [--selftest]\n");
       return k == "--help" ? 0 : 1;
     }
   }
@@ -481,6 +556,7 @@ int main(int argc, char** argv) {
         else if (ok(g.m.average_socket_power)) g.power.add(g.m.average_socket_power);
         if (ok(g.m.temperature_hotspot)) g.temp.add(g.m.temperature_hotspot);
         if (ok(g.m.temperature_mem)) g.temp_mem.add(g.m.temperature_mem);
+        if (ok(g.m.temperature_edge)) g.temp_edge.add(g.m.temperature_edge);
         if (ok(g.m.current_gfxclk)) g.clk.add(g.m.current_gfxclk);
       }
     }
@@ -494,6 +570,18 @@ int main(int argc, char** argv) {
         if (slow % 10 == 0 || !g.have_ecc) {
           g.have_ecc = amdsmi_get_gpu_total_ecc_count(g.h, &g.ecc) == AMDSMI_STATUS_SUCCESS;
           read_xgmi_error(g);
+          if (processes) {
+            static amdsmi_proc_info_t list[64];
+            uint32_t n = 64;
+            const amdsmi_status_t rc = amdsmi_get_gpu_process_list(g.h, &n, list);
+            g.have_procs = rc == AMDSMI_STATUS_SUCCESS || rc == AMDSMI_STATUS_OUT_OF_RESOURCES;
+            g.procs.clear();
+            if (g.have_procs)
+              for (uint32_t k = 0; k < std::min<uint32_t>(n, 64); ++k) {
+                list[k].name[AMDSMI_MAX_STRING_LENGTH - 1] = 0;
+                g.procs.push_back({list[k].pid, list[k].name, list[k].memory_usage.vram_mem ? list[k].memory_usage.vram_mem : list[k].mem});
+              }
+          }
         }
       }
       ++slow;

@@ -284,6 +284,15 @@ class HbmHold:
         torch.cuda.synchronize(self.dev)
         return added
 
+    def drop(self, nbytes: int) -> int:
+        """Free at least `nbytes` again (whole blocks, newest first) and hand them back to the driver. Returns the bytes freed."""
+        freed = 0
+        while self.blocks and freed < nbytes:
+            freed += self.blocks.pop().numel()
+        self.torch.cuda.synchronize(self.dev)
+        self.torch.cuda.empty_cache()
+        return freed
+
     def fill_to_percent(self, percent: float, total_bytes: Optional[int] = None, used_bytes: Optional[int] = None) -> int:
         """Grow the hold until device-wide HBM use reaches `percent` of the total (as the driver
         reports it through ``mem_get_info``, which is what amdsmi's VRAM figure tracks)."""

@@ -212,6 +212,11 @@ class LlamaModel:
         self.fp8_decode = True
         return self
 
+    def prefill_gemm_backend(self) -> str:
+        """Which GEMMs carry the library path's projections (`_stack`: prefill, decode beyond 256 rows), for bench labels."""
+        return ("hipBLASLt (torch.matmul): NOT a hand-written-kernel figure; only attention, norms, rope and the KV write are "
+                "this repo's kernels in prefill")
+
     def weight_bytes(self) -> int:
         """bf16 bytes of the model (what a decode step streams without fp8 decode weights)."""
         n = self.embed.numel() + self.lm_head.numel()

@@ -82,6 +82,11 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         lib.klm_spin.argtypes = [u64, i, vp]
         lib.klm_spin.restype = i
         lib.klm_version.restype = ctypes.c_char_p
+        if hasattr(lib, "klm_src_hash"):
+            lib.klm_src_hash.restype = ctypes.c_char_p
+        if hasattr(lib, "klm_hbm_launch_plan"):
+            lib.klm_hbm_launch_plan.argtypes = [sz, i, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+            lib.klm_hbm_launch_plan.restype = i
         _lib = lib
         return lib
 
@@ -150,6 +155,36 @@ def padded_operand(rows: int, cols: int, dtype, device, pad_bytes: int = 256):
 
 def version() -> str:
     return load().klm_version().decode()
+
+
+def src_hash() -> str:
+    """The hash of the sources the LOADED library was built from ("unhashed": built by other means than build.py)."""
+    lib = load()
+    return lib.klm_src_hash().decode() if hasattr(lib, "klm_src_hash") else "unhashed"
+
+
+def tree_hash() -> str:
+    """The hash of the sources in the tree, as build.py computes it for libklm_ops.so."""
+    from .. import build as _build
+    return next(t for t in _build.targets() if t.name == "klm_ops").source_hash()
+
+
+def assert_current() -> None:
+    """Raise unless the loaded library was built from the sources in this tree: a stale `.so` (a snapshot copy or a checkout
+    rewrote the mtimes, the build was skipped) would otherwise pass tests of code that is not the code in the tree."""
+    have, want = src_hash(), tree_hash()
+    if have != want:
+        raise KlmOpsError(f"{_LIB_PATH} was built from other sources (library src:{have}, tree src:{want}): "
+                          "run `python -m k8s_llm_monitor_amd.build`")
+
+
+def hbm_launch_plan(nbytes: int, accesses_per_thread: int = 1):
+    """(launches, first grid, last grid) the default HBM kernels use for a buffer of `nbytes` (HIP's grid limit is 2^32 - 1
+    threads per launch: 64 GiB at one 16-byte access per thread; larger buffers are walked in several launches)."""
+    first, last = ctypes.c_uint(0), ctypes.c_uint(0)
+    n = load().klm_hbm_launch_plan(int(nbytes), int(accesses_per_thread), ctypes.byref(first), ctypes.byref(last))
+    _check(min(n, 0), "klm_hbm_launch_plan")
+    return n, first.value, last.value
 
 
 def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0) -> int:

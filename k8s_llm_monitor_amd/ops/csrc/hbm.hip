@@ -178,6 +178,33 @@ __global__ __launch_bounds__(kBlock) void hbm_read_tile_kernel(const u32x4* __re
 
 static inline size_t tiles_for(size_t n16, int u = kUnroll) { return (n16 + (size_t)kBlock * u - 1) / ((size_t)kBlock * u); }
 
+// HIP refuses a launch whose gridDim.x * blockDim.x passes 2^32 - 1, so a one-shot grid holds at most this many blocks:
+// 16 777 215 tiles of 4 KiB = just under 64 GiB per launch at one access per thread. The card has 288 GB, so the default
+// entry points walk a larger buffer in several launches over sub-ranges; the tuning (_ex) entry points refuse it.
+static const size_t kMaxTiles = 0xFFFFFFFFull / kBlock;
+
+// sub-ranges [off, off + n) in 16-byte elements, each at most kMaxTiles tiles of kBlock * u elements: fn(off, n, tiles)
+template <typename F>
+static inline void for_each_launch(size_t n16, int u, F fn) {
+  const size_t per = kMaxTiles * (size_t)kBlock * (size_t)u;
+  for (size_t off = 0; off < n16; off += per) {
+    const size_t n = n16 - off < per ? n16 - off : per;
+    fn(off, n, tiles_for(n, u));
+  }
+}
+
+// how a buffer of `bytes` is launched at `u` accesses per thread: number of launches; *first_tiles / *last_tiles = their grids
+extern "C" int klm_hbm_launch_plan(size_t bytes, int u, unsigned* first_tiles, unsigned* last_tiles) {
+  if (u < 1 || u > 4 || bytes == 0 || (bytes & 15)) return KLM_ERR_ARG;
+  int launches = 0;
+  for_each_launch(bytes >> 4, u, [&](size_t, size_t, size_t tiles) {
+    if (launches == 0 && first_tiles) *first_tiles = (unsigned)tiles;
+    if (last_tiles) *last_tiles = (unsigned)tiles;
+    ++launches;
+  });
+  return launches;
+}
+
 static inline int check(const void* a, const void* b, size_t bytes) {
   if (!a) return KLM_ERR_ARG;
   if (((uintptr_t)a | (uintptr_t)b) & 15) return KLM_ERR_ALIGN;
@@ -189,24 +216,22 @@ static inline int done() { return hipGetLastError() == hipSuccess ? KLM_OK : KLM
 
 extern "C" int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream) {
   if (int e = check(dst, nullptr, bytes)) return e;
-  const size_t n16 = bytes >> 4;
-  const size_t tiles = tiles_for(n16, 1);
-  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
   // one 16-byte store per thread: 6.9 TB/s (the chunked loop over 16384 blocks wrote 6.15)
-  hipLaunchKernelGGL((hbm_fill_tile_kernel<false, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
-                     (u32x4*)dst, n16, pattern);
+  for_each_launch(bytes >> 4, 1, [&](size_t off, size_t n, size_t tiles) {
+    hipLaunchKernelGGL((hbm_fill_tile_kernel<false, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
+                       (u32x4*)dst + off, n, pattern);
+  });
   return done();
 }
 
 extern "C" int klm_hbm_copy(void* dst, const void* src, size_t bytes, void* stream) {
   if (!src) return KLM_ERR_ARG;
   if (int e = check(dst, src, bytes)) return e;
-  const size_t n16 = bytes >> 4;
-  const size_t tiles = tiles_for(n16, 1);
-  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
   // one 16-byte load + store per thread, both nontemporal: 6.44 TB/s (16 KiB tiles: 5.65; the strided loop: 4.74)
-  hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
-                     (u32x4*)dst, (const u32x4*)src, n16);
+  for_each_launch(bytes >> 4, 1, [&](size_t off, size_t n, size_t tiles) {
+    hipLaunchKernelGGL((hbm_copy_tile_kernel<true, true, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
+                       (u32x4*)dst + off, (const u32x4*)src + off, n);
+  });
   return done();
 }
 
@@ -222,7 +247,7 @@ extern "C" int klm_hbm_copy_ex(void* dst, const void* src, size_t bytes, int fla
   if (flags & 24) {      // one-shot tiles: 8 -> 4 accesses per thread, 16 -> 1, 24 -> 2
     const int u = (flags & 24) == 8 ? 4 : (flags & 24) == 16 ? 1 : 2;
     const size_t tiles = tiles_for(n16, u);
-    if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+    if (tiles > kMaxTiles) return KLM_ERR_SHAPE;      // past HIP's grid limit: refused, explicitly (the default entry points split)
     const dim3 gt((unsigned)tiles);
 #define KLM_COPY_TILE(U)                                                                                  \
     switch (flags & 3) {                                                                                  \
@@ -258,7 +283,7 @@ extern "C" int klm_hbm_fill_ex(void* dst, size_t bytes, uint32_t pattern, int fl
   if (flags & 24) {      // one-shot tiles: 8 -> 4 stores per thread, 16 -> 1, 24 -> 2
     const int u = (flags & 24) == 8 ? 4 : (flags & 24) == 16 ? 1 : 2;
     const size_t tiles = tiles_for(n16, u);
-    if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+    if (tiles > kMaxTiles) return KLM_ERR_SHAPE;      // past HIP's grid limit: refused, explicitly (the default entry points split)
     const dim3 gt((unsigned)tiles);
     const bool nts = flags & 2;
     if (u == 4) { if (nts) hipLaunchKernelGGL((hbm_fill_tile_kernel<true, 4>), gt, b, 0, s, d, n16, pattern); else hipLaunchKernelGGL((hbm_fill_tile_kernel<false, 4>), gt, b, 0, s, d, n16, pattern); }
@@ -277,12 +302,11 @@ extern "C" int klm_hbm_fill_ex(void* dst, size_t bytes, uint32_t pattern, int fl
 extern "C" int klm_hbm_read(const void* src, size_t bytes, void* sink8, void* stream) {
   if (!sink8) return KLM_ERR_ARG;
   if (int e = check(src, nullptr, bytes)) return e;
-  const size_t n16 = bytes >> 4;
-  const size_t tiles = tiles_for(n16, 1);
-  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
   // one nontemporal 16-byte load per thread: 7.07 TB/s (the grid-stride loop: 6.09)
-  hipLaunchKernelGGL((hbm_read_tile_kernel<true, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
-                     (const u32x4*)src, n16, (uint32_t*)sink8);
+  for_each_launch(bytes >> 4, 1, [&](size_t off, size_t n, size_t tiles) {
+    hipLaunchKernelGGL((hbm_read_tile_kernel<true, 1>), dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const u32x4*)src + off, n, (uint32_t*)sink8);
+  });
   return done();
 }
 
@@ -302,7 +326,7 @@ extern "C" int klm_hbm_read_ex(const void* src, size_t bytes, void* sink8, int f
   }
   const int u = (flags & 24) == 8 ? 4 : (flags & 24) == 16 ? 1 : 2;
   const size_t tiles = tiles_for(n16, u);
-  if (tiles > 0x7FFFFFFFull) return KLM_ERR_SHAPE;
+  if (tiles > kMaxTiles) return KLM_ERR_SHAPE;      // past HIP's grid limit: refused, explicitly (the default entry points split)
   const dim3 gt((unsigned)tiles), b(kBlock);
   const bool ntl = flags & 1;
   if (u == 4) { if (ntl) hipLaunchKernelGGL((hbm_read_tile_kernel<true, 4>), gt, b, 0, s, r, n16, k); else hipLaunchKernelGGL((hbm_read_tile_kernel<false, 4>), gt, b, 0, s, r, n16, k); }
@@ -329,4 +353,11 @@ extern "C" int klm_spin(uint64_t cycles, int blocks, void* stream) {
   return done();
 }
 
-extern "C" const char* klm_version(void) { return "klm-ops 0.1 gfx950"; }
+// KLM_SRC_HASH: the build's hash over this target's sources and headers (k8s_llm_monitor_amd/build.py passes it; a build by
+// other means says so). build.py finds the marker in the binary to decide staleness; smoke() compares it with the tree.
+#ifndef KLM_SRC_HASH
+#define KLM_SRC_HASH "unhashed"
+#endif
+extern "C" __attribute__((used)) const char klm_src_hash_marker[] = "KLM_SRC_HASH=" KLM_SRC_HASH;
+extern "C" const char* klm_version(void) { return "klm-ops 0.2 gfx950 src:" KLM_SRC_HASH; }
+extern "C" const char* klm_src_hash(void) { return KLM_SRC_HASH; }

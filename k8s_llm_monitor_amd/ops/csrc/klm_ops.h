@@ -168,6 +168,8 @@ int klm_rope_cache_from_partials(const float* part, int ksplit, void* qkv, const
 int klm_mid_epilogue(const float* part, int ksplit, int M, int N, int kind, void* out, void* residual, float eps, void* stream);
 
 const char* klm_version(void);
+const char* klm_src_hash(void);   /* hash of the sources this library was built from (build.py), "unhashed" otherwise */
+int klm_hbm_launch_plan(size_t bytes, int u, unsigned* first_tiles, unsigned* last_tiles);   /* launches a buffer of `bytes` takes */
 
 #ifdef __cplusplus
 }

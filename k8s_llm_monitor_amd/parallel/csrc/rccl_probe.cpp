@@ -37,6 +37,12 @@
 #include <string>
 #include <vector>
 
+// the hash of the sources this binary was built from (build.py passes KLM_SRC_HASH and finds the marker to decide staleness)
+#ifndef KLM_SRC_HASH
+#define KLM_SRC_HASH "unhashed"
+#endif
+extern "C" __attribute__((used)) const char klm_src_hash_marker[] = "KLM_SRC_HASH=" KLM_SRC_HASH;
+
 #define HIPCHECK(x)                                                                        \
   do {                                                                                     \
     hipError_t e_ = (x);                                                                   \

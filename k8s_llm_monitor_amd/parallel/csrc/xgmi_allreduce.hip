@@ -40,6 +40,12 @@
 #include <stdint.h>
 #include <string.h>
 
+// the hash of the sources this binary was built from (build.py passes KLM_SRC_HASH and finds the marker to decide staleness)
+#ifndef KLM_SRC_HASH
+#define KLM_SRC_HASH "unhashed"
+#endif
+extern "C" __attribute__((used)) const char klm_src_hash_marker[] = "KLM_SRC_HASH=" KLM_SRC_HASH;
+
 extern "C" {
 int klm_xgmi_alloc(size_t bytes, void** ptr, void* handle64, int* fine_grained);
 int klm_xgmi_open(const void* handle64, void** ptr);

@@ -7,7 +7,7 @@ overhead, alert latency and the RCCL bus bandwidth at N GPUs.
 from __future__ import annotations
 
 import time
-from typing import Any, Dict
+from typing import Any, Dict, List, Optional
 
 
 def _sync_all(torch, dist, distributed):
@@ -23,13 +23,50 @@ def _sync_all(torch, dist, distributed):
 from ..models.linear_step import LinearLayerStep as _Load   # noqa: E402  (kept under its old name for callers)
 
 
-def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int, distributed=None) -> float:
-    """Seconds for exactly `steps` steps: barrier + synchronize on both sides, MAX over ranks."""
+def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int, distributed=None, min_warm_s: float = 0.0,
+                info: Optional[Dict[str, Any]] = None) -> float:
+    """Seconds for exactly `steps` steps: barrier + synchronize on both sides, MAX over ranks.
+
+    Warm-up is `warmup` steps AND at least `min_warm_s` seconds of steps: five 2 ms steps leave the card on its start-up
+    clocks (the cap's control loop has not settled: 1 552 TFLOP/s timed after 10 ms of warm-up, 1 611 sustained), so the
+    number would depend on --steps / --warmup. The extra step count is derived from the first `warmup` steps' own time
+    and agreed across ranks (MAX), because under data parallelism every step is also a collective all ranks must enter."""
     dd = (world > 1) if distributed is None else bool(distributed)   # a one-rank group still takes the collective path
+    t_w = time.perf_counter()
     for _ in range(warmup):
         load.step()
     load.drain()
     _sync_all(torch, dist, dd)
+    extra = 0
+    if min_warm_s > 0:
+        spent = time.perf_counter() - t_w
+        per = spent / warmup if warmup > 0 else 0.0
+        if per <= 0:                                            # --warmup 0: time one step to size the rest
+            t1 = time.perf_counter()
+            load.step()
+            load.drain()
+            _sync_all(torch, dist, dd)
+            per = time.perf_counter() - t1
+            spent += per
+            extra += 1
+        more = int(max(0.0, min_warm_s - spent) / max(per, 1e-6)) + 1 if spent < min_warm_s else 0
+        more = min(more, 1_000_000)
+        if dd:
+            t = torch.tensor([more], device=load.x.device, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            more = int(t.item())
+        for i in range(more):
+            load.step()
+            if i % 64 == 63:
+                load.drain()
+                if torch.cuda.is_available():
+                    torch.cuda.current_stream().synchronize()   # keep the launch queue bounded
+        load.drain()
+        _sync_all(torch, dist, dd)
+        extra += more
+    if info is not None:
+        info["warmup_steps_run"] = warmup + extra
+        info["warmup_seconds"] = round(time.perf_counter() - t_w, 3)
     t0 = time.perf_counter()
     for _ in range(steps):
         load.step()
@@ -165,19 +202,59 @@ def hbm_vendor_comparison(torch, ops, dev, gib: int = 2, rounds: int = 3, iters:
             "copy_klm_over_torch": round(med["copy_klm"] / med["copy_torch"], 3)}
 
 
+#: what the sections around the timed region cost (seconds, one MI355X), for the time budget
+SECTION_COST_S = {"dp_kernel": 4.0, "probe": 10.0, "xgmi": 15.0, "other_kernels": 25.0, "llm_serving": 30.0}
+
+
+def _rehearsal_validation(spec: str, budget) -> Dict[str, Any]:
+    """--cpu-rehearsal only: stand-ins for the validation phases, "name:priced_s:actual_s,...". They sleep instead of
+    measuring, so that the budget / shedding / rank-waiting logic of a multi-rank launch can be run without a GPU."""
+    from . import phases
+    items = [x.split(":") for x in spec.split(",") if x]
+    cost = {n: float(c) for n, c, _ in items}
+    plan, shed = phases.plan_phases(set(cost), budget.left() if budget is not None else None, cost)
+    ran = []
+    for n, c, actual in items:
+        if n not in plan:
+            continue
+        if budget is not None and not budget.allows(n, float(c)):
+            continue
+        time.sleep(float(actual))
+        ran.append(n)
+    shed = shed + [x["phase"] for x in (budget.shed if budget is not None else [])]
+    return {"summary": {"pass": {n: True for n in ran}, "shed": shed, "rehearsal": True}, "ran": ran, "shed": shed}
+
+
 def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     import torch
     import torch.distributed as dist
+    from . import phases as _ph
 
     t_run0 = time.perf_counter()
+    budget = getattr(a, "budget", None)
     wall: Dict[str, float] = {}
     size = a.size
     gemm = None
-    if dev.type != "cuda":                      # --cpu-rehearsal
+    gpu = dev.type == "cuda"
+    if not gpu:                                 # --cpu-rehearsal
         gemm = lambda x, w, out: out.copy_(x.float() @ w.float().t())
     dd = world > 1 or bool(getattr(a, "force_dist", False))       # a process group exists (one rank with --force-dist)
     load = _Load(torch, dist, ops, dev, world, size, gemm=gemm, distributed=dd)
     extras: Dict[str, Any] = {}
+    shed: List[str] = []
+
+    def allowed(section: str) -> bool:
+        """Sections outside the timed region are skipped, never cut short, when the time budget cannot pay for them. Every
+        rank holds the same budget clock to within the launch skew; sections with collectives ask rank 0 (see below)."""
+        ok = budget is None or budget.allows(section, SECTION_COST_S[section])
+        if dd and section in ("probe", "xgmi"):
+            # a collective section: all ranks must take the same decision, rank 0's
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.broadcast(t, src=0)
+            ok = bool(int(t.item()))
+        if not ok:
+            shed.append(section)
+        return ok
 
     sampler = None
     period = a.sample_period if a.sample_period > 0 else 5.0
@@ -186,9 +263,13 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     extras["sampler"] = (sampler.describe() if sampler is not None else "off")
 
     extras["flop_per_step"] = load.flops
+    extras["gemm_variant"] = load.gemm_variant
     wall["setup"] = round(time.perf_counter() - t_run0, 2)
     t_sec = time.perf_counter()
-    dt = timed_steps(torch, dist, load, world, a.steps, a.warmup, distributed=dd)
+    winfo: Dict[str, Any] = {}
+    min_warm = float(getattr(a, "min_warmup_seconds", 2.0)) if gpu else 0.0
+    dt = timed_steps(torch, dist, load, world, a.steps, a.warmup, distributed=dd, min_warm_s=min_warm, info=winfo)
+    extras.update(winfo)
     wall["warmup_and_timed_steps"] = round(time.perf_counter() - t_sec, 3)
     wall["timed_steps_only"] = round(dt, 4)
     ms = dt / a.steps * 1e3
@@ -200,13 +281,27 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         extras["allreduce_busbw_GBps_overlapped"] = round(algbw * 2 * (world - 1) / world, 2)
         extras["distributed_backend"] = dist.get_backend()
 
+    # the same step on the kernel the N > 1 ranks run (one workgroup per tile, variant 4), still on one GPU: the point a
+    # scaling curve's efficiency should be taken against, so that it does not include a kernel change
+    if gpu and not dd and load.gemm_variant not in (None, 4) and size % 256 == 0 and allowed("dp_kernel"):
+        t_sec = time.perf_counter()
+        dp = _Load(torch, dist, ops, dev, world, size, distributed=False, dp_kernel=True)
+        dt_dp = timed_steps(torch, dist, dp, world, a.steps, a.warmup, distributed=False, min_warm_s=min(1.0, min_warm))
+        extras["value_dp_kernel"] = round(dp.flops * world / (dt_dp / a.steps) / 1e12, 2)
+        extras["gemm_variant_dp_kernel"] = dp.gemm_variant
+        del dp
+        wall["dp_kernel_step"] = round(time.perf_counter() - t_sec, 2)
+    elif dd and gpu:
+        extras["value_dp_kernel"] = round(tflops / world, 2) if world == 1 else None
+        extras["gemm_variant_dp_kernel"] = load.gemm_variant
+
     if sampler is not None:
         extras["sampler_stats"] = sampler.stats()
 
     t_sec = time.perf_counter()
-    if not getattr(a, "no_probe", False):
+    if not getattr(a, "no_probe", False) and allowed("probe"):
         # the RCCL all-reduce curve at EVERY n in {1, 2, 4, 8} <= world from this one launch (outside the
-        # timed region): the first n ranks form their own communicator and sweep it in place
+        # timed region): the first n ranks form their own communicator and sweep it (n = 1: the local copy rate)
         try:
             from ..parallel import dist_probe, probe
             sizes = probe.sweep_sizes(1024, getattr(a, "probe_max_bytes", 1 << 28), 4)
@@ -215,7 +310,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
                                                     ctrl=getattr(a, "ctrl_group", None))
                 extras["rccl_ranks_seen"] = {"process_group_world_size": dist.get_world_size(),
                                              "communicators": [c.get("ranks_seen") for c in curves]}
-            elif dev.type == "cuda":
+            elif gpu:
                 # one rank and no process group: the native probe (a child process) gives the n = 1 point
                 curves = [probe.run_native(1, "bf16", max_bytes=sizes[-1], warmup=3, iters=10, timeout=120.0)]
                 extras["rccl_ranks_seen"] = {"process_group_world_size": 1,
@@ -234,20 +329,19 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             extras["rccl_curves"] = {"error": f"{type(e).__name__}: {e}"}
 
     which = getattr(a, "validation_phases", "all") or "all"
-    if dd and not a.no_validation and (which == "all" or "xgmi" in which.split(",")):
+    xf = None
+    if dd and not a.no_validation and (which == "all" or "xgmi" in which.split(",")) and allowed("xgmi"):
         # xGMI counter fidelity: only measurable with peers (every rank takes part in the collectives)
         try:
-            from . import phases as _ph
             xf = _ph.xgmi_fidelity(torch, dist, dev, rank, world)
-            if rank == 0:
-                extras["xgmi_fidelity"] = xf
         except Exception as e:
-            if rank == 0:
-                extras["xgmi_fidelity"] = {"error": f"{type(e).__name__}: {e}"}
+            xf = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            extras["xgmi_fidelity"] = xf
 
     wall["rccl_probe_and_xgmi_check"] = round(time.perf_counter() - t_sec, 2)
     t_sec = time.perf_counter()
-    if not a.no_validation and rank == 0 and dev.type == "cuda" and which == "all":
+    if not a.no_validation and rank == 0 and gpu and which == "all" and allowed("other_kernels"):
         # the other validation-load kernels, 1 s each (outside the timed region)
         try:
             from ..loadgen.burner import Burner
@@ -262,65 +356,34 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             extras["vendor_comparison"] = vendor_comparison(torch, ops, dev, size)
         except Exception as e:
             extras["other_kernels"] = {"error": f"{type(e).__name__}: {e}"}
-        # the serving load generator (Llama-3-8B architecture, random weights): decode and prefill rates
-        try:
-            from ..serving import Engine, EngineConfig
-            from ..serving import bench as sb
-            eng = Engine(EngineConfig(model="llama3-8b", device=str(dev), max_num_seqs=256, max_model_len=4096,
-                                      kv_blocks=20000))
-            eng.warmup([1, 16, 64, 192, 256])
-            dec = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64, 192, 256)]   # skinny / skinny / mid / tiled GEMM paths
-            pre = sb.prefill_ms(eng, 4, 1024, iters=2)
-            extras["llm_serving"] = {
-                "model": "llama3-8b (random weights, bf16)", "ctx": 1024,
-                "decode": [{"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3),
-                            "tokens_per_s": round(r["tokens_per_s"], 1), "TBps": round(r["TBps"], 2)} for r in dec],
-                "prefill": {"n_seqs": 4, "prompt_len": 1024, "tokens_per_s": round(pre["tokens_per_s"], 1),
-                            "TFLOPs": round(pre["TFLOPs"], 1),
-                            "gemm_backend": "hipBLASLt (torch.matmul): NOT a hand-written-kernel figure; only attention, "
-                                            "norms, rope and the KV write are this repo's kernels in prefill"},
-                "decode_gemm_backend": "hand-written skinny / mid-batch / K-split tiled kernels up to 256 rows "
-                                       "(gate_up, and wo above 208 rows, on hipBLASLt from 129 rows)"}
-            # the same decode with W8A16 weight copies (labelled: not the bf16 figure above)
-            eng.model.enable_fp8_decode()
-            eng._graphs.clear()
-            eng.warmup([1, 16, 64])
-            d8 = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64)]
-            extras["llm_serving"]["decode_fp8_weights"] = [
-                {"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3), "tokens_per_s": round(r["tokens_per_s"], 1),
-                 "TBps": round(r["TBps"], 2)} for r in d8]
-            del eng
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            # and with an e4m3 KV cache on top (large batches, where attention bytes dominate)
-            eng = Engine(EngineConfig(model="llama3-8b", device=str(dev), max_num_seqs=256, max_model_len=4096,
-                                      kv_blocks=20000, kv_cache_dtype="fp8"))
-            eng.warmup([64, 256])
-            dk = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (64, 256)]
-            extras["llm_serving"]["decode_fp8_kv_cache"] = [
-                {"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3), "tokens_per_s": round(r["tokens_per_s"], 1),
-                 "TBps": round(r["TBps"], 2)} for r in dk]
-            del eng, dec, pre, d8, dk
-            gc.collect()
-            torch.cuda.empty_cache()
-        except Exception as e:
-            extras["llm_serving"] = {"error": f"{type(e).__name__}: {e}"}
+    if not a.no_validation and rank == 0 and gpu and which == "all" and allowed("llm_serving"):
+        extras["llm_serving"] = llm_serving_rates(torch, dev)
 
     wall["other_kernels_and_llm_serving"] = round(time.perf_counter() - t_sec, 2)
     t_sec = time.perf_counter()
     local_phases = ",".join(p for p in which.split(",") if p != "xgmi")
-    if not a.no_validation and local_phases:
+    v: Dict[str, Any] = {}
+    spec = getattr(a, "rehearsal_phases", "")
+    if spec and not gpu and rank == 0:
+        v = _rehearsal_validation(spec, budget)
+    elif not a.no_validation and local_phases:
         try:
-            from . import phases
             t0 = time.time()
-            v = phases.run_all(torch, dist, ops, dev, rank, world, load, sampler, a, quick=True, which=local_phases)
+            v = _ph.run_all(torch, dist, ops, dev, rank, world, load, sampler, a, quick=True, which=local_phases, budget=budget)
             if v:
-                extras["validation"] = v.get("summary")
-                extras["validation_detail"] = {k: x for k, x in v.items() if k != "summary"}
                 extras["validation_seconds"] = round(time.time() - t0, 1)
         except Exception as e:  # the validation phases never invalidate the timed number
             extras["validation_error"] = f"{type(e).__name__}: {e}"
+    if rank == 0 and (v or xf):
+        if xf:
+            # the unit verdict of the xGMI counters (KiB or KB per count) belongs to the report /api/validation serves: the
+            # first run with peers pins it there
+            v = dict(v)
+            v["xgmi_fidelity"] = xf
+            v["summary"] = _ph.summarize(v) if "rehearsal" not in (v.get("summary") or {}) else v["summary"]
+        extras["validation"] = v.get("summary")
+        extras["validation_detail"] = {k: x for k, x in v.items() if k != "summary"}
+        shed += [p for p in (v.get("shed") or [])]
 
     if sampler is not None:
         sampler.stop()
@@ -328,6 +391,8 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     wall["total"] = round(time.perf_counter() - t_run0, 2)
     # only `timed_steps_only` enters `value`; everything else is reported, untimed work around it
     extras["wall_seconds"] = wall
+    extras["time_budget_s"] = None if budget is None else budget.seconds
+    extras["shed"] = shed
 
     return {
         "metric": "monitored validation-load throughput: bf16 MFMA burner training step (fwd+dgrad+wgrad GEMMs, DP all-reduce over RCCL) under telemetry sampling",
@@ -350,3 +415,156 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         },
         **extras,
     }
+
+
+def llm_serving_rates(torch, dev) -> Dict[str, Any]:
+    """The serving load generator (Llama-3-8B architecture, random weights): decode and prefill rates."""
+    import gc
+    try:
+        from ..serving import Engine, EngineConfig
+        from ..serving import bench as sb
+        eng = Engine(EngineConfig(model="llama3-8b", device=str(dev), max_num_seqs=256, max_model_len=4096,
+                                  kv_blocks=20000))
+        eng.warmup([1, 16, 64, 192, 256])
+        dec = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64, 192, 256)]   # skinny / skinny / mid / tiled GEMM paths
+        pre = sb.prefill_ms(eng, 4, 1024, iters=2)
+        out: Dict[str, Any] = {
+            "model": "llama3-8b (random weights, bf16)", "ctx": 1024,
+            "decode": [{"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3),
+                        "tokens_per_s": round(r["tokens_per_s"], 1), "TBps": round(r["TBps"], 2)} for r in dec],
+            "prefill": {"n_seqs": 4, "prompt_len": 1024, "tokens_per_s": round(pre["tokens_per_s"], 1),
+                        "TFLOPs": round(pre["TFLOPs"], 1), "gemm_backend": eng.model.prefill_gemm_backend()},
+            "decode_gemm_backend": "hand-written skinny / mid-batch / K-split tiled kernels up to 256 rows "
+                                   "(gate_up, and wo above 208 rows, on hipBLASLt from 129 rows)"}
+        # the same decode with W8A16 weight copies (labelled: not the bf16 figure above)
+        eng.model.enable_fp8_decode()
+        eng._graphs.clear()
+        eng.warmup([1, 16, 64])
+        d8 = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (1, 16, 64)]
+        out["decode_fp8_weights"] = [
+            {"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3), "tokens_per_s": round(r["tokens_per_s"], 1),
+             "TBps": round(r["TBps"], 2)} for r in d8]
+        del eng
+        gc.collect()
+        torch.cuda.empty_cache()
+        # and with an e4m3 KV cache on top (large batches, where attention bytes dominate)
+        eng = Engine(EngineConfig(model="llama3-8b", device=str(dev), max_num_seqs=256, max_model_len=4096,
+                                  kv_blocks=20000, kv_cache_dtype="fp8"))
+        eng.warmup([64, 256])
+        dk = [sb.decode_step_ms(eng, b, 1024, iters=10) for b in (64, 256)]
+        out["decode_fp8_kv_cache"] = [
+            {"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3), "tokens_per_s": round(r["tokens_per_s"], 1),
+             "TBps": round(r["TBps"], 2)} for r in dk]
+        del eng, dec, pre, d8, dk
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:
+        gc.collect()
+        torch.cuda.empty_cache()
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+# ---- the output contract: ONE compact JSON line on stdout, everything else in a file --------------------------------
+#: keys of the full result that go into the compact line as they are
+_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "flop_per_step", "gemm_variant", "value_dp_kernel", "gemm_variant_dp_kernel",
+              "warmup_steps_run", "warmup_seconds", "allreduce_bytes_per_step", "allreduce_busbw_GBps_overlapped",
+              "distributed_backend", "rccl_ranks_seen", "launcher", "time_budget_s", "shed", "validation_error")
+#: BASELINE.json's metric ("telemetry error vs amdsmi/rocprof (%), sampling overhead, alert latency"): flat scalars of the summary
+_SUMMARY_KEYS = ("hbm_error_pct", "gfx_activity_error_points", "power_error_pct", "sampling_overhead_pct", "sampling_overhead_ci95_pct",
+                 "sampling_overhead_high_pct", "alert_latency_max_s", "alert_latency_crossings", "sse_latency_max_s", "poll_latency_max_s",
+                 "power_alert", "throttle_alert", "vllm_tokens_per_s_error_pct", "vllm_kv_cache_error_points",
+                 "xgmi_unit_verdict_tx", "xgmi_tx_error_pct")
+LINE_LIMIT = 4096
+
+
+def detail_path(a=None) -> str:
+    """Where the full result goes: --detail-out, else $KLM_BENCH_DETAIL, else bench_detail.json next to bench.py (the
+    repository root; the state directory when that is not writable)."""
+    import os
+    p = getattr(a, "detail_out", "") or os.environ.get("KLM_BENCH_DETAIL", "")
+    if p:
+        return p
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if os.access(root, os.W_OK):
+        return os.path.join(root, "bench_detail.json")
+    from ..server.http import validation_report_path
+    return os.path.join(os.path.dirname(validation_report_path()), "bench_detail.json")
+
+
+def _round_floats(x, nd: int = 4):
+    if isinstance(x, float):
+        return round(x, nd)
+    if isinstance(x, dict):
+        return {k: _round_floats(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round_floats(v, nd) for v in x]
+    return x
+
+
+def compact(result: Dict[str, Any], detail: str = "") -> Dict[str, Any]:
+    """The line bench.py prints: the contract's keys, BASELINE.json's metric as flat scalars, which kernel ran, how many
+    ranks RCCL saw and the peak bus bandwidth per n -- nothing that grows with the run (the driver keeps 8 000 characters
+    of stdout; round 2's 20.8 KB line was recorded as `parsed: null`)."""
+    line = {k: result[k] for k in _LINE_KEYS if k in result}
+    summ = result.get("validation") or {}
+    for k in _SUMMARY_KEYS:
+        if summ.get(k) is not None:
+            line[k] = summ[k]
+    if summ.get("pass") is not None:
+        line["validation_pass"] = bool(summ["pass"]) and all(summ["pass"].values())
+        line["validation_failed"] = sorted(k for k, ok in summ["pass"].items() if not ok)
+        line["validation_checks"] = len(summ["pass"])
+    for name in ("rccl_curves", "rccl_curves_native"):
+        cs = result.get(name)
+        if isinstance(cs, dict) and "error" not in cs:
+            # n = 1 carries the local copy rate (no link traffic); an unverified point is null, never a number
+            line["peak_busbw_GBps" + ("_native" if name.endswith("native") else "")] = {
+                n: ((c.get("peak_busbw_GBps") if int(n) > 1 else c.get("peak_algbw_GBps")) if c.get("verified") else None)
+                for n, c in sorted(cs.items(), key=lambda kv: int(kv[0]))}
+        elif isinstance(cs, dict):
+            line[name + "_error"] = str(cs["error"])[:200]
+    vc = result.get("vendor_comparison") or {}
+    for k in ("bf16_klm_over_hipblaslt", "fp8_klm_over_scaled_mm"):
+        if k in vc:
+            line[k] = vc[k]
+    if "wall_seconds" in result:
+        line["wall_total_s"] = result["wall_seconds"].get("total")
+    if detail:
+        line["detail"] = detail
+    line = _round_floats(line)
+    # the line must stay a line the driver can keep whole: drop the optional parts, longest first, if it ever grows past the limit
+    import json
+    optional = [k for k in line if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                             "scaling", "vs_baseline", "dtype", "data", "config", "detail")]
+    while len(json.dumps(line)) >= LINE_LIMIT and optional:
+        worst = max(optional, key=lambda k: len(json.dumps(line[k])))
+        optional.remove(worst)
+        line.pop(worst)
+        line["truncated"] = True
+    return line
+
+
+def write_detail(result: Dict[str, Any], path: str) -> str:
+    """The full result (curves, per-phase rows, llm_serving, vendor_comparison) as a JSON file, and the validation report
+    where /api/validation reads it."""
+    import json
+    import os
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    tmp = f"{path}.tmp.{os.getpid()}"
+    with open(tmp, "w", encoding="utf-8") as f:
+        json.dump(result, f, indent=1)
+    os.replace(tmp, path)
+    if result.get("validation") and not (result["validation"] or {}).get("rehearsal"):
+        try:
+            from ..server.http import validation_report_path
+            rp = validation_report_path()
+            os.makedirs(os.path.dirname(rp) or ".", exist_ok=True)
+            doc = dict(result.get("validation_detail") or {}, summary=result["validation"], timestamp=time.time(), source="bench.py")
+            with open(rp + ".tmp", "w", encoding="utf-8") as f:
+                json.dump(doc, f, indent=1)
+            os.replace(rp + ".tmp", rp)
+        except OSError:
+            pass
+    return path

@@ -14,9 +14,17 @@ Each phase puts a KNOWN load on the GPU and compares what the monitor reports wi
   overhead           burner throughput alone, next to the whole product (Monitor + HTTP server + one
                      SSE stream + polling clients), and next to a 20 Hz bare poller; interleaved repeats,
                      overhead = mean paired difference with its 95 % confidence interval.
-  alert_latency      the full stack (amdsmi -> sampler thread -> alert engine -> HTTP): HBM is
-                     pushed across 70 / 85 / 95 % of the card and /api/alerts is polled like
-                     the page does; latency = crossing -> alert visible.
+  throttle_alerts    BASELINE.json config 5 without root: the burner at 100 % duty sits on the 1400 W cap, so the
+                     power-cap residency (`ppt`) goes to ~100 % and the clock drops below its idle value; the
+                     `gpu/N/power` (serious) and `gpu/N/throttle_ppt` (minor) alerts must appear in /api/alerts and
+                     over /api/events, and clear within two periods of the stop.
+  alert_latency      the full stack (amdsmi -> sampler thread -> alert engine -> HTTP): HBM is pushed across
+                     70 % of the card >= 8 times in small steps, at crossing phases spread over the sampler's
+                     period, then across 85 / 95 %; latency = crossing -> alert visible, per delivery path
+                     (/api/alerts as the server has it, the page's poll, the /api/events push): min / mean / max
+                     next to the analytical bound period + tick + poll.
+
+``plan_phases`` / ``Budget``: bench.py's --time-budget sheds whole phases, longest first, instead of overrunning.
 
 Targets: error <= 2 %, overhead < 1 %, latency < 10 s.
 """
@@ -61,6 +69,157 @@ def _smi_index_for(torch, dev, src) -> int:
             except (IndexError, ValueError):
                 continue
     return int(gpus[0].get("index", 0)) if gpus else 0
+
+
+
+# ------------------------------------------------------------------------------------------
+#: canonical order of the phases and what each costs on one MI355X (seconds, quick mode; measured in the round-2 and
+#: round-3 driver runs and rounded up). `plan_phases` prices a run with these before it starts.
+PHASE_ORDER = ("hbm", "activity", "power", "throttle", "mem", "overhead", "latency", "llm", "vllm")
+PHASE_COST_S = {"hbm": 10.0, "activity": 25.0, "power": 22.0, "throttle": 30.0, "mem": 13.0, "overhead": 85.0,
+                "latency": 120.0, "llm": 10.0, "vllm": 20.0}
+
+
+def plan_phases(want, budget_s: Optional[float], cost: Optional[Dict[str, float]] = None):
+    """(phases to run, in canonical order; phases shed). While the priced total exceeds `budget_s` the LONGEST remaining
+    phase is dropped (ties: the later one), so a short budget keeps as many checks as fit rather than the first few."""
+    cost = PHASE_COST_S if cost is None else cost
+    order = [p for p in PHASE_ORDER if p in want] + sorted(p for p in want if p not in PHASE_ORDER)
+    keep, shed = list(order), []
+    if budget_s is None:
+        return keep, shed
+    while keep and sum(cost.get(p, 30.0) for p in keep) > budget_s:
+        worst = max(keep, key=lambda p: (cost.get(p, 30.0), order.index(p)))
+        keep.remove(worst)
+        shed.append(worst)
+    return keep, shed
+
+
+class Budget:
+    """Wall-clock budget of a bench run: `left()` seconds remain before `deadline`; None = unlimited."""
+
+    def __init__(self, seconds: Optional[float], t0: Optional[float] = None, reserve_s: float = 10.0):
+        self.t0 = time.monotonic() if t0 is None else t0
+        self.seconds, self.reserve_s = seconds, reserve_s
+        self.shed: List[Dict[str, Any]] = []
+
+    def left(self) -> Optional[float]:
+        return None if self.seconds is None else self.seconds - self.reserve_s - (time.monotonic() - self.t0)
+
+    def allows(self, name: str, cost_s: float) -> bool:
+        left = self.left()
+        if left is None or cost_s <= left:
+            return True
+        self.shed.append({"phase": name, "cost_s": cost_s, "left_s": round(left, 1)})
+        return False
+
+
+class SseListener:
+    """One /api/events stream held open, as the page's EventSource holds it: every `alerts` event with its arrival time."""
+
+    def __init__(self, url: str):
+        import threading
+        self.url = url
+        self.events: List[Any] = []          # (t_perf, {tier: [keys]})
+        self.errors = 0
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, name="klm-val-sse", daemon=True)
+
+    def _run(self) -> None:
+        try:
+            with urllib.request.urlopen(self.url + "/api/events", timeout=30) as r:
+                kind = None
+                while not self._stop.is_set():
+                    line = r.readline()
+                    if not line:
+                        break
+                    if line.startswith(b"event:"):
+                        kind = line[6:].strip()
+                    elif line.startswith(b"data:") and kind == b"alerts":
+                        t = time.perf_counter()
+                        try:
+                            doc = json.loads(line[5:])
+                            self.events.append((t, {tier: [a.get("key") for a in doc.get(tier, [])] for tier in ("minor", "serious", "critical")}))
+                        except ValueError:
+                            self.errors += 1
+        except Exception:
+            if not self._stop.is_set():
+                self.errors += 1
+
+    def start(self) -> "SseListener":
+        self._th.start()
+        return self
+
+    def stop(self) -> None:
+        self._stop.set()
+
+    def first(self, key: str, tier: Optional[str], after: float, present: bool = True) -> Optional[float]:
+        """Arrival time of the first event after `after` in which `key` is (or, with present=False, is no longer) listed
+        under `tier` (any tier when None)."""
+        for t, doc in list(self.events):
+            if t < after:
+                continue
+            tiers = (tier,) if tier else ("minor", "serious", "critical")
+            if any(key in doc[x] for x in tiers) == present:
+                return t
+        return None
+
+
+class PagePoller:
+    """The page's fallback path: GET /api/alerts every `period_s` on a fixed timer (monitor.html's setInterval)."""
+
+    def __init__(self, url: str, period_s: float, offset_s: float = 0.0):
+        import threading
+        self.url, self.period_s, self.offset_s = url, period_s, offset_s
+        self.polls: List[Any] = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, name="klm-val-poll", daemon=True)
+
+    def _run(self) -> None:
+        nxt = time.monotonic() + self.offset_s
+        while not self._stop.wait(max(0.0, nxt - time.monotonic())):
+            nxt += self.period_s
+            try:
+                doc = json.loads(urllib.request.urlopen(self.url + "/api/alerts", timeout=3).read())
+                self.polls.append((time.perf_counter(), {tier: [a.get("key") for a in doc.get(tier, [])] for tier in ("minor", "serious", "critical")}))
+            except Exception:
+                pass
+
+    def start(self) -> "PagePoller":
+        self._th.start()
+        return self
+
+    def stop(self) -> None:
+        self._stop.set()
+
+    first = SseListener.first
+    events = property(lambda self: self.polls)
+
+
+def stratified_phases(n: int, seed: int) -> List[float]:
+    """n numbers in [0, 1): one from each of n equal strata, in a seeded random order (crossing phases that cover the
+    sampler period evenly whatever n is, instead of n draws that may all land together)."""
+    import random
+    rng = random.Random(seed)
+    xs = [(i + rng.random()) / n for i in range(n)]
+    rng.shuffle(xs)
+    return xs
+
+
+def _alerts_have(url: str, key: str, tier: Optional[str]) -> bool:
+    a = json.loads(urllib.request.urlopen(url + "/api/alerts", timeout=3).read())
+    tiers = (tier,) if tier else ("minor", "serious", "critical")
+    return any(x.get("key") == key for t in tiers for x in a[t])
+
+
+def _wait_until(cond, timeout_s: float, step_s: float = 0.05) -> Optional[float]:
+    """perf_counter time at which `cond()` first held, None after `timeout_s`."""
+    t_end = time.perf_counter() + timeout_s
+    while time.perf_counter() < t_end:
+        if cond():
+            return time.perf_counter()
+        time.sleep(step_s)
+    return None
 
 
 # ------------------------------------------------------------------------------------------
@@ -408,49 +567,248 @@ def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s
     return res
 
 
-def alert_latency(torch, dev, realtime_period: float = 5.0, poll_s: float = 0.25, tiers=(("minor", 71.0), ("serious", 86.0), ("critical", 96.0)),
-                  timeout_s: float = 20.0) -> Dict[str, Any]:
+def alert_latency(torch, dev, realtime_period: float = 5.0, crossings: int = 8, step_gib: float = 2.0, seed: int = 20261111,
+                  upper_tiers=(("serious", 85.0), ("critical", 95.0)), timeout_s: float = 20.0, fast_poll_s: float = 0.05,
+                  monitor=None, hold=None) -> Dict[str, Any]:
+    """Threshold crossing -> alert visible, as a distribution and per delivery path (BASELINE.json: "< 10 s").
+
+    HBM is first held `step_gib`/2 below 70 % of the card. Each of `crossings` rounds then adds `step_gib` (crossing the
+    minor threshold) at a phase of the sampler's period drawn from `stratified_phases` -- the crossing time is spread
+    evenly over the 5 s grid instead of always landing right after a tick -- waits for the alert on all three paths,
+    and drops the step again. After that one crossing each of 85 % and 95 % checks the upper tiers (a tier CHANGE of the
+    same alert key). Paths, all timed from the moment the memory is allocated and touched:
+
+      server   /api/alerts has it (polled every `fast_poll_s`): the sampler's and the alert engine's share;
+      sse      the /api/events push reaches an open stream (what the page's EventSource shows);
+      poll     the page's fallback timer, `periods.page_alert_poll` (4 s), sees it.
+
+    `bound_*`: the analytical worst case, period + slowest tick (+ poll period); every measured maximum must sit below it.
+    `monitor` / `hold`: an unstarted Monitor and a hold object to use instead of amdsmi and real HBM (CPU tests drive the
+    same loop against the fake GPU source)."""
     from ..config import load_config
-    from ..loadgen.burner import HbmHold
     from ..server.http import MonitorServer
     from ..server.sampler import Monitor
-    cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"},
-                                         "sources": {"gpu": "amdsmi", "kube": "none", "vllm": "none", "history": "local"},
-                                         "periods": {"realtime": realtime_period}})
-    mon = Monitor(cfg).start()
+    if monitor is None:
+        cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"},
+                                             "sources": {"gpu": "amdsmi", "kube": "none", "vllm": "none", "history": "local"},
+                                             "periods": {"realtime": realtime_period}})
+        monitor = Monitor(cfg)
+    cfg = monitor.cfg
+    realtime_period = float(cfg.periods.realtime)
+    if hold is None:
+        from ..loadgen.burner import HbmHold
+        hold = HbmHold(dev.index or 0)
+    page_poll_s = float(cfg.periods.page_alert_poll)
+    mon = monitor.start()
     srv = MonitorServer(mon, cfg).start()
-    rows = []
+    sse = SseListener(srv.url).start()
+    page = PagePoller(srv.url, page_poll_s, offset_s=0.37 * page_poll_s).start()
+    rows: List[Dict[str, Any]] = []
+    step = int(step_gib * GIB)
+    rt = mon.tasks["realtime"]
     try:
         smi_idx = _smi_index_for(torch, dev, mon.gpu)
         key = f"gpu/{smi_idx}/hbm"
         total_mib = next(g["memoryTotal"] for g in mon.get("gpus") if g["index"] == smi_idx)
-        with HbmHold(dev.index or 0) as hold:
-            for tier, pct in tiers:
-                # decorrelate the crossing from the sampler's grid
-                time.sleep(0.37 * realtime_period % 1.0)
-                used_mib = next(g["memoryUsed"] for g in mon.gpu.sample() if g["index"] == smi_idx)
-                want = int(total_mib * pct / 100.0 - used_mib) * MIB
-                t_alloc0 = time.perf_counter()
-                got = hold.add(want) if want > 0 else 0
-                t_cross = time.perf_counter()                 # memory is allocated AND touched here
-                seen = None
-                while time.perf_counter() - t_cross < timeout_s:
-                    a = json.loads(urllib.request.urlopen(srv.url + "/api/alerts", timeout=3).read())
-                    if any(x.get("key") == key for x in a[tier]):
-                        seen = time.perf_counter()
-                        break
-                    time.sleep(poll_s)
-                rows.append({"tier": tier, "target_percent": pct, "added_GiB": got / GIB, "alloc_s": t_cross - t_alloc0,
-                             "latency_s": None if seen is None else seen - t_cross})
-                if seen is None:
+        minor = float(cfg.thresholds.hbm[0])
+
+        def used_mib() -> int:
+            return next(g["memoryUsed"] for g in mon.gpu.sample() if g["index"] == smi_idx)
+
+        def observe(tier: str, t_cross: float) -> Dict[str, Any]:
+            seen = _wait_until(lambda: _alerts_have(srv.url, key, tier), timeout_s, fast_poll_s)
+            out = {"server_latency_s": None if seen is None else seen - t_cross}
+            if seen is not None:
+                # the push follows the evaluation at once; the page's timer may need up to one more poll period
+                t_sse = _wait_until(lambda: sse.first(key, tier, t_cross) is not None, 2.0)
+                t_poll = _wait_until(lambda: page.first(key, tier, t_cross) is not None, page_poll_s + 2.0)
+                out["sse_latency_s"] = None if t_sse is None else sse.first(key, tier, t_cross) - t_cross
+                out["poll_latency_s"] = None if t_poll is None else page.first(key, tier, t_cross) - t_cross
+            return out
+
+        with hold:
+            t0 = time.perf_counter()
+            base = int(total_mib * minor / 100.0 - used_mib()) * MIB - step // 2
+            hold.add(base)
+            fill_s = time.perf_counter() - t0
+            for i, u in enumerate(stratified_phases(crossings, seed)):
+                # start from a tick at which the alert is NOT showing, then cross `u` of a period after that tick
+                if _wait_until(lambda: not _alerts_have(srv.url, key, None), timeout_s) is None:
                     break
-        time.sleep(min(realtime_period, 2.0) + 0.5)
+                n_calls = rt.calls
+                _wait_until(lambda: rt.calls > n_calls, realtime_period + 2.0, 0.01)
+                t_tick = time.perf_counter()
+                time.sleep(max(0.0, u * realtime_period - (time.perf_counter() - t_tick)))
+                t_a = time.perf_counter()
+                got = hold.add(step)
+                t_cross = time.perf_counter()                 # memory is allocated AND touched here
+                row = {"tier": "minor", "round": i, "phase_of_period": round((t_cross - t_tick) / realtime_period, 3),
+                       "added_GiB": got / GIB, "alloc_s": t_cross - t_a}
+                row.update(observe("minor", t_cross))
+                t_d = time.perf_counter()
+                hold.drop(step)
+                cleared = _wait_until(lambda: not _alerts_have(srv.url, key, None), timeout_s)
+                row["clear_s"] = None if cleared is None else cleared - t_d
+                rows.append(row)
+                if row["server_latency_s"] is None:
+                    break
+            for j, (tier, pct) in enumerate(upper_tiers):
+                want = int(total_mib * pct / 100.0 - used_mib()) * MIB + step // 2
+                time.sleep(stratified_phases(len(upper_tiers), seed + 1)[j] * realtime_period)
+                t_a = time.perf_counter()
+                got = hold.add(want) if want > 0 else 0
+                t_cross = time.perf_counter()
+                row = {"tier": tier, "target_percent": pct, "added_GiB": got / GIB, "alloc_s": t_cross - t_a}
+                row.update(observe(tier, t_cross))
+                rows.append(row)
+                if row["server_latency_s"] is None:
+                    break
+        tick_max_s = rt.max_s
+        time.sleep(0.5)
     finally:
+        sse.stop()
+        page.stop()
         srv.stop()
         mon.stop()
-    lats = [r["latency_s"] for r in rows if r["latency_s"] is not None]
-    return {"rows": rows, "sample_period_s": realtime_period, "client_poll_s": poll_s,
-            "max_latency_s": max(lats) if len(lats) == len(tiers) else None, "mean_latency_s": _mean(lats)}
+
+    def dist(k: str, only_minor: bool = False) -> Dict[str, Any]:
+        xs = [r[k] for r in rows if r.get(k) is not None and (r["tier"] == "minor" or not only_minor)]
+        return {"n": len(xs), "min": min(xs) if xs else None, "mean": _mean(xs), "max": max(xs) if xs else None}
+
+    want_rows = crossings + len(upper_tiers)
+    complete = len(rows) == want_rows and all(r.get("server_latency_s") is not None for r in rows)
+    server, push, poll = dist("server_latency_s"), dist("sse_latency_s"), dist("poll_latency_s")
+    minor_server = dist("server_latency_s", only_minor=True)
+    all_max = [d["max"] for d in (server, push, poll) if d["max"] is not None]
+    return {"rows": rows, "crossings": len(rows), "sample_period_s": realtime_period, "page_poll_s": page_poll_s, "seed": seed,
+            "step_GiB": step_gib, "base_fill_s": fill_s, "tick_max_s": tick_max_s, "complete": complete,
+            "server": server, "sse": push, "poll": poll,
+            "server_latency_spread_s": (minor_server["max"] - minor_server["min"]) if minor_server["n"] else None,
+            "bound_sse_s": realtime_period + tick_max_s, "bound_poll_s": realtime_period + tick_max_s + page_poll_s,
+            "sse_latency_max_s": push["max"], "poll_latency_max_s": poll["max"], "server_latency_max_s": server["max"],
+            # the headline: the slowest any path ever was, over every crossing (None unless every crossing was seen)
+            "max_latency_s": max(all_max) if (complete and all_max) else None,
+            "mean_latency_s": server["mean"], "sse_errors": sse.errors}
+
+
+def throttle_alerts(torch, dev, src, smi_idx: int, burn_s: float = 12.0, period_s: float = 2.0, idle_s: float = 3.0,
+                    size: int = 8192, timeout_s: float = 15.0, monitor=None, burner=None) -> Dict[str, Any]:
+    """Power-cap throttling on real hardware (BASELINE.json config 5, "thermal throttle"; the reference's only GPU health
+    rule is its temperature rule, monitor_server.js:183-184). Changing the power cap needs root, but the bf16 burner at
+    100 % duty sits ON the 1400 W cap by itself: the firmware then holds the package at the cap by lowering the clock,
+    which is exactly what `throttle.residencyPercent.ppt` counts. The phase runs the whole product next to the burner and
+    checks, from outside (HTTP and the event stream):
+
+      * `gpu/N/power` (serious: >= 98 % of powerCapW) and `gpu/N/throttle_ppt` (minor: ppt residency > 50 %) appear, how
+        long after the load started, on /api/alerts and on /api/events;
+      * ppt residency > 50 % in steady state, with the clock below its idle value (the cross-check: residency says the
+        firmware is capping, the clock shows it doing so);
+      * both alerts clear within two sampler periods of the load's stop."""
+    from ..config import load_config
+    from ..server.http import MonitorServer
+    from ..server.sampler import Monitor
+    if monitor is None:
+        cfg = load_config(env={}, overrides={"server": {"port": 0, "host": "127.0.0.1"},
+                                             "sources": {"gpu": "amdsmi", "kube": "none", "vllm": "none", "history": "local"},
+                                             "periods": {"realtime": period_s}})
+        monitor = Monitor(cfg)
+    cfg = monitor.cfg
+    period_s = float(cfg.periods.realtime)
+    if burner is None:
+        from ..loadgen.burner import Burner
+        burner = Burner("gemm_bf16", size=size, duty=100.0, device=dev.index or 0)
+        torch.cuda.synchronize(dev)
+        time.sleep(1.0)                                       # the calibration's own power burst is over
+    b = burner
+    mon = monitor.start()
+    srv = MonitorServer(mon, cfg).start()
+    sse = SseListener(srv.url).start()
+    k_power, k_ppt = f"gpu/{smi_idx}/power", f"gpu/{smi_idx}/throttle_ppt"
+    trace: List[Dict[str, Any]] = []
+    seen_version = [-1]
+
+    def snap(phase: str) -> None:
+        if mon.version == seen_version[0]:
+            return
+        seen_version[0] = mon.version
+        g = next((x for x in mon.get("gpus") if x.get("index") == smi_idx), None)
+        if g:
+            trace.append({"t": time.perf_counter(), "phase": phase, "power_w": g.get("powerW"), "power_cap_w": g.get("powerCapW"),
+                          "clock_gfx_mhz": g.get("clockGfxMHz"), "ppt_residency_pct": ((g.get("throttle") or {}).get("residencyPercent") or {}).get("ppt"),
+                          "temperature": g.get("temperature")})
+
+    def watch(seconds: float, phase: str, until=None) -> None:
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end and not (until and until()):
+            snap(phase)
+            time.sleep(0.05)
+
+    res: Dict[str, Any] = {"period_s": period_s, "burn_s": burn_s}
+    try:
+        watch(idle_s, "idle")
+        res["alerts_before_load"] = [k for k in (k_power, k_ppt) if _alerts_have(srv.url, k, None)]
+        t_start = time.perf_counter()
+        b.start(burn_s + 60.0)
+        first: Dict[str, Optional[float]] = {k_power: None, k_ppt: None}
+        t_end = t_start + burn_s
+        while time.perf_counter() < t_end:
+            snap("burn")
+            for k, tier in ((k_power, "serious"), (k_ppt, "minor")):
+                if first[k] is None and _alerts_have(srv.url, k, tier):
+                    first[k] = time.perf_counter()
+            time.sleep(0.05)
+        out = b.stop()
+        t_stop = time.perf_counter()
+        cleared = {k: None for k in first}
+
+        def all_clear() -> bool:
+            for k in cleared:
+                if cleared[k] is None and not _alerts_have(srv.url, k, None):
+                    cleared[k] = time.perf_counter()
+            return all(v is not None for v in cleared.values())
+
+        watch(timeout_s, "cool", until=all_clear)
+        watch(0.3, "cool")
+        idle = [r for r in trace if r["phase"] == "idle"]
+        burn = [r for r in trace if r["phase"] == "burn" and r["t"] - t_start >= 2 * period_s + 1.0]     # steady state
+        ppt = [r["ppt_residency_pct"] for r in burn if r["ppt_residency_pct"] is not None]
+        clk_idle, clk_burn = _mean([r["clock_gfx_mhz"] for r in idle]), _mean([r["clock_gfx_mhz"] for r in burn])
+        pw, cap = _mean([r["power_w"] for r in burn]), next((r["power_cap_w"] for r in burn if r["power_cap_w"]), None)
+        res.update({
+            "tflops_busy": out.get("tflops_busy"), "duty_achieved": out.get("duty_achieved"),
+            "power_mean_w": pw, "power_cap_w": cap, "power_pct_of_cap": (pw / cap * 100.0) if pw and cap else None,
+            "ppt_residency_mean_pct": _mean(ppt), "ppt_residency_min_pct": min(ppt) if ppt else None,
+            "clock_idle_mhz": clk_idle, "clock_under_cap_mhz": clk_burn,
+            "clock_dropped": bool(clk_idle and clk_burn and clk_burn < clk_idle - 50.0),
+            "power_alert_latency_s": None if first[k_power] is None else first[k_power] - t_start,
+            "throttle_alert_latency_s": None if first[k_ppt] is None else first[k_ppt] - t_start,
+            "power_alert_sse_latency_s": (lambda t: None if t is None else t - t_start)(sse.first(k_power, "serious", t_start)),
+            "throttle_alert_sse_latency_s": (lambda t: None if t is None else t - t_start)(sse.first(k_ppt, "minor", t_start)),
+            "power_alert_clear_s": None if cleared[k_power] is None else cleared[k_power] - t_stop,
+            "throttle_alert_clear_s": None if cleared[k_ppt] is None else cleared[k_ppt] - t_stop,
+            "power_alert_sse_clear_s": (lambda t: None if t is None else t - t_stop)(sse.first(k_power, None, t_stop, present=False)),
+            "clear_bound_s": 2.0 * period_s,
+            "trace": [{"t": round(r["t"] - trace[0]["t"], 2), "phase": r["phase"], "power_w": r["power_w"], "clock_gfx_mhz": r["clock_gfx_mhz"],
+                       "ppt_residency_pct": None if r["ppt_residency_pct"] is None else round(r["ppt_residency_pct"], 1)} for r in trace]})
+        bound = res["clear_bound_s"]
+        res["power_alert"] = bool(res["power_alert_latency_s"] is not None and res["power_alert_sse_latency_s"] is not None
+                                  and res["power_alert_clear_s"] is not None and res["power_alert_clear_s"] <= bound
+                                  and not res["alerts_before_load"])
+        res["throttle_alert"] = bool(res["throttle_alert_latency_s"] is not None and res["throttle_alert_sse_latency_s"] is not None
+                                     and res["throttle_alert_clear_s"] is not None and res["throttle_alert_clear_s"] <= bound
+                                     and (res["ppt_residency_mean_pct"] or 0.0) > 50.0 and res["clock_dropped"])
+    finally:
+        try:
+            b.stop()                                          # a second stop is harmless; an exception above must not leave it burning
+        except Exception:
+            pass
+        sse.stop()
+        srv.stop()
+        mon.stop()
+        del b, burner
+        if torch is not None:
+            torch.cuda.empty_cache()
+    return res
 
 
 def xgmi_expected_bytes(world: int, nbytes: int, iters: int) -> float:
@@ -667,20 +1025,32 @@ def llm_activity(torch, dev, src, smi_idx: int, seconds: float = 2.5, model: str
 
 # ------------------------------------------------------------------------------------------
 def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=None, a=None,
-            quick: bool = True, which: str = "all") -> Dict[str, Any]:
+            quick: bool = True, which: str = "all", budget: Optional[Budget] = None) -> Dict[str, Any]:
     """Every phase on this rank's GPU. Rank 0 only when several ranks share a node (the
-    phases fill HBM and start a server)."""
+    phases fill HBM and start a server). With a `budget` the run is priced first (`plan_phases`: phases that do not fit
+    are shed, longest first) and every phase is checked against what is left before it starts; `shed` lists both."""
     if rank != 0:
         return {}
     from ..collectors.gpu import open_gpu_source
     out: Dict[str, Any] = {}
-    want = set(which.split(",")) if which != "all" else {"hbm", "activity", "power", "mem", "overhead", "latency", "llm", "vllm"}
+    want = set(which.split(",")) if which != "all" else set(PHASE_ORDER)
+    left = budget.left() if budget is not None else None
+    plan, shed = plan_phases(want, left)
+    out["plan"] = {"phases": plan, "shed_before_start": shed, "budget_left_s": None if left is None else round(left, 1),
+                   "priced_s": sum(PHASE_COST_S.get(p, 30.0) for p in plan)}
+    if shed:
+        print(f"[validate] time budget: {left:.0f} s left, shedding {shed}", file=sys.stderr, flush=True)
     src = open_gpu_source("amdsmi")
     try:
         idx = _smi_index_for(torch, dev, src)
         out["amdsmi_index"] = idx
 
-        def guard(name, fn):
+        def guard(phase, name, fn):
+            if phase not in plan:
+                return
+            if budget is not None and not budget.allows(phase, PHASE_COST_S.get(phase, 30.0)):
+                print(f"[validate] {name}: shed, {budget.shed[-1]}", file=sys.stderr, flush=True)
+                return
             t0 = time.time()
             try:
                 out[name] = fn()
@@ -690,25 +1060,19 @@ def run_all(torch, dist, ops, dev, rank: int, world: int, load=None, sampler=Non
             # progress goes to stderr: bench.py's stdout carries exactly one JSON line
             print(f"[validate] {name}: {json.dumps(out[name])[:600]}", file=sys.stderr, flush=True)
 
-        if "hbm" in want:
-            guard("hbm_fidelity", lambda: hbm_fidelity(torch, dev, src, idx, steps_gib=(16, 64) if quick else (16, 64, 128, 200)))
-        if "activity" in want:
-            guard("activity_fidelity", lambda: activity_fidelity(torch, dev, src, idx, seconds=4.0 if quick else 10.0))
-        if "power" in want:
-            guard("power_temperature", lambda: power_temperature(torch, dev, src, idx, burn_s=13.0 if quick else 25.0))
-        if "mem" in want:
-            guard("mem_activity", lambda: mem_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
-        if "overhead" in want:
-            guard("overhead", lambda: overhead(torch, dev, seconds=5.0 if quick else 8.0, repeats=5 if quick else 7))
-        if "latency" in want:
-            guard("alert_latency", lambda: alert_latency(torch, dev))
-        if "llm" in want:
-            guard("llm_activity", lambda: llm_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
-        if "vllm" in want:
-            guard("vllm_fidelity", lambda: vllm_fidelity(torch, dev, seconds=12.0 if quick else 30.0,
-                                                         period_s=3.0 if quick else 5.0))
+        guard("hbm", "hbm_fidelity", lambda: hbm_fidelity(torch, dev, src, idx, steps_gib=(16, 64) if quick else (16, 64, 128, 200)))
+        guard("activity", "activity_fidelity", lambda: activity_fidelity(torch, dev, src, idx, seconds=4.0 if quick else 10.0))
+        guard("power", "power_temperature", lambda: power_temperature(torch, dev, src, idx, burn_s=13.0 if quick else 25.0))
+        guard("throttle", "throttle_alerts", lambda: throttle_alerts(torch, dev, src, idx, burn_s=12.0 if quick else 20.0))
+        guard("mem", "mem_activity", lambda: mem_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
+        guard("overhead", "overhead", lambda: overhead(torch, dev, seconds=5.0 if quick else 8.0, repeats=5 if quick else 7))
+        guard("latency", "alert_latency", lambda: alert_latency(torch, dev, crossings=8 if quick else 16))
+        guard("llm", "llm_activity", lambda: llm_activity(torch, dev, src, idx, seconds=2.0 if quick else 5.0))
+        guard("vllm", "vllm_fidelity", lambda: vllm_fidelity(torch, dev, seconds=12.0 if quick else 30.0,
+                                                             period_s=3.0 if quick else 5.0))
     finally:
         src.close()
+    out["shed"] = shed + [x["phase"] for x in (budget.shed if budget is not None else [])]
     out["summary"] = summarize(out)
     return out
 
@@ -732,16 +1096,43 @@ def summarize(out: Dict[str, Any]) -> Dict[str, Any]:
          "sampling_overhead_gpu_side_pct": g("overhead", "overhead_gpu_side_pct"),
          "sampling_overhead_20hz_pct": g("overhead", "overhead_stress_pct"),
          "sampler_calls_per_window": ((g("overhead", "sampler_stats") or {}).get("on") or {}).get("calls"),
+         # the slowest of every crossing on every delivery path (server, /api/events push, the page's poll)
          "alert_latency_max_s": g("alert_latency", "max_latency_s"),
+         "alert_latency_crossings": g("alert_latency", "crossings"),
+         "alert_latency_spread_s": g("alert_latency", "server_latency_spread_s"),
+         "sse_latency_max_s": g("alert_latency", "sse_latency_max_s"),
+         "poll_latency_max_s": g("alert_latency", "poll_latency_max_s"),
+         "alert_latency_bound_s": g("alert_latency", "bound_poll_s"),
+         "power_alert": g("throttle_alerts", "power_alert"),
+         "throttle_alert": g("throttle_alerts", "throttle_alert"),
+         "ppt_residency_pct": g("throttle_alerts", "ppt_residency_mean_pct"),
+         "power_alert_latency_s": g("throttle_alerts", "power_alert_latency_s"),
+         "throttle_alert_clear_s": g("throttle_alerts", "throttle_alert_clear_s"),
          "vllm_tokens_per_s_error_pct": g("vllm_fidelity", "max_tokens_per_s_error_pct"),
          "vllm_kv_cache_error_points": g("vllm_fidelity", "max_kv_error_points"),
          "vllm_ttft_p50_in_true_bucket": g("vllm_fidelity", "ttft_p50_in_true_bucket")}
     s["targets"] = {"error_pct": 2.0, "overhead_pct": 1.0, "alert_latency_s": 10.0, "temperature_rise_c": 3.0}
     high = s["sampling_overhead_high_pct"] if s["sampling_overhead_high_pct"] is not None else s["sampling_overhead_pct"]
-    s["pass"] = {"hbm": s["hbm_error_pct"] is not None and s["hbm_error_pct"] <= 2.0,
-                 "activity": s["gfx_activity_error_points"] is not None and s["gfx_activity_error_points"] <= 2.0,
-                 "overhead": high is not None and high < 1.0,
-                 "latency": s["alert_latency_max_s"] is not None and s["alert_latency_max_s"] < 10.0}
+    s["pass"] = {}
+    if "hbm_fidelity" in out:
+        s["pass"]["hbm"] = s["hbm_error_pct"] is not None and s["hbm_error_pct"] <= 2.0
+    if "activity_fidelity" in out:
+        s["pass"]["activity"] = s["gfx_activity_error_points"] is not None and s["gfx_activity_error_points"] <= 2.0
+    if "overhead" in out:
+        s["pass"]["overhead"] = high is not None and high < 1.0
+    if "alert_latency" in out:
+        s["pass"]["latency"] = s["alert_latency_max_s"] is not None and s["alert_latency_max_s"] < 10.0
+    if "throttle_alerts" in out:
+        s["pass"]["power_alert"] = bool(s["power_alert"])
+        s["pass"]["throttle_alert"] = bool(s["throttle_alert"])
+    if "xgmi_fidelity" in out:
+        xf = out["xgmi_fidelity"] or {}
+        s["xgmi_unit_verdict_tx"] = (xf.get("unit_check_tx") or {}).get("verdict")
+        s["xgmi_unit_verdict_rx"] = (xf.get("unit_check_rx") or {}).get("verdict")
+        s["xgmi_tx_error_pct"], s["xgmi_world"] = xf.get("tx_error_pct"), xf.get("world")
+        if (xf.get("world") or 1) > 1:
+            s["pass"]["xgmi"] = xf.get("tx_error_pct") is not None and xf["tx_error_pct"] <= 2.0
+    s["shed"] = out.get("shed") or []
     if "power_temperature" in out:
         s["pass"]["power"] = s["power_error_pct"] is not None and s["power_error_pct"] <= 2.0
         s["pass"]["temperature"] = bool(s["temperature_monotonic"]) and bool(s["temperature_follows_load"])

@@ -58,6 +58,19 @@ def test_native_sampler_agrees_with_the_python_reader(torch_dev):
         assert a["memoryTotal"] == b["memoryTotal"] and abs(a["memoryUsed"] - b["memoryUsed"]) < 512
         assert abs(a["temperature"] - b["temperature"]) <= 3 and "Instinct" in a["name"] and "Instinct" in b["name"]
         assert a["peak"]["power_w"] >= a["powerW"] - 1
+        # the same RAW key sets (with sources.gpu = native the PCIe-replay alert and the per-XCD bars
+        # must not silently disappear), minus a documented allow-list and the sampler's own additions
+        ra, rb = nat.reader.read()[0], py.reader.read()[0]
+        missing = set(rb) - set(ra) - NativeSamplerReader.RAW_KEYS_NOT_EMITTED
+        assert not missing, sorted(missing)
+        assert set(ra) - set(rb) <= {"peak"}, sorted(set(ra) - set(rb))
+        for k in ("pcie_replay_acc", "pcie_l0_recovery_acc", "pcie_link_speed", "pcie_link_width", "pcie_bandwidth_acc"):
+            assert ra[k] == rb[k] or abs(ra[k] - rb[k]) <= max(4, rb[k] // 1000), (k, ra[k], rb[k])
+        assert len(ra["xcd_busy_acc"]) == len(rb["xcd_busy_acc"]) == 8 and len(ra["xcd_busy_inst"]) == 8
+        # ... and so the same normalised panels: PCIe link, error counters, per-XCD activity
+        assert a["pcie"]["linkWidth"] == b["pcie"]["linkWidth"] and a["pcie"]["linkSpeedGTs"] == b["pcie"]["linkSpeedGTs"]
+        assert set(a["pcie"]["errors"]) == set(b["pcie"]["errors"]) and "replay" in a["pcie"]["errors"]
+        assert a["xcdActivity"] is not None and len(a["xcdActivity"]) == 8
     finally:
         nat.close()
         py.close()

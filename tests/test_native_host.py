@@ -77,6 +77,21 @@ def test_sampler_json_writer_under_asan_ubsan_feeds_the_python_reader(built, tmp
     assert g1["temp_edge"] is None                                   # unsupported sentinel -> null
     assert g1["xgmi_link_status"][1] is None and g1["xgmi_link_status"][0] == 1
     assert g1["peak"]["power_w"] == 900 and g1["power_w"] == 600     # mean and peak of the period
+    # PCIe health, per-XCD accumulators and the process table: what the Python reader emits
+    assert g1["pcie_replay_acc"] == 8 and g1["pcie_l0_recovery_acc"] == 2 and g1["pcie_nak_sent_acc"] == 0 and g1["pcie_nak_rcvd_acc"] is None
+    assert g1["pcie_link_speed"] == 320 and g1["pcie_link_width"] == 16 and g1["pcie_bandwidth_acc"] == 123456789 and g1["pcie_replay_rollover_acc"] == 0
+    assert g1["xcd_busy_acc"] == [1000000 * (x + 1) + 1 for x in range(8)] and g1["xcd_busy_inst"] == [10 * x for x in range(8)]
+    assert g1["processes"] == 2 and g1["process_list"][0] == {"pid": 4242, "name": 'python3 "vllm"', "vramBytes": 17179869184}
+    assert "processes" not in line["gpus"][0] and g1["peak"]["temp_edge"] is None
+    from k8s_llm_monitor_amd.collectors.gpu import metrics_to_raw
+    py_keys = set(metrics_to_raw({k: 1 for k in (
+        "average_gfx_activity", "average_umc_activity", "gfx_activity_acc", "mem_activity_acc", "accumulation_counter", "firmware_timestamp",
+        "current_socket_power", "energy_accumulator", "temperature_hotspot", "temperature_mem", "temperature_edge", "current_gfxclk", "current_uclk",
+        "prochot_residency_acc", "ppt_residency_acc", "socket_thm_residency_acc", "vr_thm_residency_acc", "hbm_thm_residency_acc",
+        "xgmi_read_data_acc", "xgmi_write_data_acc", "xgmi_link_status", "xgmi_link_width", "xgmi_link_speed", "pcie_bandwidth_inst",
+        "pcie_bandwidth_acc", "pcie_link_speed", "pcie_link_width", "pcie_replay_count_acc", "pcie_replay_rover_count_acc",
+        "pcie_l0_to_recov_count_acc", "pcie_nak_sent_count_acc", "pcie_nak_rcvd_count_acc")} | {"xcp_stats.gfx_busy_acc": [[1] * 8], "xcp_stats.gfx_busy_inst": [[1] * 8]}))
+    assert py_keys <= set(g1), sorted(py_keys - set(g1))             # every metrics key of the Python reader is in the sampler's line
     # the same line through the production reader and normaliser
     src = GpuSource(NativeSamplerReader(argv=[str(san.out), "--selftest"]))
     try:
@@ -84,6 +99,8 @@ def test_sampler_json_writer_under_asan_ubsan_feeds_the_python_reader(built, tmp
         assert [x["index"] for x in s] == [0, 1] and s[0]["memoryTotal"] == 294896 and s[1]["memoryUsed"] == 1284
         assert s[0]["temperature"] == 46 and s[0]["utilization"] == 20 and s[0]["powerCapW"] == 1400
         assert len(s[0]["xgmi"]["links"]) == 7 and s[0]["peak"]["gfx_activity"] == 30
+        assert s[1]["pcie"]["errors"]["replay"]["count"] == 8 and s[1]["pcie"]["linkSpeedGTs"] == 32.0 and s[1]["xcdActivity"] == [10 * x for x in range(8)]
+        assert s[1]["processes"] == 2 and s[1]["processList"][1]["name"] == "klm_burner"
     finally:
         src.close()
 

@@ -1,5 +1,7 @@
 """Operand layout helpers of the GEMM wrappers (CPU): which row pitches get padded, what a padded operand looks like, and
 that the wrappers refuse what the kernels cannot take before anything is launched."""
+import os
+
 import pytest
 import torch
 
@@ -33,3 +35,55 @@ def test_pitch_of_a_pair_of_operands():
         ops._pitch_bytes(a, torch.empty(512, 12288, dtype=torch.bfloat16))
     with pytest.raises(ops.KlmOpsError, match="GPU only"):
         ops.gemm_bf16(a, b)
+
+
+def test_build_staleness_is_a_content_hash_embedded_in_the_binary(tmp_path):
+    """mtimes prove nothing after a snapshot copy or a checkout. The build passes a hash of the target's
+    sources to the compiler, the binary carries it, `stale()` compares it with the tree, `smoke()` asserts it."""
+    import shutil
+    import time
+    from k8s_llm_monitor_amd import build
+    if not shutil.which("g++"):
+        import pytest
+        pytest.skip("g++ not installed")
+    src = tmp_path / "tool.cpp"
+    hdr = tmp_path / "tool.h"
+    hdr.write_text("#define ANSWER 42\n")
+    src.write_text('#include <cstdio>\n#include "tool.h"\nextern "C" __attribute__((used)) const char klm_src_hash_marker[] = "KLM_SRC_HASH=" KLM_SRC_HASH;\n'
+                   'int main() { printf("%d %s\\n", ANSWER, klm_src_hash_marker); return 0; }\n')
+    t = build.Target("tool", tmp_path / "tool", [src], "cxx-exe", deps=[hdr])
+    assert t.stale() and build.embedded_hash(t.out) is None
+    assert build.build_target(t, verbose=False) is True
+    h1 = t.source_hash()
+    assert not t.stale() and build.embedded_hash(t.out) == h1 and build.build_target(t, verbose=False) is False
+    # touching the files (new mtimes, same content) does not make it stale; an OLDER source with new content does
+    now = time.time()
+    os.utime(src, (now + 100, now + 100))
+    assert not t.stale()
+    hdr.write_text("#define ANSWER 43\n")
+    os.utime(hdr, (now - 10000, now - 10000))
+    assert t.stale() and t.source_hash() != h1
+    build.build_target(t, verbose=False)
+    assert not t.stale() and build.embedded_hash(t.out) == t.source_hash()
+    # flags are part of the hash: the sanitizer preset of the same sources is another artefact
+    assert build.sanitized(t, tmp_path / "asan").source_hash() != t.source_hash()
+
+
+def test_shipped_library_carries_the_tree_hash_and_the_hbm_launch_plan():
+    from k8s_llm_monitor_amd import build, ops
+    if build.hipcc() is None:
+        import pytest
+        pytest.skip("hipcc not installed")
+    build.build_all(verbose=False)
+    ops.assert_current()
+    assert ops.src_hash() == ops.tree_hash() and ops.src_hash() in ops.version() and len(ops.src_hash()) == 16
+    assert all(not t.stale() for t in build.targets())
+    # ADVICE r2: HIP's grid limit (2^32 - 1 threads) is 64 GiB at one 16-byte access per thread; the 288 GB card needs more
+    GIB = 1 << 30
+    assert ops.hbm_launch_plan(4 * GIB) == (1, 4 * GIB // 4096, 4 * GIB // 4096)
+    assert ops.hbm_launch_plan(64 * GIB - 4096) == (1, 16777215, 16777215)
+    n, first, last = ops.hbm_launch_plan(64 * GIB)
+    assert (n, first, last) == (2, 16777215, 1)
+    n, first, last = ops.hbm_launch_plan(200 * GIB)
+    assert n == 4 and first == 16777215 and (n - 1) * first + last == 200 * GIB // 4096
+    assert first * 256 <= 0xFFFFFFFF < (first + 1) * 256

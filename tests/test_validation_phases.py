@@ -63,3 +63,130 @@ def test_kernel_durations_skip_warmup_and_match_by_name():
     d = rocprof.kernel_durations(rows, "gemm_bf16", skip=4)
     assert d == [0.7] * 6
     assert rocprof.kernel_durations(rows, "nothing") == []
+
+
+# ---- time budget ---------------------------------------------------------------
+def test_plan_phases_sheds_the_longest_first_and_keeps_canonical_order():
+    cost = {"hbm": 10, "activity": 25, "overhead": 85, "latency": 120, "vllm": 20}
+    want = {"vllm", "hbm", "latency", "overhead", "activity"}
+    assert phases.plan_phases(want, None, cost) == (["hbm", "activity", "overhead", "latency", "vllm"], [])
+    assert phases.plan_phases(want, 260, cost) == (["hbm", "activity", "overhead", "latency", "vllm"], [])
+    assert phases.plan_phases(want, 259, cost) == (["hbm", "activity", "overhead", "vllm"], ["latency"])
+    assert phases.plan_phases(want, 60, cost) == (["hbm", "activity", "vllm"], ["latency", "overhead"])
+    assert phases.plan_phases(want, 5, cost) == ([], ["latency", "overhead", "activity", "vllm", "hbm"])
+    assert set(phases.PHASE_COST_S) == set(phases.PHASE_ORDER)
+    b = phases.Budget(100.0, t0=time.monotonic() - 50.0, reserve_s=10.0)
+    assert 39.0 < b.left() <= 40.0 and b.allows("hbm", 10.0) and not b.allows("overhead", 85.0)
+    assert b.shed[0]["phase"] == "overhead" and phases.Budget(None).allows("x", 1e9)
+
+
+def test_stratified_phases_cover_the_period_and_are_seeded():
+    xs = phases.stratified_phases(8, 20261111)
+    assert xs == phases.stratified_phases(8, 20261111) != phases.stratified_phases(8, 1)
+    assert sorted(int(x * 8) for x in xs) == list(range(8)) and max(xs) - min(xs) > 0.75
+
+
+class _FakeHold:
+    """HbmHold's interface over the fake GPU reader's scripted HBM level."""
+
+    def __init__(self, level, total_bytes):
+        self.level, self.total, self.held = level, total_bytes, 0
+
+    def add(self, n):
+        self.held += n
+        self.level["frac"] += n / self.total
+        return n
+
+    def drop(self, n):
+        self.held -= n
+        self.level["frac"] -= n / self.total
+        return n
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.level["frac"] -= self.held / self.total
+        self.held = 0
+
+
+def _fake_monitor(scenario, realtime, page_poll=0.3):
+    from k8s_llm_monitor_amd.collectors.gpu import GpuSource
+    from k8s_llm_monitor_amd.config import demo_config
+    from k8s_llm_monitor_amd.fakes.gpu import FakeGpuReader
+    from k8s_llm_monitor_amd.server.sampler import Monitor
+    cfg = demo_config(periods={"realtime": realtime, "page_alert_poll": page_poll}, sources={"kube": "none", "vllm": "none"})
+    return Monitor(cfg, gpu=GpuSource(FakeGpuReader(1, scenario=scenario)))
+
+
+def test_alert_latency_loop_measures_a_distribution_on_every_path():
+    """The crossing loop, the three observers and the summary arithmetic against the fake GPU source (a 0.5 s sampler period
+    and a 0.3 s page poll so the test takes seconds): VERDICT r2 weak 4."""
+    from k8s_llm_monitor_amd.fakes.gpu import HBM_TOTAL_MIB, GpuState
+    level = {"frac": 0.10}
+    mon = _fake_monitor(lambda t, i: GpuState(hbm_frac=level["frac"]), realtime=0.5)
+    r = phases.alert_latency(None, None, crossings=4, step_gib=4.0, monitor=mon, hold=_FakeHold(level, HBM_TOTAL_MIB << 20), timeout_s=5.0)
+    assert r["complete"] and r["crossings"] == 6 and [x["tier"] for x in r["rows"]] == ["minor"] * 4 + ["serious", "critical"]
+    assert sorted(int(x["phase_of_period"] * 4) for x in r["rows"][:4]) == [0, 1, 2, 3]          # one crossing per quarter of the period
+    for x in r["rows"]:
+        assert 0 <= x["server_latency_s"] <= r["bound_sse_s"] + 0.1 and x["sse_latency_s"] is not None and x["poll_latency_s"] is not None
+        assert x["sse_latency_s"] <= x["server_latency_s"] + 0.06              # the push does not wait for a poll
+        assert x["poll_latency_s"] <= r["bound_poll_s"] + 0.1
+    assert r["server_latency_spread_s"] > 0.2 and r["max_latency_s"] == max(r["poll"]["max"], r["sse"]["max"], r["server"]["max"])
+    assert r["sample_period_s"] == 0.5 and r["page_poll_s"] == 0.3 and r["bound_poll_s"] == pytest_approx(0.8 + r["tick_max_s"])
+    assert abs(level["frac"] - 0.10) < 1e-9                                       # everything released
+    s = phases.summarize({"alert_latency": r})
+    assert s["pass"] == {"latency": True} and s["alert_latency_crossings"] == 6 and s["sse_latency_max_s"] == r["sse"]["max"]
+
+
+def test_throttle_phase_sees_both_alerts_appear_and_clear():
+    """BASELINE.json config 5 on the fake: the "burner" puts the card on its power cap (99 % of 1400 W, ppt residency 100 %,
+    clock 2400 -> 1830 MHz); both alerts appear on /api/alerts and /api/events and clear within two periods of the stop."""
+    from k8s_llm_monitor_amd.fakes.gpu import GpuState
+    on = {"burn": False}
+
+    class FakeBurner:
+        def start(self, seconds):
+            on["burn"] = True
+            return self
+
+        def stop(self):
+            on["burn"] = False
+            return {"tflops_busy": 1600.0, "duty_achieved": 100.0}
+
+    def scen(t, i):
+        return GpuState(power_w=1390.0, ppt_throttle=1.0, clk_gfx=1830.0, gfx=100.0) if on["burn"] else GpuState(power_w=300.0, clk_gfx=2400.0)
+
+    r = phases.throttle_alerts(None, None, None, 0, burn_s=2.0, idle_s=0.5, timeout_s=4.0, monitor=_fake_monitor(scen, realtime=0.25), burner=FakeBurner())
+    assert r["power_alert"] and r["throttle_alert"] and r["alerts_before_load"] == [], r
+    assert r["ppt_residency_mean_pct"] > 90 and r["clock_dropped"] and r["clock_idle_mhz"] == 2400.0 and r["clock_under_cap_mhz"] == 1830.0
+    assert 0 < r["power_alert_latency_s"] < 0.6 and 0 < r["throttle_alert_latency_s"] < 0.9 and r["power_alert_sse_latency_s"] < 0.6
+    assert 0 < r["power_alert_clear_s"] <= 0.5 and 0 < r["throttle_alert_clear_s"] <= 0.5 and r["power_alert_sse_clear_s"] is not None
+    s = phases.summarize({"throttle_alerts": r})
+    assert s["pass"] == {"power_alert": True, "throttle_alert": True} and s["power_alert"] is True
+    # a card that never reaches its cap fails both flags, and says why
+    r = phases.throttle_alerts(None, None, None, 0, burn_s=1.0, idle_s=0.3, timeout_s=1.0, burner=FakeBurner(),
+                               monitor=_fake_monitor(lambda t, i: GpuState(power_w=900.0, clk_gfx=2400.0), realtime=0.25))
+    assert not r["power_alert"] and not r["throttle_alert"] and r["power_alert_latency_s"] is None and not r["clock_dropped"]
+
+
+def pytest_approx(x):
+    import pytest
+    return pytest.approx(x, abs=1e-6)
+
+
+def test_bench_detail_feeds_api_validation(tmp_path, monkeypatch):
+    """bench.py's full result goes to a file; its validation part is what /api/validation serves."""
+    from k8s_llm_monitor_amd.server import http
+    from k8s_llm_monitor_amd.validation import benchlib
+    monkeypatch.setenv("KLM_STATE_DIR", str(tmp_path / "state"))
+    xf = {"world": 8, "tx_error_pct": 0.7, "unit_check_tx": {"verdict": "KiB (x1024)"}, "unit_check_rx": {"verdict": "KiB (x1024)"}}
+    detail = dict(_phase_results(0.05, 0.12, 0.4), xgmi_fidelity=xf)
+    res = {"metric": "m", "value": 1.0, "validation": phases.summarize(detail), "validation_detail": detail}
+    p = benchlib.write_detail(res, str(tmp_path / "out" / "bench_detail.json"))
+    assert json.load(open(p))["validation"]["pass"]["hbm"] is True
+    rep = http.load_validation_report()
+    assert rep["source"] == "bench.py" and rep["summary"]["pass"]["xgmi"] is True and rep["summary"]["xgmi_unit_verdict_tx"] == "KiB (x1024)"
+    assert rep["xgmi_fidelity"]["world"] == 8 and rep["alert_latency"]["max_latency_s"] == 4.2
+    line = benchlib.compact(res, p)
+    assert line["xgmi_unit_verdict_tx"] == "KiB (x1024)" and line["hbm_error_pct"] == 0.2 and line["validation_pass"] is True and line["detail"] == p

@@ -29,8 +29,8 @@ def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int, d
 
     Warm-up is `warmup` steps AND at least `min_warm_s` seconds of steps: five 2 ms steps leave the card on its start-up
     clocks (the cap's control loop has not settled: 1 552 TFLOP/s timed after 10 ms of warm-up, 1 611 sustained), so the
-    number would depend on --steps / --warmup. The extra step count is derived from the first `warmup` steps' own time
-    and agreed across ranks (MAX), because under data parallelism every step is also a collective all ranks must enter."""
+    number would depend on --steps / --warmup. The extra step count is derived from the measured step time and agreed across
+    ranks (MAX), because under data parallelism every step is also a collective all ranks must enter."""
     dd = (world > 1) if distributed is None else bool(distributed)   # a one-rank group still takes the collective path
     t_w = time.perf_counter()
     for _ in range(warmup):
@@ -39,31 +39,31 @@ def timed_steps(torch, dist, load: _Load, world: int, steps: int, warmup: int, d
     _sync_all(torch, dist, dd)
     extra = 0
     if min_warm_s > 0:
-        spent = time.perf_counter() - t_w
-        per = spent / warmup if warmup > 0 else 0.0
-        if per <= 0:                                            # --warmup 0: time one step to size the rest
+        # the first steps of a process carry one-time costs (code objects, RCCL's first collective), so the step time is
+        # taken from a small synchronised chunk and the count re-derived until the wall time is met (at most a few rounds)
+        chunk = 8
+        for _ in range(6):
             t1 = time.perf_counter()
-            load.step()
+            for i in range(chunk):
+                load.step()
+                if i % 64 == 63:
+                    load.drain()
+                    if torch.cuda.is_available():
+                        torch.cuda.current_stream().synchronize()   # keep the launch queue bounded
             load.drain()
             _sync_all(torch, dist, dd)
-            per = time.perf_counter() - t1
-            spent += per
-            extra += 1
-        more = int(max(0.0, min_warm_s - spent) / max(per, 1e-6)) + 1 if spent < min_warm_s else 0
-        more = min(more, 1_000_000)
-        if dd:
-            t = torch.tensor([more], device=load.x.device, dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            more = int(t.item())
-        for i in range(more):
-            load.step()
-            if i % 64 == 63:
-                load.drain()
-                if torch.cuda.is_available():
-                    torch.cuda.current_stream().synchronize()   # keep the launch queue bounded
-        load.drain()
-        _sync_all(torch, dist, dd)
-        extra += more
+            extra += chunk
+            per = (time.perf_counter() - t1) / chunk
+            left = min_warm_s - (time.perf_counter() - t_w)
+            more = 0 if left <= 0 else min(int(left / max(per, 1e-6)) + 1, 1_000_000)
+            if dd:
+                # under data parallelism every step is also a collective all ranks must enter: agree on the count
+                t = torch.tensor([more], device=load.x.device, dtype=torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                more = int(t.item())
+            if more <= 0:
+                break
+            chunk = more
     if info is not None:
         info["warmup_steps_run"] = warmup + extra
         info["warmup_seconds"] = round(time.perf_counter() - t_w, 3)

@@ -77,7 +77,7 @@ def _smi_index_for(torch, dev, src) -> int:
 #: round-3 driver runs and rounded up). `plan_phases` prices a run with these before it starts.
 PHASE_ORDER = ("hbm", "activity", "power", "throttle", "mem", "overhead", "latency", "llm", "vllm")
 PHASE_COST_S = {"hbm": 10.0, "activity": 25.0, "power": 22.0, "throttle": 30.0, "mem": 13.0, "overhead": 85.0,
-                "latency": 120.0, "llm": 10.0, "vllm": 20.0}
+                "latency": 140.0, "llm": 10.0, "vllm": 20.0}
 
 
 def plan_phases(want, budget_s: Optional[float], cost: Optional[Dict[str, float]] = None):

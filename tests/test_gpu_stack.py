@@ -63,7 +63,8 @@ def test_native_sampler_agrees_with_the_python_reader(torch_dev):
         ra, rb = nat.reader.read()[0], py.reader.read()[0]
         missing = set(rb) - set(ra) - NativeSamplerReader.RAW_KEYS_NOT_EMITTED
         assert not missing, sorted(missing)
-        assert set(ra) - set(rb) <= {"peak"}, sorted(set(ra) - set(rb))
+        # (a field this card does not support is `null` in the sampler's line and absent from the Python reader's dict)
+        assert {k for k, v in ra.items() if v is not None} - set(rb) <= {"peak"}, sorted(set(ra) - set(rb))
         for k in ("pcie_replay_acc", "pcie_l0_recovery_acc", "pcie_link_speed", "pcie_link_width", "pcie_bandwidth_acc"):
             assert ra[k] == rb[k] or abs(ra[k] - rb[k]) <= max(4, rb[k] // 1000), (k, ra[k], rb[k])
         assert len(ra["xcd_busy_acc"]) == len(rb["xcd_busy_acc"]) == 8 and len(ra["xcd_busy_inst"]) == 8

@@ -57,6 +57,12 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         lib.klm_gemm_bf16_pitched.restype = i
         lib.klm_gemm_mx_pitched.argtypes = [i, vp, vp, vp, i, i, i, i, i, vp]
         lib.klm_gemm_mx_pitched.restype = i
+        if hasattr(lib, "klm_gemm_stream"):
+            lib.klm_gemm_stream.argtypes = [i, vp, vp, vp, i, i, i, i, i, i, i, vp, sz, vp]
+            lib.klm_gemm_stream.restype = i
+            lib.klm_gemm_stream_plan.argtypes = [i, i, i, i, i, i, sz, ctypes.POINTER(ctypes.c_int)]
+            lib.klm_gemm_stream_plan.restype = i
+            lib.klm_gemm_has_diag.restype = i
         if hasattr(lib, "klm_gemm_fp8"):
             lib.klm_gemm_fp8.argtypes = [vp, vp, vp, i, i, i, i, vp]
             lib.klm_gemm_fp8.restype = i
@@ -96,7 +102,7 @@ def _check(rc: int, what: str) -> None:
         raise KlmOpsError(f"{what}: {STATUS.get(rc, rc)} (status {rc})")
 
 
-def _stream(t) -> int:
+def _stream_of(t) -> int:
     import torch
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -190,19 +196,77 @@ def hbm_launch_plan(nbytes: int, accesses_per_thread: int = 1):
 def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0) -> int:
     """The kernel `gemm_bf16(variant=None)` runs for a shape (pure: no device, no library)."""
     if pitch:
-        return 8               # row-pitched operands: the streams are the kernels that take a pitch
+        return 10              # row-pitched operands: the streams are the kernels that take a pitch
     if (M // 256) * (N // 256) <= 32 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
         return 0               # a handful of 256 x 256 tiles leaves most CUs idle: 1024^3 runs at 127 TFLOP/s on 128 x 128 tiles, 101 on 256 x 256
     if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
-        return 8 if (K % 128 == 0 and K >= 256) else 1      # an even number of K tiles >= 4, else the ring's schedule 0
+        return 10 if (K % 128 == 0 and K >= 256) else 1     # an even number of K tiles >= 4, else the ring's schedule 0
     return 0
+
+
+#: fp32 partial sums of one K slice of one 256 x 256 tile
+SLOT_BYTES = 256 * 256 * 4
+_ws_cache: dict = {}
+
+
+def stream_workspace(device, nbytes: int = 0):
+    """The scratch the persistent streams cut their last partial round into K slices with: one buffer per (device, stream),
+    sized for the worst case (one slot per CU), allocated on first use through torch's caching allocator and kept."""
+    import torch
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ws_cache.get(key)
+    need = max(int(nbytes), torch.cuda.get_device_properties(dev).multi_processor_count * SLOT_BYTES)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _ws_cache[key] = ws
+    return ws
+
+
+def gemm_has_diag() -> bool:
+    """True when the library carries the A/B-record and diagnostic streams (a -DKLM_GEMM_DIAG build, never the shipped one)."""
+    lib = load()
+    return bool(hasattr(lib, "klm_gemm_has_diag") and lib.klm_gemm_has_diag())
+
+
+def gemm_stream_plan(M: int, N: int, Kbytes: int, cus: int = 0, mode: int = 1, rot: int = 0, ws_bytes: int = 1 << 40) -> dict:
+    """How the persistent stream runs an M x N problem whose rows hold `Kbytes` bytes of K on `cus` workgroups (0: this
+    device's CUs): `rounds` full rounds of whole tiles on `grid` workgroups, then `rest` tiles, each cut into `split` K slices
+    (0: run whole); `rot`: the K-loop stagger in passes."""
+    out = (ctypes.c_int * 5)()
+    _check(load().klm_gemm_stream_plan(M, N, Kbytes, cus, mode, rot, ws_bytes, out), f"klm_gemm_stream_plan({M},{N},{Kbytes})")
+    return dict(zip(("grid", "rounds", "rest", "split", "rot"), (int(x) for x in out)))
+
+
+#: K-loop stagger for dense operands whose row pitch the memory channels camp on: the workgroups of XCD x start their K loop
+#: x * CAMPING_ROT passes (of two K tiles, 256 bytes of a row) in; -1 = an eighth of the K extent per XCD
+CAMPING_ROT = -1
+#: what `variant=None` does on a camping pitch: 0 = nothing (set from the measurement in scripts/exp/gemm_units.py)
+AUTO_ROT = 0
+
+
+def _stream(dtype_code: int, a, b, out, M, N, Kbytes, pitch, store=0, mode=1, rot=None, what="gemm"):
+    lib = load()
+    ld = pitch or Kbytes
+    if rot is None:
+        rot = AUTO_ROT if (not pitch and camping_pitch(Kbytes)) else 0
+    if rot < 0:
+        rot = max(1, (Kbytes // 256) // 8)
+    ws = stream_workspace(a.device) if mode else None
+    with _on_device(a):
+        rc = lib.klm_gemm_stream(dtype_code, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kbytes, ld if pitch else 0, store, mode, rot,
+                                 ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream_of(a))
+    _check(rc, f"klm_gemm_stream({what},M={M},N={N},Kbytes={Kbytes},pitch={pitch},mode={mode},rot={rot})")
+    return out
 
 
 def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
 
     variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream in its persistent
-    form (8: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue) for whole
+    form (10: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue; a last,
+    partial round of tiles is cut into K slices where that pays -- `gemm_stream_plan` -- and the K loops are staggered on a
+    row pitch the memory channels camp on; 8: the same without either, 11 / 12: with one of them forced) for whole
     256 x 256 tiles and an even number of K tiles >= 4, else the 8-wave ring kernel (2, or 1 for an odd tile count), else
     the 128x128 one (0; also for shapes of at most 32 tiles of 256 x 256, which would leave most CUs idle). 4: the same stream, one workgroup per tile; 9: 8 with C stored past the caches (`sc1 nt`: +1.6 - 2.7 %
     when one 8192^3 GEMM repeats on the same operands, which then stay in the Infinity Cache; -0.8 % in the training step,
@@ -226,14 +290,19 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
         _require_cuda(out)
         if out.shape != (M, N) or out.dtype != torch.bfloat16:
             raise KlmOpsError("gemm_bf16: bad `out`")
+    if variant in (10, 11, 12, 13):
+        # the persistent stream with its plan: 10 the default (the partial round split into K slices where that pays, the K loops
+        # staggered on a camping pitch); 11: split wherever the shape allows, 12: stagger always, 13: neither (= 8)
+        return _stream(0, a, b, out, M, N, 2 * K, pitch, mode={10: 1, 11: 2, 12: 0, 13: 0}[variant],
+                       rot={10: None, 11: 0, 12: CAMPING_ROT, 13: 0}[variant], what="bf16")
     with _on_device(a):
         if pitch:
             # row-pitched operands (padded_operand): the hand-scheduled streams only
             if variant not in (4, 8, 9):
-                raise KlmOpsError(f"gemm_bf16: pitched operands need the hand-scheduled stream (variant 4 / 8 / 9), shape {M}x{N}x{K} gives {variant}")
-            rc = load().klm_gemm_bf16_pitched(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, {4: 0, 8: 1, 9: 2}[variant], _stream(a))
+                raise KlmOpsError(f"gemm_bf16: pitched operands need the hand-scheduled stream (variant 4 / 8 / 9 / 10), shape {M}x{N}x{K} gives {variant}")
+            rc = load().klm_gemm_bf16_pitched(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, {4: 0, 8: 1, 9: 2}[variant], _stream_of(a))
         else:
-            rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+            rc = load().klm_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream_of(a))
     _check(rc, f"klm_gemm_bf16(M={M},N={N},K={K},variant={variant},pitch={pitch})")
     return out
 
@@ -261,20 +330,23 @@ def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     M, K = a.shape
     N = b.shape[0]
     if variant is None:
-        variant = 4 if (K % 256 == 0 and K >= 512) else 1
+        variant = 7 if (K % 256 == 0 and K >= 512 and M % 256 == 0 and N % 256 == 0) else 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()
     if not hasattr(lib, "klm_gemm_fp8"):
         raise KlmOpsError("libklm_ops.so was built without the fp8 kernel")
     pitch = _pitch_bytes(a, b)
+    if variant in (7, 8):
+        # 7: the persistent stream with its plan (as bf16 variant 10); 8: the partial round split wherever the shape allows
+        return _stream(1, a, b, out, M, N, K, pitch, mode=1 if variant == 7 else 2, rot=None if variant == 7 else 0, what="fp8")
     with _on_device(a):
         if pitch:
             if variant not in (2, 4, 5):
                 raise KlmOpsError(f"gemm_fp8: pitched operands need the hand-scheduled stream (variant 2 / 4 / 5), K={K} gives {variant}")
-            rc = lib.klm_gemm_mx_pitched(1, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, {2: 0, 4: 1, 5: 2}[variant], _stream(a))
+            rc = lib.klm_gemm_mx_pitched(1, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, pitch, {2: 0, 4: 1, 5: 2}[variant], _stream_of(a))
         else:
-            rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream(a))
+            rc = lib.klm_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, variant, _stream_of(a))
     _check(rc, f"klm_gemm_fp8(M={M},N={N},K={K},variant={variant},pitch={pitch})")
     return out
 
@@ -309,20 +381,23 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     M, Kb = a.shape
     N = b.shape[0]
     if variant is None:
-        variant = 3 if (Kb % 256 == 0 and Kb >= 512) else 1
+        variant = 6 if (Kb % 256 == 0 and Kb >= 512 and M % 256 == 0 and N % 256 == 0) else 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()
     if not hasattr(lib, "klm_gemm_fp4"):
         raise KlmOpsError("libklm_ops.so was built without the fp4 kernel")
     pitch = _pitch_bytes(a, b)
+    if variant in (6, 7):
+        # 6: the persistent stream with its plan (as bf16 variant 10); 7: the partial round split wherever the shape allows
+        return _stream(2, a, b, out, M, N, Kb, pitch, mode=1 if variant == 6 else 2, rot=None if variant == 6 else 0, what="fp4")
     with _on_device(a):
         if pitch:
             if variant not in (2, 3, 4):
                 raise KlmOpsError(f"gemm_fp4: pitched operands need the hand-scheduled stream (variant 2 / 3 / 4), K={Kb * 2} gives {variant}")
-            rc = lib.klm_gemm_mx_pitched(2, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb, pitch, {2: 0, 3: 1, 4: 2}[variant], _stream(a))
+            rc = lib.klm_gemm_mx_pitched(2, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb, pitch, {2: 0, 3: 1, 4: 2}[variant], _stream_of(a))
         else:
-            rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, variant, _stream(a))
+            rc = lib.klm_gemm_fp4(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, Kb * 2, variant, _stream_of(a))
     _check(rc, f"klm_gemm_fp4(M={M},N={N},K={Kb * 2},variant={variant},pitch={pitch})")
     return out
 
@@ -335,7 +410,7 @@ def hbm_fill(t, pattern: int = 0xA5A5A5A5):
     """Write `pattern` (32-bit) over the whole tensor with streaming 16-byte stores."""
     _require_cuda(t)
     with _on_device(t):
-        _check(load().klm_hbm_fill(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, _stream(t)), "klm_hbm_fill")
+        _check(load().klm_hbm_fill(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, _stream_of(t)), "klm_hbm_fill")
     return t
 
 
@@ -344,7 +419,7 @@ def hbm_copy(dst, src):
     if _nbytes(dst) != _nbytes(src):
         raise KlmOpsError("hbm_copy: size mismatch")
     with _on_device(src):
-        _check(load().klm_hbm_copy(dst.data_ptr(), src.data_ptr(), _nbytes(src), _stream(src)), "klm_hbm_copy")
+        _check(load().klm_hbm_copy(dst.data_ptr(), src.data_ptr(), _nbytes(src), _stream_of(src)), "klm_hbm_copy")
     return dst
 
 
@@ -354,14 +429,14 @@ def hbm_copy_ex(dst, src, flags: int = 3, grid: int = 0):
     if _nbytes(dst) != _nbytes(src):
         raise KlmOpsError("hbm_copy_ex: size mismatch")
     with _on_device(src):
-        _check(load().klm_hbm_copy_ex(dst.data_ptr(), src.data_ptr(), _nbytes(src), flags, grid, _stream(src)), "klm_hbm_copy_ex")
+        _check(load().klm_hbm_copy_ex(dst.data_ptr(), src.data_ptr(), _nbytes(src), flags, grid, _stream_of(src)), "klm_hbm_copy_ex")
     return dst
 
 
 def hbm_fill_ex(t, pattern: int = 0xA5A5A5A5, flags: int = 2, grid: int = 0):
     _require_cuda(t)
     with _on_device(t):
-        _check(load().klm_hbm_fill_ex(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, flags, grid, _stream(t)), "klm_hbm_fill_ex")
+        _check(load().klm_hbm_fill_ex(t.data_ptr(), _nbytes(t), pattern & 0xFFFFFFFF, flags, grid, _stream_of(t)), "klm_hbm_fill_ex")
     return t
 
 
@@ -369,14 +444,14 @@ def hbm_read_ex(src, sink, flags: int = 1, grid: int = 0):
     """Tuning variant of hbm_read (see klm_ops.h)."""
     _require_cuda(src, sink)
     with _on_device(src):
-        _check(load().klm_hbm_read_ex(src.data_ptr(), _nbytes(src), sink.data_ptr(), flags, grid, _stream(src)), "klm_hbm_read_ex")
+        _check(load().klm_hbm_read_ex(src.data_ptr(), _nbytes(src), sink.data_ptr(), flags, grid, _stream_of(src)), "klm_hbm_read_ex")
     return sink
 
 
 def hbm_read(src, sink):
     _require_cuda(src, sink)
     with _on_device(src):
-        _check(load().klm_hbm_read(src.data_ptr(), _nbytes(src), sink.data_ptr(), _stream(src)), "klm_hbm_read")
+        _check(load().klm_hbm_read(src.data_ptr(), _nbytes(src), sink.data_ptr(), _stream_of(src)), "klm_hbm_read")
 
 
 def hbm_checksum(src) -> int:
@@ -385,7 +460,7 @@ def hbm_checksum(src) -> int:
     _require_cuda(src)
     acc = torch.zeros(1, dtype=torch.int64, device=src.device)
     with _on_device(src):
-        _check(load().klm_hbm_checksum(src.data_ptr(), _nbytes(src), acc.data_ptr(), _stream(src)),
+        _check(load().klm_hbm_checksum(src.data_ptr(), _nbytes(src), acc.data_ptr(), _stream_of(src)),
                "klm_hbm_checksum")
     return int(acc.item()) & 0xFFFFFFFFFFFFFFFF
 

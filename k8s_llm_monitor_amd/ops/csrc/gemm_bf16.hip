@@ -324,6 +324,53 @@ extern "C" int klm_gemm_persistent_grid(int grid) {
   return before;
 }
 
+// 1 when the A/B-record and diagnostic streams are compiled in (-DKLM_GEMM_DIAG: never the shipped library)
+extern "C" int klm_gemm_has_diag(void) {
+#if defined(KLM_GEMM_DIAG)
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+// The plan the persistent streams run an M x N problem with rows of `Kbytes` under: out = {grid, rounds, rest, split, rot}.
+// cus: workgroups available (0: the current device's CU count, or the tests' override). Pure arithmetic apart from that.
+extern "C" int klm_gemm_stream_plan(int M, int N, int Kbytes, int cus, int mode, int rot, size_t ws_bytes, int* out) {
+  if (!out) return KLM_ERR_ARG;
+  if (!klm_quad_asm_shape_ok(M, N, Kbytes)) return KLM_ERR_SHAPE;
+  if (cus <= 0) cus = klm_quad_p_cus();
+  if (cus <= 0) return KLM_ERR_HIP;
+  const KlmQuadPlan p = klm_quad_plan(M, N, Kbytes, cus, mode, rot, ws_bytes);
+  out[0] = p.grid, out[1] = p.rounds, out[2] = p.rest, out[3] = p.split, out[4] = p.rot;
+  return KLM_OK;
+}
+
+// The persistent hand-scheduled stream, every option: dtype 0 bf16 / 1 fp8 (e4m3) / 2 fp4 (e2m1 pairs); rows of A and B hold
+// `Kbytes` bytes of K and are `ld_bytes` apart (0: dense); store 1: C written with `sc1 nt`; mode 0: whole tiles only, 1: the
+// last partial round is cut into K slices where that pays (needs `ws`: rest * split * 256 KiB of scratch on the device, at most
+// CUs * 256 KiB), 2: wherever the shape allows (tests); rot > 0: every workgroup starts its K loop `rot` passes after its
+// neighbour's (dense operands on a row pitch the memory channels camp on).
+extern "C" int klm_gemm_stream(int dtype, const void* A, const void* B, void* C, int M, int N, int Kbytes, int ld_bytes, int store,
+                               int mode, int rot, void* ws, size_t ws_bytes, void* stream) {
+  if (!A || !B || !C) return KLM_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) return KLM_ERR_ALIGN;
+  if (dtype < 0 || dtype > 2 || store < 0 || store > 1 || mode < 0 || mode > 2 || rot < 0) return KLM_ERR_VARIANT;
+  if (!klm_quad_asm_shape_ok(M, N, Kbytes, ld_bytes)) return KLM_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (!klm_stream_on_current_device(s)) return KLM_ERR_ARG;
+  int e;
+  switch (dtype * 2 + store) {
+    case 0: e = klm_launch_quad_asm_p<0>(A, B, C, M, N, Kbytes, s, ld_bytes, mode, rot, ws, ws_bytes); break;
+    case 1: e = klm_launch_quad_asm_p<1>(A, B, C, M, N, Kbytes, s, ld_bytes, mode, rot, ws, ws_bytes); break;
+    case 2: e = klm_launch_quad_asm_p<30>(A, B, C, M, N, Kbytes, s, ld_bytes, mode, rot, ws, ws_bytes); break;
+    case 3: e = klm_launch_quad_asm_p<31>(A, B, C, M, N, Kbytes, s, ld_bytes, mode, rot, ws, ws_bytes); break;
+    case 4: e = klm_launch_quad_asm_p<20>(A, B, C, M, N, Kbytes, s, ld_bytes, mode, rot, ws, ws_bytes); break;
+    default: e = klm_launch_quad_asm_p<21>(A, B, C, M, N, Kbytes, s, ld_bytes, mode, rot, ws, ws_bytes); break;
+  }
+  if (e) return e;
+  return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+}
+
 // The hand-scheduled stream on operands whose rows are `ld_bytes` apart (>= 2 K, a multiple of 16; A and B alike).
 extern "C" int klm_gemm_bf16_pitched(const void* A, const void* B, void* C, int M, int N, int K, int ld_bytes, int persistent,
                                      void* stream) {
@@ -362,18 +409,24 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     // persistent, C stored with `sc1 nt` (streamed past the caches)
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
     if (int e = klm_launch_quad_asm_p<1>(A, B, C, M, N, K * 2, s)) return e;
-  } else if (variant == 8 || variant == 48 || variant == 49) {
+  } else if (variant == 8) {
     // the persistent form of stream 4: one workgroup per CU, the next output tile's operands fetched under the epilogue
-    // (48 / 49: diagnostic, without the stores / without the epilogue -- C is NOT written)
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
-    if (int e = variant == 8 ? klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s)
-              : variant == 48 ? klm_launch_quad_asm_p<10>(A, B, C, M, N, K * 2, s) : klm_launch_quad_asm_p<11>(A, B, C, M, N, K * 2, s)) return e;
-  } else if ((variant >= 4 && variant <= 7) || (variant >= 40 && variant <= 43)) {
-    // hand-scheduled streams (gemm_quad_asm.h): 4 the kernel; 5..7 earlier placements; 40..43 diagnostic, results meaningless
+    if (int e = klm_launch_quad_asm_p<0>(A, B, C, M, N, K * 2, s)) return e;
+  } else if (variant == 4) {
+    // the hand-scheduled stream (gemm_quad_asm.h), one workgroup per tile
+    if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
+    if (int e = klm_launch_quad_asm<0>(A, B, C, M, N, K * 2, s)) return e;
+#if defined(KLM_GEMM_DIAG)
+  } else if (variant == 48 || variant == 49) {
+    // diagnostic: stream 8 without the stores / without the epilogue -- C is NOT written
+    if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
+    if (int e = variant == 48 ? klm_launch_quad_asm_p<10>(A, B, C, M, N, K * 2, s) : klm_launch_quad_asm_p<11>(A, B, C, M, N, K * 2, s)) return e;
+  } else if ((variant >= 5 && variant <= 7) || (variant >= 40 && variant <= 43)) {
+    // 5..7 earlier placements of stream 4 (the A/B record); 40..43 diagnostic, results meaningless
     if (!klm_quad_asm_shape_ok(M, N, K * 2)) return KLM_ERR_SHAPE;
     int e = KLM_OK;
     switch (variant) {
-      case 4: e = klm_launch_quad_asm<0>(A, B, C, M, N, K * 2, s); break;
       case 5: e = klm_launch_quad_asm<1>(A, B, C, M, N, K * 2, s); break;
       case 6: e = klm_launch_quad_asm<2>(A, B, C, M, N, K * 2, s); break;
       case 7: e = klm_launch_quad_asm<3>(A, B, C, M, N, K * 2, s); break;
@@ -383,6 +436,7 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
       default: e = klm_launch_quad_asm<13>(A, B, C, M, N, K * 2, s); break;
     }
     if (e) return e;
+#endif
   } else if (variant == 1 || variant == 2) {
     if ((M & 255) || (N & 255) || (K & 63) || K < 128) return KLM_ERR_SHAPE;
     const int grid = (M >> 8) * (N >> 8);

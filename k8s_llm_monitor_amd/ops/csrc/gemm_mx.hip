@@ -184,7 +184,12 @@ static int check_mx(const void* A, const void* B, const void* C, int M, int N, i
 
 extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                             void* stream) {
-  if (variant >= 2 && variant <= 6) {
+#if defined(KLM_GEMM_DIAG)
+  const bool stream_variant = variant >= 2 && variant <= 6;
+#else
+  const bool stream_variant = variant == 2 || variant == 4 || variant == 5;      // 3 and 6 are A/B-record streams: diagnostic builds only
+#endif
+  if (stream_variant) {
     // the hand-scheduled 4-wave stream (gemm_quad_asm.h, generator: body_fp8); 3: another placement, for the A/B record;
     // 4: the persistent form (one workgroup per CU, generator: body_p)
     if (!A || !B || !C) return KLM_ERR_ARG;
@@ -192,10 +197,12 @@ extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N,
     if (!klm_quad_asm_shape_ok(M, N, K)) return KLM_ERR_SHAPE;
     if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
     if (int e = variant == 2   ? klm_launch_quad_asm<30>(A, B, C, M, N, K, (hipStream_t)stream)
-                : variant == 3 ? klm_launch_quad_asm<31>(A, B, C, M, N, K, (hipStream_t)stream)
                 : variant == 4 ? klm_launch_quad_asm_p<30>(A, B, C, M, N, K, (hipStream_t)stream)
-                : variant == 5 ? klm_launch_quad_asm_p<31>(A, B, C, M, N, K, (hipStream_t)stream)    // 5: 4 with C streamed (sc1 nt)
-                               : klm_launch_quad_asm_p<32>(A, B, C, M, N, K, (hipStream_t)stream)) return e;   // 6: 4 on the block-scaled MFMA with unit scales (what 4 used before: same bits, slower)
+#if defined(KLM_GEMM_DIAG)
+                : variant == 3 ? klm_launch_quad_asm<31>(A, B, C, M, N, K, (hipStream_t)stream)
+                : variant == 6 ? klm_launch_quad_asm_p<32>(A, B, C, M, N, K, (hipStream_t)stream)    // 6: 4 on the block-scaled MFMA with unit scales (what 4 used before: same bits, slower)
+#endif
+                               : klm_launch_quad_asm_p<31>(A, B, C, M, N, K, (hipStream_t)stream)) return e;   // 5: 4 with C streamed (sc1 nt)
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
   if (int e = check_mx(A, B, C, M, N, K, variant)) return e;
@@ -230,7 +237,12 @@ extern "C" int klm_gemm_mx_pitched(int kind, const void* A, const void* B, void*
 extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant,
                             void* stream) {
   if (K <= 0 || (K & 1)) return KLM_ERR_SHAPE;
-  if (variant >= 2 && variant <= 5) {
+#if defined(KLM_GEMM_DIAG)
+  const bool stream_variant = variant >= 2 && variant <= 5;
+#else
+  const bool stream_variant = variant >= 2 && variant <= 4;                      // 5 is an A/B-record stream: diagnostic builds only
+#endif
+  if (stream_variant) {
     // the hand-scheduled 4-wave stream (gemm_quad_asm.h): same fragments and K tile as bf16, the MX MFMA with unit scales;
     // 3: its persistent form; 4: 3 with C streamed (sc1 nt)
     if (!A || !B || !C) return KLM_ERR_ARG;
@@ -239,8 +251,10 @@ extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N,
     if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
     if (int e = variant == 2   ? klm_launch_quad_asm<20>(A, B, C, M, N, K >> 1, (hipStream_t)stream)
                 : variant == 3 ? klm_launch_quad_asm_p<20>(A, B, C, M, N, K >> 1, (hipStream_t)stream)
-                : variant == 4 ? klm_launch_quad_asm_p<21>(A, B, C, M, N, K >> 1, (hipStream_t)stream)
-                               : klm_launch_quad_asm_p<22>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;   // 5: 3 on the block-scaled MFMA with unit scales (same bits, slower)
+#if defined(KLM_GEMM_DIAG)
+                : variant == 5 ? klm_launch_quad_asm_p<22>(A, B, C, M, N, K >> 1, (hipStream_t)stream)   // 5: 3 on the block-scaled MFMA with unit scales (same bits, slower)
+#endif
+                               : klm_launch_quad_asm_p<21>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;   // 4: 3 with C streamed (sc1 nt)
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
   if (int e = check_mx(A, B, C, M, N, K >> 1, variant)) return e;

@@ -57,6 +57,14 @@ int klm_gemm_mx_pitched(int kind, const void* A, const void* B, void* C, int M, 
 // Persistent GEMM variants (bf16 variant 8, fp8 variant 4, fp4 variant 3): one workgroup per CU walks its output tiles.
 // Tests: set a fixed workgroup count (0 = one per CU; < 0 = only read); returns the previous setting.
 int klm_gemm_persistent_grid(int grid);
+int klm_gemm_has_diag(void);    // 1: built with -DKLM_GEMM_DIAG (A/B-record and diagnostic streams compiled in)
+
+// The persistent stream with every option (gemm_bf16.hip): dtype 0 bf16 / 1 fp8 / 2 fp4; mode 1 cuts the last partial round of
+// tiles into K slices (stream-K style; fp32 partial sums in `ws`, added up by a second kernel) where that pays, 2 wherever it
+// can; rot > 0 staggers the workgroups' K loops (dense operands on a camping row pitch). klm_gemm_stream_plan: the plan alone.
+int klm_gemm_stream(int dtype, const void* A, const void* B, void* C, int M, int N, int Kbytes, int ld_bytes, int store, int mode,
+                    int rot, void* ws, size_t ws_bytes, void* stream);
+int klm_gemm_stream_plan(int M, int N, int Kbytes, int cus, int mode, int rot, size_t ws_bytes, int* out5);
 
 // HBM helpers. `bytes` must be a multiple of 16 and pointers 16-byte aligned.
 int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream);   // write-only

@@ -14,7 +14,8 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from . import KlmOpsError, _check, _stream, load
+from . import KlmOpsError, _check, load
+from . import _stream_of as _stream
 from . import ref
 
 HEAD_DIM = ref.HEAD_DIM

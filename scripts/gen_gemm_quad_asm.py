@@ -259,54 +259,84 @@ def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# Persistent kernels: one workgroup per CU walks ITS output tiles (tile b, b + grid, ..: the same tile -> XCD / round map as
-# one workgroup per tile under in-order dispatch) and treats their K tiles as ONE stream. The LDS-DMA of the last pass of
-# an output tile fetches K tiles 0 and 1 of the NEXT output tile (the descriptors are switched just before that pass),
-# and its fragment reads load the next tile's first fragments, so the epilogue -- accumulators out, 32 MB of stores per
-# round on the chip -- runs with the next tile's operands already in LDS and registers instead of in front of a cold
+# Persistent kernels: one workgroup per CU walks ITS list of UNITS and treats their K tiles as ONE stream. A unit is a
+# K range of one output tile: a whole tile (tile b, b + grid, ..: the same tile -> XCD / round map as one workgroup per tile
+# under in-order dispatch), or -- for the last, partial round of a tile count that is no multiple of the CU count -- one K
+# slice of a tile, whose fp32 partial sums go to a workspace that a small kernel adds up afterwards (stream-K style: 2.25
+# rounds cost 2.25 rounds, not 3), or one of two segments of a tile whose K loop starts in the middle (row pitches the
+# memory channels camp on: neighbouring workgroups then read different K offsets at any one time).
+# The LDS-DMA of the last pass of a unit fetches K tiles 0 and 1 of the NEXT unit (the descriptors are switched just before
+# that pass), and its fragment reads load the next unit's first fragments, so the epilogue -- accumulators out, 32 MB of
+# stores per round on the chip -- runs with the next operands already in LDS and registers instead of in front of a cold
 # prologue whose loads queue behind those stores; workgroup launch, argument loads and set-up are paid once.
-#   table (LDS, written by the HIP part): per output tile {A rows lo, hi, B rows lo, hi, C lo, hi, -, -} (32 bytes)
+#   table (LDS, written by the HIP part): per unit {A rows lo, hi, B rows lo, hi, C lo, hi, passes, flags} (32 bytes)
+#   flags: bit F_ACC the unit adds to the accumulators as they are (it is not its tile's first unit); bit F_NOEPI no
+#   epilogue (the tile's sum continues in the next unit); bit F_PARTIAL the epilogue stores the fp32 accumulators to the
+#   workspace slot "C" points at (register-major: [wave][acc tile][lane][16 bytes], every store 1 KiB contiguous)
 #   v[TBL]      LDS address of the next table entry;  v[TBL+3 : TBL+10]  the entry just read
-#   s[96:97] next A, s[98:99] next B, s[76:77] next C (this wave's rows: + %[dab] / %[dab] / %[dc]; s100 up are reserved)
-#   s78 output tiles left (this one included), s80 num_records of the next tile's A / B descriptors: 0 when there is no
-#   next tile (those loads then fetch nothing)
+#   s[96:97] next A, s[98:99] next B, s[76:77] next C (this wave's rows: + %[dab] / %[dab] / %[dc] or %[dw]; s100 up are reserved)
+#   s78 units left (this one included), s79 the next unit's passes | flags << 16, s80 num_records of the next unit's A / B
+#   descriptors: 0 when there is no next unit (those loads then fetch nothing); s88 passes left, s89 flags of this unit
+F_ACC, F_NOEPI, F_PARTIAL = 0, 1, 2
+PARTIAL_WAVE_BYTES = 0x10000       # one wave's 128 x 128 fp32 accumulators
 TBL_BF16, TBL_FP8 = 177, 241
 
 
 def fetch_next(tbl):
     e = tbl + 3
-    return ["; ---- next output tile's bases from the table",
+    return ["; ---- next unit's bases, pass count and flags from the table",
             f"ds_read_b128 v[{e}:{e + 3}], v{tbl}", f"ds_read_b128 v[{e + 4}:{e + 7}], v{tbl} offset:16",
             f"v_add_u32 v{tbl}, 32, v{tbl}", "s_waitcnt lgkmcnt(0)"] + \
-           [f"v_readfirstlane_b32 s{r}, v{e + k}" for k, r in enumerate((96, 97, 98, 99, 76, 77))] + \
-           ["s_add_u32 s96, s96, %[dab]", "s_addc_u32 s97, s97, 0", "s_add_u32 s98, s98, %[dab]", "s_addc_u32 s99, s99, 0",
-            "s_add_u32 s76, s76, %[dc]", "s_addc_u32 s77, s77, 0"]
+           [f"v_readfirstlane_b32 s{r}, v{e + k}" for k, r in enumerate((96, 97, 98, 99, 76, 77, 79, 94))] + \
+           ["s_lshl_b32 s94, s94, 16", "s_or_b32 s79, s79, s94",
+            "s_add_u32 s96, s96, %[dab]", "s_addc_u32 s97, s97, 0", "s_add_u32 s98, s98, %[dab]", "s_addc_u32 s99, s99, 0",
+            # this wave's part of the destination: its rows and columns of C, or its 64 KiB of a workspace slot
+            f"s_bitcmp1_b32 s79, {16 + F_PARTIAL}", "s_cselect_b32 s94, %[dw], %[dc]",
+            "s_add_u32 s76, s76, s94", "s_addc_u32 s77, s77, 0"]
+
+
+# the unit whose bases sit in s[96:99] / s[76:77] / s79 becomes the current one (the A / B descriptors are switched by the
+# last pass of the unit before it, or by the set-up)
+ADOPT = ["s_mov_b32 s72, s76", "s_mov_b32 s73, s77", "s_and_b32 s88, s79, 0xffff", "s_lshr_b32 s89, s79, 16",
+         f"s_bitcmp1_b32 s89, {F_PARTIAL}", f"s_cselect_b32 s74, {PARTIAL_WAVE_BYTES:#x}, %[rc2]"]
 
 
 def setup_lines_p(RB, SCALE, tbl):
     o = ["; ==== setup (persistent)", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s67, %[ra3]", "s_mov_b32 s70, %[ra2]", "s_mov_b32 s71, %[ra3]",
-         "s_mov_b32 s74, %[rc2]", "s_mov_b32 s75, %[ra3]",
+         "s_mov_b32 s75, %[ra3]",
          "s_lshl_b32 s81, %[lda], 3", "s_lshl_b32 s82, %[lda], 4", "s_add_u32 s83, s82, s81", "s_lshl_b32 s84, %[lda], 5",
          "s_add_u32 s85, s84, s81", "s_add_u32 s86, s84, s82", "s_add_u32 s87, s86, s81",
-         "s_mov_b32 s88, %[passes]", "s_mov_b32 s78, %[ntl]",
+         "s_mov_b32 s78, %[ntl]",
          "s_mov_b32 s90, %[lw]", "s_add_u32 s91, s90, 0x8000", "s_add_u32 s92, s90, 0x10000", "s_add_u32 s93, s90, 0x18000",
          f"v_mov_b32 v{RB}, %[a0]", f"v_mov_b32 v{RB + 1}, %[a1]", f"v_mov_b32 v{RB + 2}, %[b0]", f"v_mov_b32 v{RB + 3}, %[b1]",
          f"v_add_u32 v{RB + 4}, 0x10000, v{RB}", f"v_add_u32 v{RB + 5}, 0x10000, v{RB + 1}",
          f"v_add_u32 v{RB + 6}, 0x10000, v{RB + 2}", f"v_add_u32 v{RB + 7}, 0x10000, v{RB + 3}",
          f"v_mov_b32 v{SCALE}, 0x7f7f7f7f", f"v_mov_b32 v{tbl}, %[tbl]"]
     o += fetch_next(tbl)
-    o += ["s_mov_b32 s64, s96", "s_mov_b32 s65, s97", "s_mov_b32 s68, s98", "s_mov_b32 s69, s99", "s_mov_b32 s72, s76", "s_mov_b32 s73, s77"]
+    o += ["s_mov_b32 s64, s96", "s_mov_b32 s65, s97", "s_mov_b32 s68, s98", "s_mov_b32 s69, s99"] + ADOPT
     o += next_or_none(tbl, "first")
     return o
 
 
 def next_or_none(tbl, tag):
-    """s78 = output tiles left including the current one: fetch the next one's bases, or make its loads empty."""
+    """s78 = units left including the current one: fetch the next one's bases, or make its loads empty."""
     return ["s_mov_b32 s80, %[ra2]", "s_cmp_lg_u32 s78, 1", f"s_cbranch_scc1 Lklm%=_fetch_{tag}", "s_mov_b32 s80, 0",
             f"s_branch Lklm%=_fetched_{tag}", f"Lklm%=_fetch_{tag}:"] + fetch_next(tbl) + [f"Lklm%=_fetched_{tag}:"]
 
 
-SWITCH = ["; ---- last pass of this output tile: its DMA fetches the next output tile's K tiles 0 and 1",
+def epilogue32_lines():
+    """A K slice's partial sums: the 256 fp32 accumulators of every lane straight from the AGPRs to this wave's 64 KiB of the
+    unit's workspace slot, register-major ([acc tile][lane][16 bytes]: each store instruction writes 1 KiB contiguous). The
+    kernel that adds the slices up knows the (tile, lane) -> (row, column) map (gemm_quad_asm.h, quad_partial_reduce)."""
+    o = ["; ==== fp32 partial epilogue", "s_nop 15", "s_nop 15", "s_mov_b32 s94, 0"]
+    for t in range(64):
+        o.append(f"buffer_store_dwordx4 a[{4 * t}:{4 * t + 3}], %[vw], s[72:75], s94 offen offset:{(t % 4) * 1024}")
+        if t % 4 == 3 and t != 63:
+            o.append("s_add_u32 s94, s94, 0x1000")
+    return o
+
+
+SWITCH = ["; ---- last pass of this unit: its DMA fetches the next unit's K tiles 0 and 1",
           "s_mov_b32 s64, s96", "s_mov_b32 s65, s97", "s_mov_b32 s66, s80", "s_mov_b32 s68, s98", "s_mov_b32 s69, s99", "s_mov_b32 s70, s80"]
 
 
@@ -343,7 +373,9 @@ def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
 
     for w in waves:
         # the first pass of an output tile starts its accumulators from the constant 0: nothing is ever cleared
+        # (a unit that continues its tile's sum, F_ACC, goes straight to the loop)
         o += [f"; ==== wave {w}, first pass of an output tile (s88 = passes left)", f"Lklm%=_w{w}:",
+              f"s_bitcmp1_b32 s89, {F_ACC}", f"s_cbranch_scc1 Lklm%=_l{w}",
               "s_cmp_lg_u32 s88, 1", f"s_cbranch_scc1 Lklm%=_f{w}"] + SWITCH + [f"Lklm%=_f{w}:"]
         o += one_pass(w, True)
         o += ["s_sub_u32 s88, s88, 1", "s_cmp_eq_u32 s88, 0", "s_cbranch_scc1 Lklm%=_epilogue"]
@@ -353,7 +385,8 @@ def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
         o += ["s_sub_u32 s88, s88, 1", "s_cmp_lg_u32 s88, 0", f"s_cbranch_scc1 Lklm%=_l{w}"]
         if w != waves[-1]:
             o += ["s_branch Lklm%=_epilogue"]
-    o += ["Lklm%=_epilogue:"]
+    o += ["Lklm%=_epilogue:", f"s_bitcmp1_b32 s89, {F_NOEPI}", "s_cbranch_scc1 Lklm%=_next",
+          f"s_bitcmp1_b32 s89, {F_PARTIAL}", "s_cbranch_scc1 Lklm%=_epi32"]
     # scratch = fragment set 1 (bf16 / fp4) / the odd K tiles' A set (fp8): dead after the last MFMA, while set 0 already
     # holds the next output tile's first fragments
     global STORE_CACHE
@@ -365,8 +398,9 @@ def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
     if "epilogue" in ablate:       # diagnostic: what the whole epilogue costs
         epi = []
     o += epi
-    o += ["; ---- next output tile", "s_sub_u32 s78, s78, 1", "s_cmp_eq_u32 s78, 0", "s_cbranch_scc1 Lklm%=_done",
-          "s_mov_b32 s72, s76", "s_mov_b32 s73, s77", "s_mov_b32 s66, %[ra2]", "s_mov_b32 s70, %[ra2]", "s_mov_b32 s88, %[passes]"]
+    o += ["s_branch Lklm%=_next", "Lklm%=_epi32:"] + epilogue32_lines()
+    o += ["; ---- next unit", "Lklm%=_next:", "s_sub_u32 s78, s78, 1", "s_cmp_eq_u32 s78, 0", "s_cbranch_scc1 Lklm%=_done",
+          "s_mov_b32 s66, %[ra2]", "s_mov_b32 s70, %[ra2]"] + ADOPT
     o += next_or_none(tbl, "loop")
     MX_SCALED = False
     o += ["s_branch Lklm%=_tile", "Lklm%=_done:",
@@ -504,28 +538,33 @@ def body_fp8(**kw):
     return o
 
 
-# macro suffix -> (schedule, ablations, dtype). The ablated streams keep a GEMM's timing, not its result.
-BODIES = {"": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEBAR": ("one_barrier", (), "bf16"),
-          "_PEROP": ("per_operand", (), "bf16"),
-          "_NODMA": ("spread", ("dma",), "bf16"), "_NOREAD": ("spread", ("read",), "bf16"), "_L2ONLY": ("spread", ("bump",), "bf16"),
-          "_MFMAONLY": ("spread", ("dma", "read", "barrier"), "bf16"),
-          "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"), "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8"),
-          # ("cache:sc0" / "cache:sc1" / "cache:nt" in the ablation tuple put cache-policy bits on the LDS-DMA; measured: sc0 / sc1 no
-          #  change, nt -10 %, profiles/r2_prof/dma_cache_bits.json -- the bodies are no longer generated)
-          "_P_NOSTORE": ("persistent", ("store",), "bf16"), "_P_NOEPI": ("persistent", ("epilogue",), "bf16"),
-          # _ST: C stored with `sc1 nt` (written through, not kept): for shapes whose operands just fit the 256 MB Infinity Cache
-          "_P_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "bf16"), "_P_FP4_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp4"),
-          "_P_FP8_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp8"),
-          "_P_FP4_SC": ("persistent", ("scaled",), "fp4"), "_P_FP8_SC": ("persistent", ("scaled",), "fp8"),
-          "_P": ("persistent", (), "bf16"), "_P_FP4": ("persistent", (), "fp4"), "_P_FP8": ("persistent", (), "fp8")}
+# macro suffix -> (schedule, ablations, dtype). SHIPPED: the bodies libklm_ops.so and klm_burner are built from. DIAGNOSTIC: earlier
+# placements kept for the A/B record and streams with parts of the loop removed (they keep a GEMM's timing, not its result);
+# generated only with --diag and compiled only under -DKLM_GEMM_DIAG (scripts/exp/build_exp.sh), never into the shipped library.
+SHIPPED = {"": ("stagger", (), "bf16"), "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"),
+           # _ST: C stored with `sc1 nt` (written through, not kept): for shapes whose operands just fit the 256 MB Infinity Cache
+           "_P_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "bf16"), "_P_FP4_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp4"),
+           "_P_FP8_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp8"),
+           "_P": ("persistent", (), "bf16"), "_P_FP4": ("persistent", (), "fp4"), "_P_FP8": ("persistent", (), "fp8")}
+DIAGNOSTIC = {"_SPREAD": ("spread", (), "bf16"), "_ONEBAR": ("one_barrier", (), "bf16"), "_PEROP": ("per_operand", (), "bf16"),
+              "_NODMA": ("spread", ("dma",), "bf16"), "_NOREAD": ("spread", ("read",), "bf16"), "_L2ONLY": ("spread", ("bump",), "bf16"),
+              "_MFMAONLY": ("spread", ("dma", "read", "barrier"), "bf16"),
+              "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8"),
+              # ("cache:sc0" / "cache:sc1" / "cache:nt" in the ablation tuple put cache-policy bits on the LDS-DMA; measured: sc0 / sc1 no
+              #  change, nt -10 %, profiles/r2_prof/dma_cache_bits.json -- the bodies are no longer generated)
+              "_P_NOSTORE": ("persistent", ("store",), "bf16"), "_P_NOEPI": ("persistent", ("epilogue",), "bf16"),
+              "_P_FP4_SC": ("persistent", ("scaled",), "fp4"), "_P_FP8_SC": ("persistent", ("scaled",), "fp8")}
+BODIES = dict(SHIPPED, **DIAGNOSTIC)
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                             "k8s_llm_monitor_amd", "ops", "csrc", "gemm_quad_asm.inc")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    diag = "--diag" in sys.argv[1:]
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "k8s_llm_monitor_amd", "ops", "csrc")
+    out = args[0] if args else os.path.join(here, "gemm_quad_asm_diag.inc" if diag else "gemm_quad_asm.inc")
     with open(out, "w") as f:
-        f.write("// GENERATED by scripts/gen_gemm_quad_asm.py -- do not edit; the schedules are documented there.\n")
-        for suffix, (sched, ablate, dtype) in BODIES.items():
+        f.write("// GENERATED by scripts/gen_gemm_quad_asm.py%s -- do not edit; the schedules are documented there.\n" % (" --diag" if diag else ""))
+        for suffix, (sched, ablate, dtype) in (DIAGNOSTIC if diag else SHIPPED).items():
             if sched == "persistent":
                 lines = body_p(dtype, ablate=ablate)
             else:
@@ -537,7 +576,8 @@ def main():
             n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
             print(f"KLM_QUAD_ASM_BODY{suffix}: {len(lines)} lines, {n_mfma} MFMAs, {sum(1 for l in lines if l.startswith('buffer_load'))} DMA, "
                   f"{sum(1 for l in lines if l.startswith('ds_read'))} reads, {sum(1 for l in lines if l.startswith('s_barrier'))} barriers")
-        f.write("#define KLM_QUAD_ASM_CLOBBERS " + ", ".join('"%s"' % c for c in clobbers()) + "\n")
+        if not diag:
+            f.write("#define KLM_QUAD_ASM_CLOBBERS " + ", ".join('"%s"' % c for c in clobbers()) + "\n")
 
 
 if __name__ == "__main__":

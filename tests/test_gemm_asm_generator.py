@@ -27,8 +27,12 @@ def test_checked_in_inc_is_the_generators_output(gen, tmp_path, capsys):
         sys.argv = argv
     have = open(os.path.join(ROOT, "k8s_llm_monitor_amd", "ops", "csrc", "gemm_quad_asm.inc")).read()
     assert out.read_text() == have, "run scripts/gen_gemm_quad_asm.py and rebuild"
-    for suffix in gen.BODIES:
+    for suffix in gen.SHIPPED:
         assert f"#define KLM_QUAD_ASM_BODY{suffix} " in have
+    # the A/B-record and diagnostic streams are not part of the shipped file: --diag writes them elsewhere
+    for suffix in gen.DIAGNOSTIC:
+        assert f"#define KLM_QUAD_ASM_BODY{suffix} " not in have
+    assert set(gen.SHIPPED) & set(gen.DIAGNOSTIC) == set() and len(have.splitlines()) < 30000
 
 
 def _kinds(lines):
@@ -108,7 +112,7 @@ def test_persistent_body_is_one_stream_over_output_tiles(gen, dtype):
     assert sum(l.split(", ")[3].startswith("0") for l in mf) == waves * 64
     assert not any(l.startswith("v_accvgpr_write") for l in L)                       # nothing is ever cleared
     # every pass may be the last of its output tile: the descriptor switch sits in front of each, skipped unless s88 == 1
-    sw = [i for i, l in enumerate(L) if l.startswith("; ---- last pass of this output tile")]
+    sw = [i for i, l in enumerate(L) if l.startswith("; ---- last pass of this unit")]
     assert len(sw) == 2 * waves
     for i in sw:
         assert L[i - 2] == "s_cmp_lg_u32 s88, 1" and L[i - 1].startswith("s_cbranch_scc1")
@@ -127,6 +131,22 @@ def test_persistent_body_is_one_stream_over_output_tiles(gen, dtype):
     for tag in ("first", "loop"):
         i = L.index(f"Lklm%=_fetch_{tag}:")
         assert L[i - 4: i] == ["s_cmp_lg_u32 s78, 1", f"s_cbranch_scc1 Lklm%=_fetch_{tag}", "s_mov_b32 s80, 0", f"s_branch Lklm%=_fetched_{tag}"]
+    # units (round 3): a unit that continues its tile's sum skips the constant-0 pass; the end of a unit takes no epilogue, the
+    # bf16 epilogue or the fp32 partial one by its flags; pass count and flags come from the table entry, never from an operand
+    for w in range(waves):
+        i = L.index(f"Lklm%=_w{w}:")
+        assert L[i + 1: i + 3] == [f"s_bitcmp1_b32 s89, {gen.F_ACC}", f"s_cbranch_scc1 Lklm%=_l{w}"]
+    i = L.index("Lklm%=_epilogue:")
+    assert L[i + 1: i + 5] == [f"s_bitcmp1_b32 s89, {gen.F_NOEPI}", "s_cbranch_scc1 Lklm%=_next", f"s_bitcmp1_b32 s89, {gen.F_PARTIAL}", "s_cbranch_scc1 Lklm%=_epi32"]
+    p32 = L[L.index("Lklm%=_epi32:"): L.index("Lklm%=_next:")]
+    st = [l for l in p32 if l.startswith("buffer_store_dwordx4")]
+    assert len(st) == 64 and [re.match(r"buffer_store_dwordx4 a\[(\d+):", l).group(1) for l in st] == [str(4 * t) for t in range(64)]
+    assert all("%[vw], s[72:75], s94 offen" in l for l in st) and sum(l == "s_add_u32 s94, s94, 0x1000" for l in p32) == 15    # 64 KiB per wave, 1 KiB per store
+    assert p32[2:4] == ["s_nop 15", "s_nop 15"]                                      # MFMA result -> VMEM read of the AGPR
+    assert not any("%[passes]" in l for l in L) and sum(l == "s_and_b32 s88, s79, 0xffff" for l in L) == 2
+    for adopt_at in (L.index("Lklm%=_next:"),):
+        tail = L[adopt_at:]
+        assert gen.ADOPT[0] in tail and tail.index(gen.ADOPT[0]) < tail.index("s_mov_b32 s80, %[ra2]")
     # no register above the architectural limits, none of the reserved scalar registers
     for l in L:
         for m in re.findall(r"\bs(\d+)\b", l):

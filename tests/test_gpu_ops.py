@@ -20,7 +20,7 @@ def env():
                                            (2, (256, 256, 256)), (2, (512, 768, 384)), (2, (2048, 1024, 4096)), (2, (256, 512, 4224)),
                                            (3, (256, 256, 256)), (3, (512, 768, 384)), (3, (1024, 512, 4096)),
                                            (4, (256, 256, 256)), (4, (512, 768, 384)), (4, (2048, 1024, 4096)), (4, (256, 512, 4352)),
-                                           (5, (512, 768, 384)), (6, (512, 768, 384)), (7, (512, 768, 384)), (5, (256, 256, 4352)),
+                                           (10, (512, 768, 384)), (11, (512, 768, 1024)), (12, (512, 768, 1024)), (13, (256, 256, 4352)), (11, (1280, 1536, 2048)),
                                            (8, (256, 256, 256)), (8, (512, 768, 384)), (8, (2048, 1024, 4096)), (8, (256, 512, 4352)),
                                            (9, (512, 768, 384)), (9, (2048, 1024, 4096)),
                                            (None, (1024, 1024, 1024)), (None, (384, 128, 64)), (None, (256, 256, 192))])
@@ -36,7 +36,7 @@ def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=1e-2 * K ** 0.5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13])
 def test_gemm_bf16_exact_on_small_integers_with_asymmetric_operands(env, variant):
     torch, ops, dev = env
     M, N, K = 512, 256, (192 if variant < 2 else 384)
@@ -54,7 +54,7 @@ def test_gemm_bf16_identity_picks_rows_not_columns(env):
     n = 256
     eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
     b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)      # asymmetric
-    for v in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+    for v in (0, 1, 2, 3, 4, 8, 10, 13):
         assert torch.equal(ops.gemm_bf16(eye, b, variant=v), b.t().contiguous())      # C = I @ B^T
 
 
@@ -63,7 +63,7 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
     a = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     b = torch.randn(1024, 2048, device=dev, dtype=torch.bfloat16)
     c0 = ops.gemm_bf16(a, b, variant=1).clone()
-    for v in (1, 2, 3, 4, 5, 6, 7, 8):                                # every pipeline gives the same bits, every run
+    for v in (1, 2, 3, 4, 8, 9, 13):                                  # every pipeline gives the same bits, every run
         for _ in range(20):
             assert torch.equal(ops.gemm_bf16(a, b, variant=v), c0)   # a ring-buffer race would show as a rare diff
 
@@ -81,9 +81,10 @@ def test_gemm_fp8_matches_fp32_reference(env, shape):
     # every pipeline sums an element's products in the same order: same bits
     assert torch.equal(c, ops.gemm_fp8(a, b, variant=0)) and torch.equal(c, ops.gemm_fp8(a, b, variant=1))
     if K % 256 == 0 and K >= 512:
-        assert torch.equal(c, ops.gemm_fp8(a, b, variant=2)) and torch.equal(c, ops.gemm_fp8(a, b, variant=3))
+        assert torch.equal(c, ops.gemm_fp8(a, b, variant=2)) and torch.equal(c, ops.gemm_fp8(a, b, variant=7))
         assert torch.equal(c, ops.gemm_fp8(a, b, variant=4)) and torch.equal(c, ops.gemm_fp8(a, b, variant=5))
-        assert torch.equal(c, ops.gemm_fp8(a, b, variant=6))       # the streams use the plain f8f6f4 MFMA, 6 and the ring kernels the block-scaled one
+        if ops.gemm_has_diag():                                    # 3 / 6: A/B-record streams, in diagnostic builds only (6 and the ring kernels use the block-scaled MFMA)
+            assert torch.equal(c, ops.gemm_fp8(a, b, variant=3)) and torch.equal(c, ops.gemm_fp8(a, b, variant=6))
 
 
 def test_gemm_fp8_exact_on_small_integers(env):
@@ -113,7 +114,9 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     assert torch.equal(c, ops.gemm_fp4(a, b, variant=0)) and torch.equal(c, ops.gemm_fp4(a, b, variant=1))
     if (K // 2) % 256 == 0 and K // 2 >= 512:
         assert torch.equal(c, ops.gemm_fp4(a, b, variant=2)) and torch.equal(c, ops.gemm_fp4(a, b, variant=3))
-        assert torch.equal(c, ops.gemm_fp4(a, b, variant=4)) and torch.equal(c, ops.gemm_fp4(a, b, variant=5))
+        assert torch.equal(c, ops.gemm_fp4(a, b, variant=4)) and torch.equal(c, ops.gemm_fp4(a, b, variant=6))
+        if ops.gemm_has_diag():
+            assert torch.equal(c, ops.gemm_fp4(a, b, variant=5))
     ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
     assert torch.equal(c, ref.float().to(torch.bfloat16))
     if hasattr(torch, "float4_e2m1fn_x2"):
@@ -161,17 +164,22 @@ def test_gemm_streams_take_row_pitched_operands(env, pad_bytes):
         return p
 
     want = ops.gemm_bf16(a, b, variant=4)
-    for v in (4, 8, 9, None):
+    for v in (4, 8, 9, 13):
         assert torch.equal(ops.gemm_bf16(padded(a), padded(b), variant=v), want)
+    # the default may cut these six tiles into K slices (another summation order): same bits as on dense operands, close to fp32
+    assert torch.equal(ops.gemm_bf16(padded(a), padded(b)), ops.gemm_bf16(a, b, variant=10))
+    assert torch.equal(ops.gemm_bf16(padded(a), padded(b), variant=11), ops.gemm_bf16(a, b, variant=11))
+    torch.testing.assert_close(ops.gemm_bf16(padded(a), padded(b)).float(), a.float() @ b.float().t(), rtol=1.6e-2, atol=0.3)
     a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
     want8 = ops.gemm_fp8(a8, b8, variant=2)
-    for v in (2, 4, None):
+    for v in (2, 4):
         assert torch.equal(ops.gemm_fp8(padded(a8), padded(b8), variant=v), want8)
+    assert torch.equal(ops.gemm_fp8(padded(a8), padded(b8)), ops.gemm_fp8(a8, b8, variant=7))
     a4 = torch.randint(0, 256, (M, K), device=dev, generator=g, dtype=torch.uint8)
     b4 = torch.randint(0, 256, (N, K), device=dev, generator=g, dtype=torch.uint8)
     want4 = ops.gemm_fp4(a4, b4, variant=2)
     for v in (2, 3, None):
-        assert torch.equal(ops.gemm_fp4(padded(a4), padded(b4), variant=v), want4)
+        assert torch.equal(ops.gemm_fp4(padded(a4), padded(b4), variant=v), want4)              # fp4 sums are exact: any order gives the same bits
     # what cannot take a pitch says so instead of reading the wrong rows
     with pytest.raises(ops.KlmOpsError, match="pitched"):
         ops.gemm_bf16(padded(a), padded(b), variant=2)
@@ -208,7 +216,48 @@ def test_default_dispatch_over_random_shapes(env):
             pa, pb = ops.padded_operand(M, K, torch.bfloat16, dev, pad_bytes=256), ops.padded_operand(N, K, torch.bfloat16, dev, pad_bytes=256)
             pa.copy_(a); pb.copy_(b)
             if not pa.is_contiguous():
-                assert torch.equal(ops.gemm_bf16(pa, pb), ops.gemm_bf16(a, b, variant=4)), (M, N, K)
+                plan = ops.gemm_stream_plan(M, N, 2 * K, mode=1)
+                if plan["split"] <= 1:             # whole tiles only: the same bits as the one-workgroup-per-tile stream
+                    assert torch.equal(ops.gemm_bf16(pa, pb), ops.gemm_bf16(a, b, variant=4)), (M, N, K)
+                else:                              # K slices: another summation order
+                    torch.testing.assert_close(ops.gemm_bf16(pa, pb).float(), a.float() @ b.float().t(), rtol=1.6e-2, atol=6e-3 * K ** 0.5)
+
+
+@pytest.mark.parametrize("grid,shape", [(4, (768, 768, 1024)), (4, (512, 768, 512)), (16, (1280, 1024, 2048)), (6, (1024, 1280, 3072)), (0, (1536, 1536, 4096))])
+def test_partial_round_split_into_k_slices_and_staggered_k_loops(env, grid, shape):
+    """The unit-based persistent stream (gemm_quad_asm.h): with `grid` workgroups the tile count is no multiple of the grid, so
+    the last round is cut into K slices whose fp32 partial sums a second kernel adds up (variants 11 / fp8 8 / fp4 7 force it);
+    variant 12 starts the K loop of XCD x's workgroups x * P / 8 passes in. Small-integer operands: every form must give the
+    exact product, whatever its summation order; on random operands they stay within bf16 rounding of fp32."""
+    torch, ops, dev = env
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(M + K)
+    a = torch.randint(-3, 4, (M, K), device=dev, generator=g).to(torch.bfloat16)
+    b = torch.randint(-3, 4, (N, K), device=dev, generator=g).to(torch.bfloat16)
+    want = (a.float() @ b.float().t()).to(torch.bfloat16)
+    a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+    a4 = torch.randint(0, 256, (M, K), device=dev, generator=g, dtype=torch.uint8)
+    b4 = torch.randint(0, 256, (N, K), device=dev, generator=g, dtype=torch.uint8)
+    want4 = (ops.fp4_decode(a4).double() @ ops.fp4_decode(b4).double().t()).float().to(torch.bfloat16)
+    x = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    y = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    before = ops.gemm_persistent_grid(grid)
+    try:
+        plan = ops.gemm_stream_plan(M, N, 2 * K, mode=2)
+        assert plan["rest"] > 0 and plan["split"] >= 2, plan          # the shapes are chosen so that there IS a partial round to split
+        for _ in range(2):
+            for v in (10, 11, 12, 13):
+                c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+                assert torch.equal(ops.gemm_bf16(a, b, out=c, variant=v), want), v
+            assert torch.equal(ops.gemm_fp8(a8, b8, variant=8), want) and torch.equal(ops.gemm_fp8(a8, b8, variant=7), want)
+            assert torch.equal(ops.gemm_fp4(a4, b4, variant=7), want4) and torch.equal(ops.gemm_fp4(a4, b4, variant=6), want4)
+        ref = x.float() @ y.float().t()
+        for v in (11, 12):
+            torch.testing.assert_close(ops.gemm_bf16(x, y, variant=v).float(), ref, rtol=1.6e-2, atol=6e-3 * K ** 0.5)
+        assert torch.equal(ops.gemm_bf16(x, y, variant=13), ops.gemm_bf16(x, y, variant=4))      # no slices, no stagger: the plain stream's bits
+        assert torch.equal(ops.gemm_bf16(x, y, variant=11), ops.gemm_bf16(x, y, variant=11))     # and the split is deterministic
+    finally:
+        ops.gemm_persistent_grid(before)
 
 
 def test_ops_follow_the_tensors_device_not_the_current_one(env):

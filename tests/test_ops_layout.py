@@ -87,3 +87,31 @@ def test_shipped_library_carries_the_tree_hash_and_the_hbm_launch_plan():
     n, first, last = ops.hbm_launch_plan(200 * GIB)
     assert n == 4 and first == 16777215 and (n - 1) * first + last == 200 * GIB // 4096
     assert first * 256 <= 0xFFFFFFFF < (first + 1) * 256
+
+
+def test_stream_plan_splits_the_partial_round_only_where_it_pays():
+    """The persistent streams' plan (klm_quad_plan): R full rounds of whole tiles, then the r remaining tiles, cut into S K
+    slices when the time a split saves exceeds its partial-sum traffic (6144^3 on 256 CUs: 2.25 rounds instead of 3)."""
+    from k8s_llm_monitor_amd import build, ops
+    if build.hipcc() is None:
+        pytest.skip("hipcc not installed")
+    build.build_all(only=["klm_ops"], verbose=False)
+    plan = lambda M, N, K, **kw: ops.gemm_stream_plan(M, N, 2 * K, cus=256, **kw)
+    assert plan(8192, 8192, 8192) == {"grid": 256, "rounds": 4, "rest": 0, "split": 0, "rot": 0}
+    assert plan(6144, 6144, 6144) == {"grid": 256, "rounds": 2, "rest": 64, "split": 4, "rot": 0}
+    assert plan(6144, 6144, 1536)["split"] == 0 and plan(6144, 6144, 1536, mode=2)["split"] == 4       # K too short to pay for the partial sums
+    assert plan(2048, 2048, 2048) == {"grid": 64, "rounds": 0, "rest": 64, "split": 0, "rot": 0}       # 64 MB of partial sums cost more than they save
+    assert plan(2048, 2048, 2048, mode=2) == {"grid": 256, "rounds": 0, "rest": 64, "split": 4, "rot": 0}
+    assert plan(4096, 6144, 4096)["split"] == 2 and plan(4096, 6144, 4096, mode=0)["split"] == 0
+    assert plan(6144, 6144, 6144, ws_bytes=64 * 2 * ops.SLOT_BYTES)["split"] == 2 and plan(6144, 6144, 6144, ws_bytes=0)["split"] == 0   # bounded by the scratch
+    assert plan(5120, 5120, 5120)["split"] == 0                                                        # 144 left of 256: nothing to split into
+    assert plan(8192, 8192, 8192, mode=0, rot=16)["rot"] == 16 and plan(8192, 8192, 8192, mode=0, rot=64)["rot"] == 1
+    # every slice gets at least two passes, at most 8 slices, and the slices' passes add up (the kernel's arithmetic, mirrored)
+    for M, N, K in ((256, 256, 512), (256, 512, 1024), (768, 768, 1024), (1536, 1536, 12288)):
+        p = plan(M, N, K, mode=2)
+        P = 2 * K // 256
+        if p["split"]:
+            S = p["split"]
+            assert 2 <= S <= 8 and P // S >= 2
+            assert sum(P // S + (1 if s < P % S else 0) for s in range(S)) == P
+    assert ops.pick_bf16_variant(8192, 8192, 8192) == 10 and ops.pick_bf16_variant(1024, 1024, 1024) == 0 and ops.pick_bf16_variant(3072, 3072, 192) == 1

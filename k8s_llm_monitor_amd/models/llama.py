@@ -149,6 +149,7 @@ class PrefillMeta:
 
 class LlamaModel:
     WIDE_ROWS = 256      # largest row count an 8B-class model sends to the K-split tiled GEMM (see lib_projections)
+    OWN_GEMM_MIN_ROWS = 2048   # rows from which `_stack`'s projections run on ops.gemm_bf16 (token rows padded to 256)
 
     """`tp`: a parallel.tp group. With more than one rank this instance holds ONE shard (Megatron layout: q/k/v
     heads, gate/up rows and vocabulary rows split by rank; wo and w_down split along their input, their partial
@@ -188,6 +189,10 @@ class LlamaModel:
         self.wide_from: Optional[int] = None                       # rows from which the tiled GEMM also replaces the mid-batch kernel
         self.lib_proj: Optional[frozenset] = None                 # overrides lib_projections() (benchmarks)
         self.wide = True                                           # 129 - 256 rows on the K-split tiled GEMM (else hipBLASLt)
+        # the library path's projections (`_stack`: prefill, batches beyond 256 rows) on this repo's persistent bf16 stream
+        # from OWN_GEMM_MIN_ROWS rows on (below, a few dozen 256 x 256 tiles leave most CUs idle: hipBLASLt, labelled)
+        self.own_gemm = True
+        self._pad: Dict[tuple, torch.Tensor] = {}                  # token-dimension padding scratch, per (rows, K)
         self.fused_rope = True                                     # skinny decode path: RoPE + cache write inside the attention kernel
         self.lm_head8: Optional[torch.Tensor] = None
         self.lm_head_s: Optional[torch.Tensor] = None
@@ -212,10 +217,45 @@ class LlamaModel:
         self.fp8_decode = True
         return self
 
-    def prefill_gemm_backend(self) -> str:
-        """Which GEMMs carry the library path's projections (`_stack`: prefill, decode beyond 256 rows), for bench labels."""
+    def prefill_gemm_backend(self, rows: int = 4096) -> str:
+        """Which GEMMs carry the library path's projections (`_stack`: prefill, decode beyond 256 rows) at `rows` rows, for
+        bench labels."""
+        c = self.lcfg
+        own = [n for n, (N, K) in (("wqkv", (c.qkv_dim, c.hidden)), ("wo", (c.hidden, c.q_dim)), ("w_gate_up", (2 * c.ffn, c.hidden)),
+                                   ("w_down", (c.hidden, c.ffn))) if self._own(rows, N, K)]
+        if len(own) == 4:
+            return ("klm persistent bf16 MFMA stream (ops.gemm_bf16, token rows padded to 256) for wqkv / wo / w_gate_up / w_down; "
+                    "the lm_head on the prompts' last rows on the skinny weight-streaming kernel (up to 16 rows; hipBLASLt beyond)")
+        if own:
+            return f"klm persistent bf16 MFMA stream for {' / '.join(own)}; hipBLASLt (torch.matmul) for the rest"
         return ("hipBLASLt (torch.matmul): NOT a hand-written-kernel figure; only attention, norms, rope and the KV write are "
                 "this repo's kernels in prefill")
+
+    def _own(self, rows: int, N: int, K: int) -> bool:
+        return bool(self.own_gemm and self.device.type == "cuda" and self.dtype == torch.bfloat16 and rows >= self.OWN_GEMM_MIN_ROWS
+                    and N % 256 == 0 and K % 128 == 0 and K >= 256)
+
+    def _proj(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """``x[T, K] @ w[N, K]^T`` for the library path. From OWN_GEMM_MIN_ROWS rows on, and when N and K fit its tiles (every
+        Llama-3 projection does: 6144 / 4096 / 28672 / 14336), on this repo's persistent MFMA stream: the token dimension is
+        padded to whole 256-row tiles in a persistent scratch buffer (the extra rows hold stale values; their outputs are cut
+        off), a last partial round of tiles is cut into K slices (ops.gemm_stream_plan). Else hipBLASLt through torch.matmul,
+        and `prefill_gemm_backend` says so."""
+        T, K = x.shape
+        N = w.shape[0]
+        if not self._own(T, N, K):
+            return torch.matmul(x, w.t())
+        from .. import ops
+        Mp = (T + 255) // 256 * 256
+        if Mp != T or not x.is_contiguous():
+            buf = self._pad.get((Mp, K))
+            if buf is None:
+                buf = self._pad[(Mp, K)] = torch.zeros((Mp, K), dtype=x.dtype, device=x.device)
+            buf[:T].copy_(x)
+            x = buf
+        out = torch.empty((Mp, N), dtype=x.dtype, device=x.device)
+        ops.gemm_bf16(x, w, out=out)
+        return out[:T]
 
     def weight_bytes(self) -> int:
         """bf16 bytes of the model (what a decode step streams without fp8 decode weights)."""
@@ -250,13 +290,13 @@ class LlamaModel:
                 x = llm.rmsnorm(h, g, cfg.eps)
             else:
                 x = llm.rmsnorm(h, g, cfg.eps, residual=residual)
-            qkv = torch.matmul(x, L["wqkv"].t())
+            qkv = self._proj(x, L["wqkv"])
             llm.rope_cache(qkv, self.cos_sin, positions, slots, cache.k[li], cache.v[li], cfg.n_q, cfg.n_kv)
             a = attend(qkv, cache.k[li], cache.v[li])
-            h = tp.all_reduce(torch.matmul(a, L["wo"].t()))
+            h = tp.all_reduce(self._proj(a, L["wo"]))
             x = llm.rmsnorm(h, g, cfg.eps, residual=residual)
-            act = llm.silu_mul(torch.matmul(x, L["w_gate_up"].t()))
-            h = tp.all_reduce(torch.matmul(act, L["w_down"].t()))
+            act = llm.silu_mul(self._proj(x, L["w_gate_up"]))
+            h = tp.all_reduce(self._proj(act, L["w_down"]))
         return llm.rmsnorm(h, g, cfg.eps, residual=residual)
 
     def _stack_skinny(self, tokens, positions, slots, cache: KVCache, attend, rope: bool = True) -> torch.Tensor:
@@ -470,7 +510,16 @@ class LlamaModel:
             return o
 
         x = self._trunk(tokens, positions, slots, cache, attend)
-        return self._sample(torch.matmul(x[meta.last_rows], self.lm_head.t()), logits)
+        return self._sample(self._head(x[meta.last_rows]), logits)
+
+    def _head(self, x: torch.Tensor) -> torch.Tensor:
+        """The lm_head on already-normed rows (prefill: the prompts' last rows). Up to 16 rows: one pass of the skinny
+        weight-streaming kernel over the bf16 head (the decode path's kernel, without its fused norm); more rows: `_proj`."""
+        c = self.lcfg
+        if (self.own_gemm and x.is_cuda and x.dtype == torch.bfloat16 and 0 < x.shape[0] <= llm.SKINNY_MAX_ROWS
+                and c.hidden % 128 == 0 and c.vocab % 16 == 0):
+            return llm.skinny_linear(x.contiguous(), self.lm_head)
+        return self._proj(x, self.lm_head)
 
     def load_shard_from(self, full: "LlamaModel") -> "LlamaModel":
         """Cut this rank's shard out of an unsharded instance (tests: the sharded model must compute what the

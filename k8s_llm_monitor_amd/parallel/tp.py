@@ -36,6 +36,9 @@ class SingleGroup:
     def gather_objects(self, obj: Any) -> List[Any]:
         return [obj]
 
+    def gather_ints(self, values) -> List[List[int]]:
+        return [[int(v) for v in values]]
+
     def barrier(self) -> None:
         pass
 
@@ -173,6 +176,16 @@ class TPGroup:
         out: List[Any] = [None] * self.world
         self.dist.all_gather_object(out, obj, group=self.ctrl)
         return out
+
+    def gather_ints(self, values) -> List[List[int]]:
+        """Every rank's small vector of integers on every rank, in rank order: ONE gloo all-gather of a fixed-size int64
+        tensor, nothing pickled (the per-step control message of the serving engine; `gather_objects` costs a pickle and two
+        collectives per call)."""
+        import torch
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.ctrl)
+        return [o.tolist() for o in out]
 
     def barrier(self) -> None:
         self.dist.barrier(group=self.ctrl)

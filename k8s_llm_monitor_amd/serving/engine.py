@@ -246,21 +246,26 @@ class Engine:
         Returns True when the engine is to stop."""
         if self.tp.world == 1:
             return stop
-        # One all-gather per step: rank 0's control message, and from EVERY rank whether its last step failed and a
-        # digest of its scheduler state. Scheduling is a deterministic function of that state, so equal digests mean
-        # equal launches; a rank that failed (out of memory, a bad launch, its own tp.check()) or drifted is seen by
-        # all ranks here, BEFORE the next collective is launched, and all of them start clean together.
+        # One small all-gather per step, nothing pickled: from EVERY rank whether its last step failed and a 63-bit hash of
+        # its scheduler state, from rank 0 also its wish to stop and how many new requests it holds. Scheduling is a
+        # deterministic function of that state, so equal hashes mean equal launches; a rank that failed (out of memory, a
+        # bad launch, its own tp.check()) or drifted is seen by all ranks here, BEFORE the next collective is launched, and
+        # all of them start clean together. Only a step that brings new requests pays for a second collective (their
+        # prompts, as objects from rank 0). Before: an all_gather_object of the whole digest -- a pickle of one tuple per
+        # running request and two gloo collectives -- on the critical path of every decode step (ADVICE r2).
         with self._lock:
-            digest = (len(self.waiting), tuple(r.rid for r in self.prefilling), tuple((r.rid, len(r.out)) for r in self.running),
-                      self.alloc.free, self.alloc.total)
+            digest = hash((len(self.waiting), tuple(r.rid for r in self.prefilling), tuple((r.rid, len(r.out)) for r in self.running),
+                           self.alloc.free, self.alloc.total)) & 0x7FFFFFFFFFFFFFFF
         failed, self._tp_reset = self._tp_reset, False
-        ctl = None
+        new: List[Request] = []
         if self.tp.rank == 0:
             with self._lock:
                 new, self._inbox = self._inbox, []
-            ctl = (bool(stop), [(r.rid, r.prompt, r.max_tokens) for r in new])
-        msgs = self.tp.gather_objects((failed, digest, ctl))
-        stop_all, new_specs = msgs[0][2]
+        msgs = self.tp.gather_ints((int(bool(failed)), digest, int(bool(stop)), len(new)))
+        stop_all, n_new = bool(msgs[0][2]), int(msgs[0][3])
+        new_specs = []
+        if n_new:
+            new_specs = self.tp.broadcast_object([(r.rid, r.prompt, r.max_tokens) for r in new] if self.tp.rank == 0 else None)
         bad = [i for i, m in enumerate(msgs) if m[0]]
         drift = [i for i, m in enumerate(msgs) if m[1] != msgs[0][1]]
         if bad or drift:

@@ -433,7 +433,7 @@ def llm_serving_rates(torch, dev) -> Dict[str, Any]:
             "decode": [{"batch": int(r["batch"]), "ms_per_step": round(r["ms"], 3),
                         "tokens_per_s": round(r["tokens_per_s"], 1), "TBps": round(r["TBps"], 2)} for r in dec],
             "prefill": {"n_seqs": 4, "prompt_len": 1024, "tokens_per_s": round(pre["tokens_per_s"], 1),
-                        "TFLOPs": round(pre["TFLOPs"], 1), "gemm_backend": eng.model.prefill_gemm_backend()},
+                        "TFLOPs": round(pre["TFLOPs"], 1), "gemm_backend": eng.model.prefill_gemm_backend(4 * 1024)},
             "decode_gemm_backend": "hand-written skinny / mid-batch / K-split tiled kernels up to 256 rows "
                                    "(gate_up, and wo above 208 rows, on hipBLASLt from 129 rows)"}
         # the same decode with W8A16 weight copies (labelled: not the bf16 figure above)

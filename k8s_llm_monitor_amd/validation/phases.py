@@ -1013,8 +1013,7 @@ def llm_activity(torch, dev, src, smi_idx: int, seconds: float = 2.5, model: str
                  {"tokens_per_s": r["tokens_per_s"], "TBps": r["TBps"]})
         p = sb.prefill_ms(eng, 4, 1024, iters=1)
         hold("prefill 4 x 1024", lambda: sb.prefill_ms(eng, 4, 1024, iters=1, warmup=0),
-             {"tokens_per_s": p["tokens_per_s"], "TFLOPs": p["TFLOPs"],
-              "gemm_backend": "hipBLASLt (torch.matmul), not this repo's GEMM kernels"})
+             {"tokens_per_s": p["tokens_per_s"], "TFLOPs": p["TFLOPs"], "gemm_backend": eng.model.prefill_gemm_backend(4 * 1024)})
     finally:
         del eng
         import gc

@@ -86,14 +86,22 @@ def test_ranks_with_unequal_kv_space_agree_on_the_smallest_and_stay_in_step():
 
 
 class _ScriptedGroup:
-    """Stands in for a TPGroup in `_tp_sync`: this rank's message goes in, the scripted messages of all ranks come out."""
+    """Stands in for a TPGroup in `_tp_sync`: this rank's four integers (failed, state hash, stop, new requests) go in, the
+    scripted rows of all ranks come out; rank 0's request specs travel in a second message only when it announces any."""
 
-    def __init__(self, rank, script):
-        self.rank, self.world, self.script, self.sent = rank, 2, script, []
+    def __init__(self, rank, script, specs=None):
+        self.rank, self.world, self.script, self.sent, self.specs, self.broadcasts = rank, 2, script, [], specs, 0
+
+    def gather_ints(self, values):
+        self.sent.append(list(values))
+        return [list(r) for r in self.script(list(values))]
+
+    def broadcast_object(self, obj=None):
+        self.broadcasts += 1
+        return obj if self.rank == 0 else self.specs
 
     def gather_objects(self, obj):
-        self.sent.append(obj)
-        return self.script(obj)
+        raise AssertionError("the per-step message is four integers: nothing is pickled (ADVICE r2)")
 
     def resync(self):
         self.resyncs = getattr(self, "resyncs", 0) + 1
@@ -109,35 +117,47 @@ def test_tp_sync_resets_every_rank_when_any_rank_failed_or_drifted():
     from k8s_llm_monitor_amd.serving.engine import Request
     # a follower: rank 0 reports two new requests, nobody failed
     e = _tiny_engine()
-    e.tp = _ScriptedGroup(1, lambda mine: [(False, mine[1], (False, [(0, [1, 2, 3], 4), (1, [4, 5], 2)])), mine])
-    assert e._tp_sync() is False and [r.rid for r in e.waiting] == [0, 1] and e.tp_resets == 0
-    assert e.tp.sent[0][0] is False and e.tp.sent[0][2] is None                  # followers send no control part
+    e.tp = _ScriptedGroup(1, lambda mine: [[0, mine[1], 0, 2], mine], specs=[(0, [1, 2, 3], 4), (1, [4, 5], 2)])
+    assert e._tp_sync() is False and [r.rid for r in e.waiting] == [0, 1] and e.tp_resets == 0 and e.tp.broadcasts == 1
+    assert e.tp.sent[0][0] == 0 and e.tp.sent[0][2:] == [0, 0] and 0 <= e.tp.sent[0][1] < 2 ** 63      # followers send no control part
+    # a step without new requests is ONE small collective: no second message
+    e.tp = _ScriptedGroup(1, lambda mine: [[0, mine[1], 0, 0], mine])
+    assert e._tp_sync() is False and e.tp.broadcasts == 0 and len(e.tp.sent) == 1
     # the follower failed its last step: it says so, and drops what it holds like everyone else
+    e = _tiny_engine()
     e._tp_reset = True
-    e.tp = _ScriptedGroup(1, lambda mine: [(False, mine[1], (False, [(2, [7], 1)])), mine])
+    e.tp = _ScriptedGroup(1, lambda mine: [[0, mine[1], 0, 1], mine], specs=[(2, [7], 1)])
     e._tp_sync()
-    assert e.tp.sent[0][0] is True and [r.rid for r in e.waiting] == [2] and e.tp_resets == 1 and e._tp_reset is False
+    assert e.tp.sent[0][0] == 1 and [r.rid for r in e.waiting] == [2] and e.tp_resets == 1 and e._tp_reset is False
     # rank 0 hears that rank 1 failed: its requests in flight and the just-submitted one all end with an error
     e0 = _tiny_engine()
-    e0.tp = _ScriptedGroup(0, lambda mine: [mine, (True, mine[1], None)])
+    e0.tp = _ScriptedGroup(0, lambda mine: [mine, [1, mine[1], 0, 0]])
     held = Request(5, [1, 2, 3], 4, 0.0)
     e0.waiting.append(held)
     fresh = Request(6, [9], 2, 0.0)
     e0._inbox.append(fresh)
     e0._tp_sync()
+    assert e0.tp.sent[0][3] == 1 and e0.tp.broadcasts == 1                      # it announced the one new request
     assert held.done.is_set() and "rank(s) [1] failed" in held.error
     # ... while a request that arrived with this very message was no part of the failed step and is kept, on every rank
     assert not fresh.done.is_set() and list(e0.waiting) == [fresh] and not e0._inbox and e0.tp_resets == 1
-    # equal failure flags but a different scheduler state on rank 1 (one more block free): also a reset, before any launch
+    # equal failure flags but a different scheduler state on rank 1 (another hash): also a reset, before any launch
     e0 = _tiny_engine()
-    e0.tp = _ScriptedGroup(0, lambda mine: [mine, (False, mine[1][:3] + (mine[1][3] + 1,) + mine[1][4:], None)])
+    e0.tp = _ScriptedGroup(0, lambda mine: [mine, [0, mine[1] ^ 1, 0, 0]])
     held = Request(7, [1, 2, 3], 4, 0.0)
     e0.waiting.append(held)
     e0._tp_sync()
     assert "scheduled differently" in held.error and e0.tp_resets == 1 and e0.tp.resyncs == 1
-    # the stop wish travels in rank 0's control part
+    # the state hash moves with everything scheduling depends on: queue length, block pool
+    e1, e2 = _tiny_engine(), _tiny_engine()
+    e1.tp = _ScriptedGroup(0, lambda mine: [mine, mine])
+    e2.tp = _ScriptedGroup(0, lambda mine: [mine, mine])
+    e2.waiting.append(Request(8, [1], 1, 0.0))
+    e1._tp_sync(), e2._tp_sync()
+    assert e1.tp.sent[0][1] != e2.tp.sent[0][1]
+    # the stop wish travels in rank 0's row
     e = _tiny_engine()
-    e.tp = _ScriptedGroup(1, lambda mine: [(False, mine[1], (True, [])), mine])
+    e.tp = _ScriptedGroup(1, lambda mine: [[0, mine[1], 1, 0], mine])
     assert e._tp_sync() is True
 
 

@@ -157,15 +157,31 @@ class KubectlSource(KubeSource):
         return "kubectl(%s)" % self.argv[0]
 
 
+def api_host_url(host: str, port: str = "443") -> str:
+    """``https://host:port`` for the in-cluster service variables; an IPv6 literal (KUBERNETES_SERVICE_HOST on an IPv6
+    or dual-stack cluster: ``fd00::1``) is bracketed, as a URL needs it."""
+    h = host.strip()
+    if ":" in h and not h.startswith("["):
+        h = "[" + h + "]"
+    return "https://%s:%s" % (h, port)
+
+
 class KubeApiSource(KubeSource):
-    """``GET {api}/api/v1/pods`` with a bearer token (in-cluster service account by default)."""
+    """``GET {api}/api/v1/pods`` with a bearer token (in-cluster service account by default).
+
+    The list is read in PAGES (``limit`` / ``continue``, 500 pods each by default), so a large cluster is never one
+    multi-hundred-megabyte response, and from the API server's watch cache (``resourceVersion=0``: any recent version, no
+    quorum read from etcd every ten seconds). A continue token that expired between pages (HTTP 410) restarts the walk
+    once; the reference has nothing comparable (it shells out to ``kubectl get pods -A -o json``, monitor_server.js:99)."""
     kind = "api"
 
     def __init__(self, api: str, token_file: str = "", ca_file: str = "", timeout: float = 8.0,
-                 insecure: bool = False):
+                 insecure: bool = False, page_size: int = 500, max_pages: int = 400):
         super().__init__()
         self.url = api.rstrip("/") + "/api/v1/pods"
         self.token_file, self.ca_file, self.timeout = token_file, ca_file, timeout
+        self.page_size, self.max_pages = int(page_size), int(max_pages)
+        self.last_pages = 0
         if self.url.startswith("https"):
             if insecure:
                 self._ctx: Optional[ssl.SSLContext] = ssl._create_unverified_context()
@@ -183,13 +199,39 @@ class KubeApiSource(KubeSource):
         except OSError:
             return ""
 
-    def fetch(self) -> Mapping[str, Any]:
-        req = urllib.request.Request(self.url, headers={"Accept": "application/json"})
+    def _get(self, url: str) -> Mapping[str, Any]:
+        req = urllib.request.Request(url, headers={"Accept": "application/json"})
         tok = self._token()
         if tok:
             req.add_header("Authorization", "Bearer " + tok)
         with urllib.request.urlopen(req, timeout=self.timeout, context=self._ctx) as resp:
             return json.loads(resp.read().decode("utf-8"))
+
+    def fetch(self) -> Mapping[str, Any]:
+        import urllib.error
+        import urllib.parse
+        for attempt in (0, 1):
+            items: list = []
+            cont, pages = "", 0
+            try:
+                while True:
+                    q = {"limit": str(self.page_size)} if self.page_size > 0 else {}
+                    if cont:
+                        q["continue"] = cont
+                    else:
+                        q["resourceVersion"] = "0"                  # the first page may come from the watch cache
+                    doc = self._get(self.url + ("?" + urllib.parse.urlencode(q) if q else ""))
+                    items.extend(doc.get("items") or [])
+                    pages += 1
+                    cont = ((doc.get("metadata") or {}).get("continue") or "") if self.page_size > 0 else ""
+                    if not cont or pages >= self.max_pages:
+                        self.last_pages = pages
+                        return {"kind": "PodList", "items": items, "truncated": bool(cont)}
+            except urllib.error.HTTPError as e:
+                if e.code == 410 and attempt == 0:                 # the continue token expired: one fresh walk
+                    continue
+                raise
+        raise RuntimeError("unreachable")
 
     def describe(self) -> str:
         return f"api({self.url})"
@@ -217,8 +259,7 @@ def open_kube_source(kind: str = "auto", cfg=None) -> KubeSource:
         return KubeApiSource(api or "https://kubernetes.default.svc", token, ca if os.path.exists(ca) else "")
     if kind == "auto":
         if api or (token and os.path.exists(token) and os.environ.get("KUBERNETES_SERVICE_HOST")):
-            host = api or "https://%s:%s" % (os.environ["KUBERNETES_SERVICE_HOST"],
-                                             os.environ.get("KUBERNETES_SERVICE_PORT", "443"))
+            host = api or api_host_url(os.environ["KUBERNETES_SERVICE_HOST"], os.environ.get("KUBERNETES_SERVICE_PORT", "443"))
             return KubeApiSource(host, token, ca if os.path.exists(ca) else "")
         if shutil.which(kubectl):
             return KubectlSource(kubectl)

@@ -61,6 +61,14 @@ function fetchStub(url) {
 const sandbox = {document, console: {log() {}, error: (...a) => errors.push(a.map(x => (x && x.stack) || String(x)).join(' ')), warn() {}},
   fetch: fetchStub, setInterval: (fn, ms) => { intervals.push(ms); return intervals.length; }, setTimeout: (fn, ms) => 0, clearInterval() {},
   ResizeObserver: class { constructor(cb) { this.cb = cb; } observe() {} }, devicePixelRatio: 1};
+// scenario.raf: a frame clock the test drives. requestAnimationFrame queues its callback; the action ["frames", n, stepMs] runs n
+// frames, stepMs apart on performance.now() (the page animates a chart's first data over 500 ms, like the reference's Chart.js).
+const rafQueue = [];
+let clockMs = 1000;
+if (scenario.raf) {
+  sandbox.requestAnimationFrame = fn => { rafQueue.push(fn); return rafQueue.length; };
+  sandbox.performance = {now: () => clockMs};
+}
 sandbox.window = sandbox;
 vm.createContext(sandbox);
 const script = html.slice(html.indexOf('<script>') + 8, html.lastIndexOf('</script>'));
@@ -76,6 +84,7 @@ async function settle() { for (let i = 0; i < 50; i++) { await new Promise(r => 
       if (a[0] === 'click') badges.find(b => b.dataset.tier === a[1]).dispatch('click');
       else if (a[0] === 'eval') vm.runInContext(a[1], sandbox);
       else if (a[0] === 'mousemove') byId[a[1]].dispatch('mousemove', {clientX: a[2], clientY: 10});
+      else if (a[0] === 'frames') for (let i = 0; i < a[1]; i++) { clockMs += a[2]; const q = rafQueue.splice(0); for (const fn of q) fn(clockMs); }
     } catch (e) { errors.push('action ' + JSON.stringify(a) + ' threw: ' + (e.stack || e)); }
     await settle();
   }

@@ -105,9 +105,70 @@ def test_api_source_sends_bearer_token(tmp_path):
     tok.write_text("s3cret\n")
     try:
         src = KubeApiSource(f"http://127.0.0.1:{srv.server_address[1]}", token_file=str(tok))
-        assert len(src.pods()) == 1 and seen == {"path": "/api/v1/pods", "auth": "Bearer s3cret"}
+        assert len(src.pods()) == 1 and seen == {"path": "/api/v1/pods?limit=500&resourceVersion=0", "auth": "Bearer s3cret"}
     finally:
         srv.shutdown()
+
+
+def test_api_source_walks_pages_and_survives_an_expired_continue_token(tmp_path, monkeypatch):
+    """the pod list is read in pages (limit / continue), the first from the watch cache; a continue token
+    that expired mid-walk (410 Gone) restarts the walk once; an IPv6 service host is bracketed."""
+    import threading
+    from http.server import BaseHTTPRequestHandler, HTTPServer
+    from urllib.parse import parse_qs, urlsplit
+    from k8s_llm_monitor_amd.collectors.kube import api_host_url
+    pods = [dict(item(), metadata={"namespace": "llm", "name": f"pod-{i}"}) for i in range(23)]
+    state = {"requests": [], "expire_once": False}
+
+    class H(BaseHTTPRequestHandler):
+        def log_message(self, *a):
+            pass
+
+        def do_GET(self):
+            q = {k: v[0] for k, v in parse_qs(urlsplit(self.path).query).items()}
+            state["requests"].append(q)
+            start = int(q.get("continue", "0"))
+            if start and state["expire_once"]:
+                state["expire_once"] = False
+                self.send_response(410)
+                self.send_header("Content-Length", "0")
+                self.end_headers()
+                return
+            limit = int(q.get("limit", "100000"))
+            page = pods[start:start + limit]
+            meta = {"continue": str(start + limit)} if start + limit < len(pods) else {}
+            body = json.dumps({"kind": "PodList", "metadata": meta, "items": page}).encode()
+            self.send_response(200)
+            self.send_header("Content-Length", str(len(body)))
+            self.end_headers()
+            self.wfile.write(body)
+
+    srv = HTTPServer(("127.0.0.1", 0), H)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    try:
+        src = KubeApiSource(f"http://127.0.0.1:{srv.server_address[1]}", page_size=10)
+        got = src.pods()
+        assert [p["name"] for p in got] == [f"pod-{i}" for i in range(23)] and src.last_pages == 3
+        assert state["requests"] == [{"limit": "10", "resourceVersion": "0"}, {"limit": "10", "continue": "10"}, {"limit": "10", "continue": "20"}]
+        state["requests"].clear()
+        state["expire_once"] = True
+        assert len(src.pods()) == 23 and len(state["requests"]) == 5 and src.last_error is None      # page, 410, then a fresh walk of three
+        # a page cap bounds the walk (and says the list is cut)
+        capped = KubeApiSource(f"http://127.0.0.1:{srv.server_address[1]}", page_size=10, max_pages=2)
+        assert len(capped.pods()) == 20 and capped.fetch()["truncated"] is True
+    finally:
+        srv.shutdown()
+    assert api_host_url("10.43.0.1") == "https://10.43.0.1:443" and api_host_url("fd00:10:96::1", "6443") == "https://[fd00:10:96::1]:6443"
+    assert api_host_url("[fd00::1]") == "https://[fd00::1]:443"
+    tok = tmp_path / "token"
+    tok.write_text("t")
+    monkeypatch.setenv("KUBERNETES_SERVICE_HOST", "fd00:10:96::1")
+    monkeypatch.setenv("KUBERNETES_SERVICE_PORT", "443")
+
+    class Cfg:
+        class sources:
+            kubectl, kube_api, kube_token_file, kube_ca_file = "kubectl", "", str(tok), ""
+    assert open_kube_source("auto", Cfg).url == "https://[fd00:10:96::1]:443/api/v1/pods"
 
 
 def test_open_auto_without_cluster(monkeypatch):

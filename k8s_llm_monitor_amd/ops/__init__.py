@@ -83,6 +83,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
             lib.klm_hbm_read_ex.restype = i
         lib.klm_hbm_read.argtypes = [vp, sz, vp, vp]
         lib.klm_hbm_read.restype = i
+        if hasattr(lib, "klm_hbm_repitch"):
+            lib.klm_hbm_repitch.argtypes = [vp, sz, vp, sz, i, sz, vp]
+            lib.klm_hbm_repitch.restype = i
         lib.klm_hbm_checksum.argtypes = [vp, sz, vp, vp]
         lib.klm_hbm_checksum.restype = i
         lib.klm_spin.argtypes = [u64, i, vp]
@@ -193,14 +196,68 @@ def hbm_launch_plan(nbytes: int, accesses_per_thread: int = 1):
     return n, first.value, last.value
 
 
-def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0) -> int:
-    """The kernel `gemm_bf16(variant=None)` runs for a shape (pure: no device, no library)."""
+#: the cost model behind `pick_bf16_variant` (microseconds; fitted to profiles/r3_prof/gemm_small.json and gemm_units_first.json).
+#: A workgroup's time per element of K on a full chip and on a quarter-full one (fewer busy CUs: higher clocks, more L2 each):
+_STREAM_US_PER_K = (0.0146, 0.0212)     # 256 x 256 tile, persistent stream (variant 10)
+_P128_US_PER_K = (0.0040, 0.0078)       # 128 x 128 tile, eight-wave ring kernel (variant 14)
+_STREAM_FIXED_US, _P128_FIXED_US = 8.0, 6.5
+_SPLIT_PASS_US, _SPLIT_MB_US, _SPLIT_LAUNCH_US = 2.2, 0.30, 8.0      # klm_quad_plan's decision rule (gemm_quad_asm.h)
+_SPLIT_TIME_MB_US = 0.13               # what the partial sums were measured to add (64 MB: 8 us on top of the reduce launch)
+
+
+def _per_k(pair, occupancy: float) -> float:
+    lo, hi = pair
+    return lo + (hi - lo) * min(1.0, max(0.0, (occupancy - 0.25) / 0.75))
+
+
+def stream_plan_py(M: int, N: int, Kbytes: int, cus: int = 256, mode: int = 1):
+    """klm_quad_plan's arithmetic (rounds, rest, split) without the library: what `pick_bf16_variant` prices."""
+    ntiles, P = (M // 256) * (N // 256), Kbytes // 256
+    rounds, rest = divmod(ntiles, cus)
+    S = 0
+    if mode and rest:
+        s = min(cus // rest, 8, P // 2)
+        if s > 1:
+            saved = _SPLIT_PASS_US * (P - -(-P // s))
+            cost = _SPLIT_LAUNCH_US + _SPLIT_MB_US * rest * s * 0.25
+            if mode == 2 or saved > cost:
+                S = s
+    return rounds, rest, S
+
+
+def stream_time_us(M: int, N: int, K: int, cus: int = 256) -> float:
+    """Modelled time of the persistent 256 x 256 stream on an M x N x K bf16 problem."""
+    rounds, rest, S = stream_plan_py(M, N, 2 * K, cus)
+    t = _STREAM_FIXED_US + rounds * K * _STREAM_US_PER_K[1]
+    if rest:
+        if S > 1:
+            t += K * _per_k(_STREAM_US_PER_K, rest * S / cus) / S + _SPLIT_LAUNCH_US + _SPLIT_TIME_MB_US * rest * S * 0.25
+        else:
+            t += K * _per_k(_STREAM_US_PER_K, rest / cus)
+    return t
+
+
+def p128_time_us(M: int, N: int, K: int, cus: int = 256) -> float:
+    """Modelled time of the eight-wave 128 x 128 ring kernel (one workgroup per CU at a time: 128 KiB of LDS each)."""
+    rounds, rest = divmod((M // 128) * (N // 128), cus)
+    return _P128_FIXED_US + rounds * K * _P128_US_PER_K[1] + (K * _per_k(_P128_US_PER_K, rest / cus) if rest else 0.0)
+
+
+def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0, cus: int = 256) -> int:
+    """The kernel `gemm_bf16(variant=None)` runs for a shape (pure: no device, no library): the persistent 256 x 256 stream
+    (10) or, where fewer 256 x 256 tiles than CUs leave most of the chip idle, the 128 x 128 ring kernel (14: 2048^3 768
+    TFLOP/s against 453), whichever the cost model prices lower; the ring / old 128 x 128 kernels for shapes neither takes."""
     if pitch:
         return 10              # row-pitched operands: the streams are the kernels that take a pitch
-    if (M // 256) * (N // 256) <= 32 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0:
-        return 0               # a handful of 256 x 256 tiles leaves most CUs idle: 1024^3 runs at 127 TFLOP/s on 128 x 128 tiles, 101 on 256 x 256
-    if M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128:
-        return 10 if (K % 128 == 0 and K >= 256) else 1     # an even number of K tiles >= 4, else the ring's schedule 0
+    stream_ok = M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and K >= 256
+    p128_ok = M % 128 == 0 and N % 128 == 0 and K % 64 == 0 and K >= 64
+    if stream_ok and p128_ok:
+        return 14 if p128_time_us(M, N, K, cus) < stream_time_us(M, N, K, cus) else 10
+    if stream_ok:
+        return 10
+    if p128_ok:
+        # the ring's schedule 0 takes whole 256 x 256 tiles with an odd number of K tiles; it wins once its tiles fill half the chip
+        return 1 if (M % 256 == 0 and N % 256 == 0 and K >= 128 and (M // 256) * (N // 256) >= cus // 2) else 14
     return 0
 
 
@@ -221,6 +278,40 @@ def stream_workspace(device, nbytes: int = 0):
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         _ws_cache[key] = ws
     return ws
+
+
+_repack_cache: dict = {}
+
+#: Dense bf16 operands whose row pitch is a non-power-of-two multiple of 8 KiB (24 KiB = K 12288, 40 KiB = K 20480) cost the
+#: GEMM 17 - 21 % (8192 x 8192 x 12288: 1381 TFLOP/s dense, 1617 on rows 256 bytes further apart; the milder camping pitches --
+#: 20 KiB, 28 KiB: 7 % -- are not worth a copy: profiles/r2_prof/gemm_pitch_check.json, profiles/r3_prof/gemm_repack.json).
+#: From this many rows on, `gemm_bf16(variant=None)` copies both operands into padded scratch first (6.4 TB/s, one launch each).
+REPACK_MIN_ROWS = 6144
+
+
+def repack_worthwhile(M: int, N: int, Kbytes: int, dtype_bytes: int = 2) -> bool:
+    """True when `gemm_bf16(variant=None)` re-pitches dense operands before the GEMM (pure)."""
+    bad_pitch = Kbytes >= 24576 and Kbytes % 8192 == 0 and (Kbytes & (Kbytes - 1)) != 0
+    return dtype_bytes == 2 and bad_pitch and min(M, N) >= REPACK_MIN_ROWS and M % 256 == 0 and N % 256 == 0
+
+
+def repitched(t, role: str = "a", pad_bytes: int = 256):
+    """A row-padded copy of the 2-D tensor `t` in a scratch buffer kept per (device, stream, role): the persistent streams
+    take it as a pitched operand. One 16-byte load + store per thread (klm_hbm_repitch)."""
+    import torch
+    _require_cuda(t)
+    rows, cols = t.shape
+    es = t.element_size()
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream, role)
+    pitch_elems = cols + pad_bytes // es
+    buf = _repack_cache.get(key)
+    if buf is None or buf.dtype != t.dtype or buf.numel() < rows * pitch_elems:
+        buf = torch.empty(rows * pitch_elems, dtype=t.dtype, device=t.device)
+        _repack_cache[key] = buf
+    view = buf[: rows * pitch_elems].view(rows, pitch_elems)[:, :cols]
+    with _on_device(t):
+        _check(load().klm_hbm_repitch(view.data_ptr(), pitch_elems * es, t.data_ptr(), cols * es, rows, cols * es, _stream_of(t)), "klm_hbm_repitch")
+    return view
 
 
 def gemm_has_diag() -> bool:
@@ -264,7 +355,8 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
 
     variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream in its persistent
-    form (10: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue; a last,
+    form (10; or, for shapes of fewer 256 x 256 tiles than CUs, the eight-wave 128 x 128 ring kernel 14, whichever
+    `pick_bf16_variant` prices lower; 10: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue; a last,
     partial round of tiles is cut into K slices where that pays -- `gemm_stream_plan` -- and the K loops are staggered on a
     row pitch the memory channels camp on; 8: the same without either, 11 / 12: with one of them forced) for whole
     256 x 256 tiles and an even number of K tiles >= 4, else the 8-wave ring kernel (2, or 1 for an odd tile count), else
@@ -290,6 +382,11 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
         _require_cuda(out)
         if out.shape != (M, N) or out.dtype != torch.bfloat16:
             raise KlmOpsError("gemm_bf16: bad `out`")
+    if variant == 10 and not pitch and repack_worthwhile(M, N, 2 * K):
+        # dense operands on a row pitch the memory channels camp on, and a problem large enough to pay for a copy: both
+        # operands go through padded scratch (the same bits as on the dense operands: the pitch does not enter the sum)
+        a, b = repitched(a, "a"), repitched(b, "b")
+        pitch = _pitch_bytes(a, b)
     if variant in (10, 11, 12, 13):
         # the persistent stream with its plan: 10 the default (the partial round split into K slices where that pays, the K loops
         # staggered on a camping pitch); 11: split wherever the shape allows, 12: stagger always, 13: neither (= 8)

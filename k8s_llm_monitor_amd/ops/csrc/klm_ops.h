@@ -79,6 +79,8 @@ int klm_hbm_read_ex(const void* src, size_t bytes, void* sink8, int flags, int g
 // Sums 32-bit words of [src, src+bytes) into *sum64 (device memory, must be zeroed by the
 // caller on the same stream). Used to check that a filled region holds its pattern.
 int klm_hbm_checksum(const void* src, size_t bytes, void* sum64, void* stream);
+// `rows` rows of `row_bytes` from row pitch `src_pitch` to row pitch `dst_pitch` (bytes; everything a multiple of 16)
+int klm_hbm_repitch(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, int rows, size_t row_bytes, void* stream);
 
 // A GPU busy-wait of `cycles` s_memtime ticks on one wave per CU: a load with ~0 HBM
 // traffic and ~0 MFMA work, used to tell "GFX activity" apart from useful work.

@@ -23,7 +23,8 @@ def env():
                                            (10, (512, 768, 384)), (11, (512, 768, 1024)), (12, (512, 768, 1024)), (13, (256, 256, 4352)), (11, (1280, 1536, 2048)),
                                            (8, (256, 256, 256)), (8, (512, 768, 384)), (8, (2048, 1024, 4096)), (8, (256, 512, 4352)),
                                            (9, (512, 768, 384)), (9, (2048, 1024, 4096)),
-                                           (None, (1024, 1024, 1024)), (None, (384, 128, 64)), (None, (256, 256, 192))])
+                                           (14, (128, 128, 64)), (14, (256, 384, 128)), (14, (384, 640, 192)), (14, (1024, 512, 2048)), (14, (128, 256, 4160)),
+                                           (None, (1024, 1024, 1024)), (None, (2048, 2048, 2048)), (None, (384, 128, 64)), (None, (256, 256, 192))])
 def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch, ops, dev = env
     M, N, K = shape
@@ -36,7 +37,7 @@ def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=1e-2 * K ** 0.5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14])
 def test_gemm_bf16_exact_on_small_integers_with_asymmetric_operands(env, variant):
     torch, ops, dev = env
     M, N, K = 512, 256, (192 if variant < 2 else 384)
@@ -54,7 +55,7 @@ def test_gemm_bf16_identity_picks_rows_not_columns(env):
     n = 256
     eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
     b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)      # asymmetric
-    for v in (0, 1, 2, 3, 4, 8, 10, 13):
+    for v in (0, 1, 2, 3, 4, 8, 10, 13, 14):
         assert torch.equal(ops.gemm_bf16(eye, b, variant=v), b.t().contiguous())      # C = I @ B^T
 
 
@@ -66,6 +67,13 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
     for v in (1, 2, 3, 4, 8, 9, 13):                                  # every pipeline gives the same bits, every run
         for _ in range(20):
             assert torch.equal(ops.gemm_bf16(a, b, variant=v), c0)   # a ring-buffer race would show as a rare diff
+    # the eight-wave 128 x 128 ring (its own K order: compared with its own first run), on K tile counts 1..5 and a long one
+    for K in (64, 128, 192, 256, 320, 2048):
+        x, y = a[:, :K].contiguous(), b[:, :K].contiguous()
+        c14 = ops.gemm_bf16(x, y, variant=14).clone()
+        torch.testing.assert_close(c14.float(), x.float() @ y.float().t(), rtol=1.6e-2, atol=1e-2 * K ** 0.5)
+        for _ in range(20):
+            assert torch.equal(ops.gemm_bf16(x, y, variant=14), c14), K
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096), (256, 512, 512), (768, 256, 4608)])
@@ -258,6 +266,25 @@ def test_partial_round_split_into_k_slices_and_staggered_k_loops(env, grid, shap
         assert torch.equal(ops.gemm_bf16(x, y, variant=11), ops.gemm_bf16(x, y, variant=11))     # and the split is deterministic
     finally:
         ops.gemm_persistent_grid(before)
+
+
+def test_dense_operands_on_a_bad_pitch_are_repitched_with_the_same_bits(env):
+    """ops.repitched copies rows into padded scratch (klm_hbm_repitch); `gemm_bf16(variant=None)` does that by itself for dense
+    operands on a 24 KiB pitch once the problem is large enough, and the result has the bits of the dense run."""
+    torch, ops, dev = env
+    g = torch.Generator(device=dev).manual_seed(3)
+    t = torch.randint(0, 255, (777, 4096), device=dev, generator=g, dtype=torch.uint8)
+    p = ops.repitched(t, "t", pad_bytes=256)
+    assert p.shape == t.shape and p.stride(0) == 4096 + 256 and torch.equal(p, t)
+    M = N = 6144
+    K = 12288
+    assert ops.repack_worthwhile(M, N, 2 * K)
+    a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    c = ops.gemm_bf16(a, b)                                  # re-pitched, and its partial round split
+    pa, pb = ops.repitched(a, "x"), ops.repitched(b, "y")
+    assert not pa.is_contiguous() and torch.equal(c, ops.gemm_bf16(pa, pb, variant=10))
+    torch.testing.assert_close(c[:512, :512].float(), a[:512].float() @ b[:512].float().t(), rtol=1.6e-2, atol=1.0)
 
 
 def test_ops_follow_the_tensors_device_not_the_current_one(env):

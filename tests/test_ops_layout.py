@@ -114,4 +114,41 @@ def test_stream_plan_splits_the_partial_round_only_where_it_pays():
             S = p["split"]
             assert 2 <= S <= 8 and P // S >= 2
             assert sum(P // S + (1 if s < P % S else 0) for s in range(S)) == P
-    assert ops.pick_bf16_variant(8192, 8192, 8192) == 10 and ops.pick_bf16_variant(1024, 1024, 1024) == 0 and ops.pick_bf16_variant(3072, 3072, 192) == 1
+    assert ops.pick_bf16_variant(8192, 8192, 8192) == 10 and ops.pick_bf16_variant(1024, 1024, 1024) == 14 and ops.pick_bf16_variant(3072, 3072, 192) == 1
+
+
+def test_default_bf16_kernel_follows_the_cost_model_and_the_measurements():
+    """`pick_bf16_variant` prices the persistent 256 x 256 stream against the eight-wave 128 x 128 ring kernel; its plan
+    arithmetic is the library's (klm_quad_plan), and its choices are the measured winners of profiles/r3_prof/gemm_small.json."""
+    from k8s_llm_monitor_amd import build, ops
+    if build.hipcc() is None:
+        pytest.skip("hipcc not installed")
+    build.build_all(only=["klm_ops"], verbose=False)
+    for M, N, K in ((2048, 2048, 2048), (2048, 2048, 8192), (1024, 4096, 4096), (4096, 6144, 4096), (6144, 6144, 6144), (5120, 5120, 5120),
+                    (256, 256, 512), (768, 768, 1024), (8192, 8192, 8192), (2560, 2560, 2560)):
+        p = ops.gemm_stream_plan(M, N, 2 * K, cus=256)
+        assert ops.stream_plan_py(M, N, 2 * K) == (p["rounds"], p["rest"], p["split"]), (M, N, K)
+    pick = ops.pick_bf16_variant
+    # fewer 256 x 256 tiles than CUs and a short K: the 128 x 128 ring kernel (2048^3: 768 TFLOP/s against the stream's 453)
+    assert [pick(n, n, n) for n in (512, 1024, 1536, 2048, 2560)] == [14] * 5
+    assert pick(1024, 4096, 4096) == 14 and pick(4096, 1024, 1024) == 14 and pick(128, 384, 64) == 14 and pick(384, 128, 64) == 14
+    # from 144 tiles on, and on a long K (the split fills the chip), the stream
+    assert [pick(n, n, n) for n in (3072, 3584, 4096, 5120, 6144, 8192, 12288)] == [10] * 7
+    assert pick(2048, 2048, 8192) == 10 and pick(1024, 1024, 16384) == 10 and pick(2048, 6144, 4096) == 10 and pick(8192, 8192, 1024) == 10
+    assert pick(2048, 2048, 2048, pitch=4352) == 10                 # pitched operands: only the streams take them
+    assert pick(100, 128, 64) == 0 and pick(4096, 4096, 192) == 1 and pick(1024, 1024, 192) == 14
+    # the modelled times are the measured ones to ~15 %
+    for (M, N, K), us in (((2048, 2048, 2048), 22.4), ((1024, 1024, 1024), 10.6), ((2048, 2048, 8192), 70.2)):
+        assert abs(ops.p128_time_us(M, N, K) - us) / us < 0.15
+    for (M, N, K), us in (((4096, 4096, 4096), 94.8), ((3072, 3072, 3072), 57.5), ((8192, 8192, 8192), 687.0)):
+        assert abs(ops.stream_time_us(M, N, K) - us) / us < 0.15
+
+
+def test_repack_rule_and_camping_pitch_are_pure_and_selective():
+    from k8s_llm_monitor_amd import ops
+    assert ops.repack_worthwhile(12288, 12288, 24576) and ops.repack_worthwhile(8192, 8192, 40960) and ops.repack_worthwhile(6144, 6144, 24576)
+    assert not ops.repack_worthwhile(8192, 8192, 16384)          # a power of two: the channel hash handles it
+    assert not ops.repack_worthwhile(8192, 8192, 20480)          # camps mildly (7 %): a copy costs more
+    assert not ops.repack_worthwhile(4096, 4096, 24576)          # too few rows to pay for the copy
+    assert not ops.repack_worthwhile(12288, 12288, 24576, dtype_bytes=1)
+    assert ops.camping_pitch(24576) and ops.camping_pitch(20480) and not ops.camping_pitch(16384)

@@ -91,13 +91,13 @@ def targets() -> List[Target]:
                ops / "llm_skinny.hip", ops / "llm_mid.hip"]
     ops_src = [s for s in ops_src if s.exists()]
     out: List[Target] = [
-        Target("klm_ops", LIB_DIR / "libklm_ops.so", ops_src, "hip-shared", deps=[hdr, ops / "llm_common.h", ops / "gemm_ring256.h", ops / "gemm_quad128.h", ops / "klm_launch.h", ops / "gemm_quad_asm.inc", ops / "gemm_quad_asm.h"]),
+        Target("klm_ops", LIB_DIR / "libklm_ops.so", ops_src, "hip-shared", deps=[hdr, ops / "llm_common.h", ops / "gemm_ring256.h", ops / "gemm_p128.h", ops / "gemm_quad128.h", ops / "klm_launch.h", ops / "gemm_quad_asm.inc", ops / "gemm_quad_asm.h"]),
     ]
     burner = PKG / "loadgen" / "native" / "klm_burner.cpp"
     if burner.exists():
         # the standalone burner carries the load-generator kernels only (GEMMs, HBM, spin), not the serving engine's
         out.append(Target("klm_burner", BIN_DIR / "klm_burner", [burner, *[x for x in ops_src if not x.name.startswith("llm_")]], "hip-exe",
-                          extra=[f"-I{ops}"], deps=[hdr, ops / "llm_common.h", ops / "gemm_ring256.h", ops / "gemm_quad128.h", ops / "klm_launch.h", ops / "gemm_quad_asm.inc", ops / "gemm_quad_asm.h"]))
+                          extra=[f"-I{ops}"], deps=[hdr, ops / "llm_common.h", ops / "gemm_ring256.h", ops / "gemm_p128.h", ops / "gemm_quad128.h", ops / "klm_launch.h", ops / "gemm_quad_asm.inc", ops / "gemm_quad_asm.h"]))
     probe = PKG / "parallel" / "csrc" / "rccl_probe.cpp"
     if probe.exists():
         out.append(Target("klm_rccl_probe", BIN_DIR / "klm_rccl_probe", [probe], "hip-exe",

@@ -196,22 +196,23 @@ def hbm_launch_plan(nbytes: int, accesses_per_thread: int = 1):
     return n, first.value, last.value
 
 
-#: the cost model behind `pick_bf16_variant` (microseconds; fitted to profiles/r3_prof/gemm_small.json and gemm_units_first.json).
-#: A workgroup's time per element of K on a full chip and on a quarter-full one (fewer busy CUs: higher clocks, more L2 each):
-_STREAM_US_PER_K = (0.0146, 0.0212)     # 256 x 256 tile, persistent stream (variant 10)
-_P128_US_PER_K = (0.0040, 0.0078)       # 128 x 128 tile, eight-wave ring kernel (variant 14)
+#: the cost model behind the default kernel choice (microseconds; fitted to profiles/r3_prof/gemm_small.json and
+#: gemm_units_first.json). A workgroup's time per BYTE of a row's K extent on a quarter-full chip and on a full one (fewer busy
+#: CUs: higher clocks, more L2 bandwidth each); per byte, because both kernels stage 128-byte K tiles whatever the format:
+_STREAM_US_PER_KB = (0.0073, 0.0106)    # 256 x 256 tile, persistent stream (bf16 10, fp8 7, fp4 6)
+_P128_US_PER_KB = (0.0020, 0.0039)      # 128 x 128 tile, eight-wave ring kernel (14)
 _STREAM_FIXED_US, _P128_FIXED_US = 8.0, 6.5
 _SPLIT_PASS_US, _SPLIT_MB_US, _SPLIT_LAUNCH_US = 2.2, 0.30, 8.0      # klm_quad_plan's decision rule (gemm_quad_asm.h)
 _SPLIT_TIME_MB_US = 0.13               # what the partial sums were measured to add (64 MB: 8 us on top of the reduce launch)
 
 
-def _per_k(pair, occupancy: float) -> float:
+def _per_kb(pair, occupancy: float) -> float:
     lo, hi = pair
     return lo + (hi - lo) * min(1.0, max(0.0, (occupancy - 0.25) / 0.75))
 
 
 def stream_plan_py(M: int, N: int, Kbytes: int, cus: int = 256, mode: int = 1):
-    """klm_quad_plan's arithmetic (rounds, rest, split) without the library: what `pick_bf16_variant` prices."""
+    """klm_quad_plan's arithmetic (rounds, rest, split) without the library: what the default kernel choice prices."""
     ntiles, P = (M // 256) * (N // 256), Kbytes // 256
     rounds, rest = divmod(ntiles, cus)
     S = 0
@@ -225,40 +226,67 @@ def stream_plan_py(M: int, N: int, Kbytes: int, cus: int = 256, mode: int = 1):
     return rounds, rest, S
 
 
-def stream_time_us(M: int, N: int, K: int, cus: int = 256) -> float:
-    """Modelled time of the persistent 256 x 256 stream on an M x N x K bf16 problem."""
-    rounds, rest, S = stream_plan_py(M, N, 2 * K, cus)
-    t = _STREAM_FIXED_US + rounds * K * _STREAM_US_PER_K[1]
+def stream_time_us(M: int, N: int, Kbytes: int, cus: int = 256) -> float:
+    """Modelled time of the persistent 256 x 256 stream on a problem whose rows are `Kbytes` long."""
+    rounds, rest, S = stream_plan_py(M, N, Kbytes, cus)
+    t = _STREAM_FIXED_US + rounds * Kbytes * _STREAM_US_PER_KB[1]
     if rest:
         if S > 1:
-            t += K * _per_k(_STREAM_US_PER_K, rest * S / cus) / S + _SPLIT_LAUNCH_US + _SPLIT_TIME_MB_US * rest * S * 0.25
+            t += Kbytes * _per_kb(_STREAM_US_PER_KB, rest * S / cus) / S + _SPLIT_LAUNCH_US + _SPLIT_TIME_MB_US * rest * S * 0.25
         else:
-            t += K * _per_k(_STREAM_US_PER_K, rest / cus)
+            t += Kbytes * _per_kb(_STREAM_US_PER_KB, rest / cus)
     return t
 
 
-def p128_time_us(M: int, N: int, K: int, cus: int = 256) -> float:
+def p128_time_us(M: int, N: int, Kbytes: int, cus: int = 256) -> float:
     """Modelled time of the eight-wave 128 x 128 ring kernel (one workgroup per CU at a time: 128 KiB of LDS each)."""
     rounds, rest = divmod((M // 128) * (N // 128), cus)
-    return _P128_FIXED_US + rounds * K * _P128_US_PER_K[1] + (K * _per_k(_P128_US_PER_K, rest / cus) if rest else 0.0)
+    return _P128_FIXED_US + rounds * Kbytes * _P128_US_PER_KB[1] + (Kbytes * _per_kb(_P128_US_PER_KB, rest / cus) if rest else 0.0)
+
+
+def stream_shape_ok(M: int, N: int, Kbytes: int) -> bool:
+    return M > 0 and N > 0 and M % 256 == 0 and N % 256 == 0 and Kbytes % 256 == 0 and Kbytes >= 512
+
+
+def p128_shape_ok(M: int, N: int, Kbytes: int) -> bool:
+    return M > 0 and N > 0 and M % 128 == 0 and N % 128 == 0 and Kbytes % 128 == 0 and Kbytes >= 128
+
+
+def pick_tile_kernel(M: int, N: int, Kbytes: int, cus: int = 256) -> Optional[str]:
+    """"stream" (256 x 256 persistent), "p128" (128 x 128 eight-wave ring) or None (neither takes the shape): whichever the
+    cost model prices lower. Pure: no device, no library."""
+    s_ok, p_ok = stream_shape_ok(M, N, Kbytes), p128_shape_ok(M, N, Kbytes)
+    if s_ok and p_ok:
+        return "p128" if p128_time_us(M, N, Kbytes, cus) < stream_time_us(M, N, Kbytes, cus) else "stream"
+    return "stream" if s_ok else "p128" if p_ok else None
 
 
 def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0, cus: int = 256) -> int:
     """The kernel `gemm_bf16(variant=None)` runs for a shape (pure: no device, no library): the persistent 256 x 256 stream
-    (10) or, where fewer 256 x 256 tiles than CUs leave most of the chip idle, the 128 x 128 ring kernel (14: 2048^3 768
-    TFLOP/s against 453), whichever the cost model prices lower; the ring / old 128 x 128 kernels for shapes neither takes."""
+    (10) or, where fewer 256 x 256 tiles than CUs leave most of the chip idle, the 128 x 128 ring kernel (14: 2048^3 807
+    TFLOP/s against 465), whichever the cost model prices lower; the ring / old 128 x 128 kernels for shapes neither takes."""
     if pitch:
         return 10              # row-pitched operands: the streams are the kernels that take a pitch
-    stream_ok = M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and K >= 256
-    p128_ok = M % 128 == 0 and N % 128 == 0 and K % 64 == 0 and K >= 64
-    if stream_ok and p128_ok:
-        return 14 if p128_time_us(M, N, K, cus) < stream_time_us(M, N, K, cus) else 10
-    if stream_ok:
+    kind = pick_tile_kernel(M, N, 2 * K, cus)
+    if kind == "stream":
         return 10
-    if p128_ok:
+    if kind == "p128":
         # the ring's schedule 0 takes whole 256 x 256 tiles with an odd number of K tiles; it wins once its tiles fill half the chip
-        return 1 if (M % 256 == 0 and N % 256 == 0 and K >= 128 and (M // 256) * (N // 256) >= cus // 2) else 14
+        if not stream_shape_ok(M, N, 2 * K) and M % 256 == 0 and N % 256 == 0 and K >= 128 and (M // 256) * (N // 256) >= cus // 2:
+            return 1
+        return 14
     return 0
+
+
+def pick_mx_variant(M: int, N: int, Kbytes: int, pitch: int, stream_variant: int, cus: int = 256) -> int:
+    """fp8 / fp4 (`Kbytes`: a row's bytes): the persistent stream with its plan, the 128 x 128 ring kernel (14) where the
+    model prices it lower, else the 256 x 256 ring kernel (1)."""
+    if pitch:
+        return stream_variant
+    kind = pick_tile_kernel(M, N, Kbytes, cus)
+    if kind == "p128" and not stream_shape_ok(M, N, Kbytes) and M % 256 == 0 and N % 256 == 0 and Kbytes >= 256 and (M // 256) * (N // 256) >= cus // 2:
+        return 1
+    return {"stream": stream_variant, "p128": 14, None: 1}[kind]
 
 
 #: fp32 partial sums of one K slice of one 256 x 256 tile
@@ -323,10 +351,10 @@ def gemm_has_diag() -> bool:
 def gemm_stream_plan(M: int, N: int, Kbytes: int, cus: int = 0, mode: int = 1, rot: int = 0, ws_bytes: int = 1 << 40) -> dict:
     """How the persistent stream runs an M x N problem whose rows hold `Kbytes` bytes of K on `cus` workgroups (0: this
     device's CUs): `rounds` full rounds of whole tiles on `grid` workgroups, then `rest` tiles, each cut into `split` K slices
-    (0: run whole); `rot`: the K-loop stagger in passes."""
-    out = (ctypes.c_int * 5)()
+    (0: run whole); `rot`: the K-loop stagger in passes; `map`: 1 = the super-block tile order (mode + 4 asks for it)."""
+    out = (ctypes.c_int * 6)()
     _check(load().klm_gemm_stream_plan(M, N, Kbytes, cus, mode, rot, ws_bytes, out), f"klm_gemm_stream_plan({M},{N},{Kbytes})")
-    return dict(zip(("grid", "rounds", "rest", "split", "rot"), (int(x) for x in out)))
+    return dict(zip(("grid", "rounds", "rest", "split", "rot", "map"), (int(x) for x in out)))
 
 
 #: K-loop stagger for dense operands whose row pitch the memory channels camp on: the workgroups of XCD x start their K loop
@@ -334,6 +362,8 @@ def gemm_stream_plan(M: int, N: int, Kbytes: int, cus: int = 0, mode: int = 1, r
 CAMPING_ROT = -1
 #: what `variant=None` does on a camping pitch: 0 = nothing (set from the measurement in scripts/exp/gemm_units.py)
 AUTO_ROT = 0
+#: the default streams' plan mode: 1 = split the partial round where it pays; + 4 = the super-block tile order where the shape allows
+STREAM_MODE = 1
 
 
 def _stream(dtype_code: int, a, b, out, M, N, Kbytes, pitch, store=0, mode=1, rot=None, what="gemm"):
@@ -387,11 +417,12 @@ def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
         # operands go through padded scratch (the same bits as on the dense operands: the pitch does not enter the sum)
         a, b = repitched(a, "a"), repitched(b, "b")
         pitch = _pitch_bytes(a, b)
-    if variant in (10, 11, 12, 13):
+    if variant in (10, 11, 12, 13, 15):
         # the persistent stream with its plan: 10 the default (the partial round split into K slices where that pays, the K loops
-        # staggered on a camping pitch); 11: split wherever the shape allows, 12: stagger always, 13: neither (= 8)
-        return _stream(0, a, b, out, M, N, 2 * K, pitch, mode={10: 1, 11: 2, 12: 0, 13: 0}[variant],
-                       rot={10: None, 11: 0, 12: CAMPING_ROT, 13: 0}[variant], what="bf16")
+        # staggered on a camping pitch); 11: split wherever the shape allows, 12: stagger always, 13: neither (= 8);
+        # 15: 10 with the super-block tile order where the shape allows it
+        return _stream(0, a, b, out, M, N, 2 * K, pitch, mode={10: STREAM_MODE, 11: 2, 12: 0, 13: 0, 15: 5}[variant],
+                       rot={10: None, 11: 0, 12: CAMPING_ROT, 13: 0, 15: None}[variant], what="bf16")
     with _on_device(a):
         if pitch:
             # row-pitched operands (padded_operand): the hand-scheduled streams only
@@ -413,8 +444,9 @@ def gemm_persistent_grid(grid: int = -1) -> int:
 
 def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] (bf16) = a[M,K] @ b[N,K].T`` with OCP e4m3 inputs on the f8f6f4 MFMA (16x16x128).
-    variant None: the hand-scheduled 4-wave stream in its persistent form (4) when K is a multiple of 256 and >= 512, else
-    the ring kernel (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 2: the stream with one
+    variant None: the hand-scheduled 4-wave stream in its persistent form with its plan (7; 4 without the plan) when K is a
+    multiple of 256 and >= 512, or the eight-wave 128 x 128 ring kernel (14) where fewer 256 x 256 tiles than CUs make it
+    the faster one (`pick_mx_variant`), else the ring kernel (1: schedule 1 when the K tile count allows, else schedule 0; 0: schedule 0). 2: the stream with one
     workgroup per tile; 3: another placement of stream 2; 5: 4 with C stored past the caches (see gemm_bf16, variant 9);
     6: 4 on the block-scaled MFMA with unit scales (the streams use the plain v_mfma_f32_16x16x128_f8f6f4: same bits, one
     instruction word instead of two, +1.6 %; the ring kernels keep the block-scaled form)."""
@@ -427,16 +459,17 @@ def gemm_fp8(a, b, out=None, variant: Optional[int] = None):
     M, K = a.shape
     N = b.shape[0]
     if variant is None:
-        variant = 7 if (K % 256 == 0 and K >= 512 and M % 256 == 0 and N % 256 == 0) else 1
+        variant = pick_mx_variant(M, N, K, _pitch_bytes(a, b), 7)
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()
     if not hasattr(lib, "klm_gemm_fp8"):
         raise KlmOpsError("libklm_ops.so was built without the fp8 kernel")
     pitch = _pitch_bytes(a, b)
-    if variant in (7, 8):
-        # 7: the persistent stream with its plan (as bf16 variant 10); 8: the partial round split wherever the shape allows
-        return _stream(1, a, b, out, M, N, K, pitch, mode=1 if variant == 7 else 2, rot=None if variant == 7 else 0, what="fp8")
+    if variant in (7, 8, 9):
+        # 7: the persistent stream with its plan (as bf16 variant 10); 8: the partial round split wherever the shape allows;
+        # 9: 7 with the super-block tile order where the shape allows it
+        return _stream(1, a, b, out, M, N, K, pitch, mode={7: STREAM_MODE, 8: 2, 9: 5}[variant], rot=None if variant != 8 else 0, what="fp8")
     with _on_device(a):
         if pitch:
             if variant not in (2, 4, 5):
@@ -464,8 +497,9 @@ def fp4_decode(packed):
 def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     """``out[M,N] (bf16) = A[M,K] @ B[N,K].T`` with e2m1 (fp4) inputs packed two per byte:
     `a` is uint8 (or ``float4_e2m1fn_x2``) of shape [M, K/2], `b` of shape [N, K/2].
-    variant None: the hand-scheduled 4-wave stream in its persistent form (3) when the packed row is a multiple of 256
-    bytes and >= 512, else the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0). 2: the stream with
+    variant None: the hand-scheduled 4-wave stream in its persistent form with its plan (6; 3 without) when the packed row
+    is a multiple of 256 bytes and >= 512, or the eight-wave 128 x 128 ring kernel (14) where `pick_mx_variant` prices it
+    lower, else the ring kernel (1: schedule 1 where the tile count allows; 0: schedule 0). 2: the stream with
     one workgroup per tile; 4: 3 with C stored past the caches; 5: 3 on the block-scaled MFMA with unit scales (same bits,
     -3.3 %)."""
     import torch
@@ -478,7 +512,7 @@ def gemm_fp4(a, b, out=None, variant: Optional[int] = None):
     M, Kb = a.shape
     N = b.shape[0]
     if variant is None:
-        variant = 6 if (Kb % 256 == 0 and Kb >= 512 and M % 256 == 0 and N % 256 == 0) else 1
+        variant = pick_mx_variant(M, N, Kb, _pitch_bytes(a, b), 6)
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     lib = load()

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemm_p128.h"
 #include "gemm_quad128.h"
 #include "gemm_quad_asm.h"
 #include "gemm_ring256.h"
@@ -92,63 +93,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const uint16_t* __restrict_
 }
 
 
-// ------------------------------------------------------------------------------------
-// 128x128x64 on EIGHT waves (2 x 4, 64 x 32 of output each: two waves per SIMD), four-stage LDS-DMA ring: the kernel for
-// shapes of fewer 256 x 256 tiles than the chip has CUs (2048^3 = 64 of them: three quarters of the chip idle on the streams
-// above; as 256 tiles of 128 x 128 every CU works). A 128 x 128 tile moves twice the bytes per FLOP from L2 to LDS (32 KiB per
-// K tile and 512 MFMA cycles = the 64 B/clk a CU can take), so this kernel cannot reach the streams' efficiency and does not
-// try to hand-schedule: two waves per SIMD hide each other's LDS and barrier latency, and the MFMAs of K tile t-1 run while
-// the fragments of tile t are read (two fragment sets), so after the ONE barrier per K tile each wave has MFMAs to issue.
-//   LDS: 4 stages x (A [128 rows][128 B] | B [128 rows][128 B]) = 128 KiB, rows in lane-linear 8-row pieces, chunk ^ (row & 7).
-//   per K tile t, every wave:  vmcnt(own pieces of t landed) . lgkmcnt(0) . barrier . 4 x LDS-DMA of tile t+3 -> the stage
-//   tile t-1 lived in (every wave's reads of it have completed) . 12 x ds_read_b128 of tile t -> set t & 1 . 16 x MFMA of
-//   tile t-1 from the other set.
-// ------------------------------------------------------------------------------------
-#define KLM_P128_STAGE 32768
-#define KLM_P128_LDS (4 * KLM_P128_STAGE)
-
-struct klm_p128_frags {
-  bf16x8 a[2][4], b[2][2];   // [k step][tile]
-};
-
-__global__ __launch_bounds__(512) void gemm_bf16_128p(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
-                                                      uint16_t* __restrict__ C, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
-  int tm, tn;
-  tile_of_block<8>(blockIdx.x, M >> 7, N >> 7, tm, tn);
-  const int brow = tm << 7, bcol = tn << 7;
-  const unsigned ld = (unsigned)K * 2;
-  // staging: wave `wid` brings rows [16 wid, 16 wid + 16) of both operand tiles, two 8-row pieces each
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A) + (size_t)brow * ld), 0,
-                                                                      (int)(128u * ld), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(B) + (size_t)bcol * ld), 0,
-                                                                      (int)(128u * ld), 0x00020000);
-  const unsigned srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const unsigned voff = srow * ld + schunk * 16;
-  const unsigned soff = (unsigned)(16 * wid) * ld;
-  char* const lw = smem + wid * 2048;
-  auto issue = [&](int tile) {
-    char* l = lw + (tile & 3) * KLM_P128_STAGE;
-    const unsigned so = soff + (unsigned)tile * 128u;
-    blds16(ra, voff, so, l);
-    blds16(ra, voff, so + 8 * ld, l + 1024);
-    blds16(rb, voff, so, l + 16384);
-    blds16(rb, voff, so + 8 * ld, l + 16384 + 1024);
+// The 128 x 128 eight-wave ring kernel for shapes of few tiles (variant 14) is gemm_p128.h, shared with the MX formats.
+struct klm_p128_bf16 {
+  struct frags {
+    bf16x8 a[2][4], b[2][2];   // [k step][tile]
   };
-  // fragment reads: row = base + tile * 16 + (lane & 15); 16-byte chunk = ks * 4 + (lane >> 4), swizzled by row & 7
-  const int fr = lane & 15, fq = lane >> 4, key = lane & 7;
+  f32x4 acc[4][2];
   int a_off[2], b_off[2];
+  // fragment reads: row = base + tile * 16 + (lane & 15); 16-byte chunk = ks * 4 + (lane >> 4), swizzled by row & 7
+  __device__ __forceinline__ void init(int lane, int wr, int wc) {
+    const int fr = lane & 15, fq = lane >> 4, key = lane & 7;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int ch = ((ks * 4 + fq) ^ key) << 4;
-    a_off[ks] = (wr * 64 + fr) * 128 + ch;
-    b_off[ks] = 16384 + (wc * 32 + fr) * 128 + ch;
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ((ks * 4 + fq) ^ key) << 4;
+      a_off[ks] = (wr * 64 + fr) * 128 + ch;
+      b_off[ks] = 16384 + (wc * 32 + fr) * 128 + ch;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  auto read = [&](klm_p128_frags& f, int tile) {
-    const char* st = smem + (tile & 3) * KLM_P128_STAGE;
+  __device__ __forceinline__ void read(frags& f, const char* st) const {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -156,13 +122,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_128p(const uint16_t* __restrict
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) f.a[ks][mi] = *reinterpret_cast<const bf16x8*>(st + a_off[ks] + mi * 2048);
     }
-  };
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfma = [&](const klm_p128_frags& f) {
+  }
+  __device__ __forceinline__ void mfma(const frags& f) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -173,46 +134,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_128p(const uint16_t* __restrict
           // X = B rows (n), Y = A rows (m): D[n][m]; a lane holds 4 consecutive n of one m
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ks][ni], f.a[ks][mi], acc[mi][ni], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
-  };
-
-  const int nt = K >> 6;
-  klm_p128_frags f0, f1;
-  issue(0);
-  if (nt > 1) issue(1);
-  if (nt > 2) issue(2);
-  // one K tile: `cur` receives tile t's fragments while the MFMAs of tile t-1 run on `prev`
-  auto step = [&](int t, klm_p128_frags& cur, const klm_p128_frags& prev) {
-    if (t + 2 < nt) KLM_VMCNT(8);          // this wave's pieces of tile t have landed (t+1, t+2 may be in flight)
-    else if (t + 1 < nt) KLM_VMCNT(4);
-    else KLM_VMCNT(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its reads of tile t-1 have completed
-    KLM_BAR();                                            // true for every wave: tile t is whole, tile t-1's stage is free
-    if (t + 3 < nt) issue(t + 3);
-    read(cur, t);
-    if (t > 0) mfma(prev);
-  };
-  int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    step(t, f0, f1);
-    step(t + 1, f1, f0);
   }
-  if (t < nt) {            // odd number of K tiles
-    step(t, f0, f1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    mfma(f0);
-  } else {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    mfma(f1);
-  }
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int m = brow + wr * 64 + mi * 16 + fr;
-      const int n = bcol + wc * 32 + ni * 16 + fq * 4;
-      store_c4(C, (size_t)m * N + n, acc[mi][ni]);
-    }
-}
+};
 
 // ------------------------------------------------------------------------------------
 // 256x256x64, 8 waves: bf16 operand policy for the ring pipeline (gemm_ring256.h).
@@ -458,29 +381,36 @@ extern "C" int klm_gemm_has_diag(void) {
 
 // The plan the persistent streams run an M x N problem with rows of `Kbytes` under: out = {grid, rounds, rest, split, rot}.
 // cus: workgroups available (0: the current device's CU count, or the tests' override). Pure arithmetic apart from that.
+#define KLM_SUPERBLOCK_MIN_BYTES ((size_t)384 << 20)
+
 extern "C" int klm_gemm_stream_plan(int M, int N, int Kbytes, int cus, int mode, int rot, size_t ws_bytes, int* out) {
   if (!out) return KLM_ERR_ARG;
   if (!klm_quad_asm_shape_ok(M, N, Kbytes)) return KLM_ERR_SHAPE;
   if (cus <= 0) cus = klm_quad_p_cus();
   if (cus <= 0) return KLM_ERR_HIP;
+  if (mode == 1 && ((size_t)M + (size_t)N) * (size_t)Kbytes >= KLM_SUPERBLOCK_MIN_BYTES) mode |= 4;      // as klm_gemm_stream does
   const KlmQuadPlan p = klm_quad_plan(M, N, Kbytes, cus, mode, rot, ws_bytes);
-  out[0] = p.grid, out[1] = p.rounds, out[2] = p.rest, out[3] = p.split, out[4] = p.rot;
+  out[0] = p.grid, out[1] = p.rounds, out[2] = p.rest, out[3] = p.split, out[4] = p.rot, out[5] = p.map;
   return KLM_OK;
 }
 
 // The persistent hand-scheduled stream, every option: dtype 0 bf16 / 1 fp8 (e4m3) / 2 fp4 (e2m1 pairs); rows of A and B hold
 // `Kbytes` bytes of K and are `ld_bytes` apart (0: dense); store 1: C written with `sc1 nt`; mode 0: whole tiles only, 1: the
 // last partial round is cut into K slices where that pays (needs `ws`: rest * split * 256 KiB of scratch on the device, at most
-// CUs * 256 KiB), 2: wherever the shape allows (tests); rot > 0: every workgroup starts its K loop `rot` passes after its
+// CUs * 256 KiB), 2: wherever the shape allows (tests), + 4: the super-block tile order where the shape allows it (KlmQuadPlan.map); rot > 0: every workgroup starts its K loop `rot` passes after its
 // neighbour's (dense operands on a row pitch the memory channels camp on).
 extern "C" int klm_gemm_stream(int dtype, const void* A, const void* B, void* C, int M, int N, int Kbytes, int ld_bytes, int store,
                                int mode, int rot, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !B || !C) return KLM_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) return KLM_ERR_ALIGN;
-  if (dtype < 0 || dtype > 2 || store < 0 || store > 1 || mode < 0 || mode > 2 || rot < 0) return KLM_ERR_VARIANT;
+  if (dtype < 0 || dtype > 2 || store < 0 || store > 1 || mode < 0 || mode > 6 || (mode & 3) == 3 || rot < 0) return KLM_ERR_VARIANT;
   if (!klm_quad_asm_shape_ok(M, N, Kbytes, ld_bytes)) return KLM_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (!klm_stream_on_current_device(s)) return KLM_ERR_ARG;
+  // the automatic plan (mode 1) also picks the tile order: super-blocks once the operands are well past the 256 MB Infinity
+  // Cache (12288^3 bf16: +5 - 10 %, 16384^2 x 8192: +5 %; below that the chunked order is 0.5 - 3 % faster:
+  // profiles/r3_prof/gemm_tile_order.json)
+  if (mode == 1 && ((size_t)M + (size_t)N) * (size_t)(ld_bytes ? ld_bytes : Kbytes) >= KLM_SUPERBLOCK_MIN_BYTES) mode |= 4;
   int e;
   switch (dtype * 2 + store) {
     case 0: e = klm_launch_quad_asm_p<0>(A, B, C, M, N, Kbytes, s, ld_bytes, mode, rot, ws, ws_bytes); break;
@@ -524,10 +454,8 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
                        (const uint16_t*)B, (uint16_t*)C, M, N, K);
   } else if (variant == 14) {
     // 128 x 128 tiles on eight waves, four-stage ring: shapes of fewer 256 x 256 tiles than CUs
-    if ((M & 127) || (N & 127) || (K & 63) || (size_t)K * 2 * 128 > 0x7fffffffull) return KLM_ERR_SHAPE;
-    if (int e = klm_ensure_dyn_lds<gemm_bf16_128p>(KLM_P128_LDS)) return e;
-    hipLaunchKernelGGL(gemm_bf16_128p, dim3((M >> 7) * (N >> 7)), dim3(512), KLM_P128_LDS, s, (const uint16_t*)A, (const uint16_t*)B,
-                       (uint16_t*)C, M, N, K);
+    if ((K & 63) || K > 0x3fffffff) return KLM_ERR_SHAPE;
+    if (int e = klm_launch_p128<klm_p128_bf16>(A, B, C, M, N, K * 2, s)) return e;
   } else if (variant == 3) {
     // 4 waves of 128x128; an even number of K tiles >= 4
     if ((M & 255) || (N & 255) || (K & 127) || K < 256) return KLM_ERR_SHAPE;

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gemm_p128.h"
 #include "gemm_quad_asm.h"
 #include "gemm_ring256.h"
 
@@ -118,6 +119,69 @@ struct klm_op_mx {
   }
 };
 
+// The operand policy of the 128 x 128 eight-wave ring kernel (gemm_p128.h) for the MX formats: the same chunks as klm_op_mx
+// above; an accumulator is touched once (fp8) or twice, eight MFMAs apart (fp4), per K tile.
+template <int FMT>
+struct klm_p128_mx {
+  typedef typename klm_mx_frag<FMT>::type frag;
+  struct frags {
+    frag a[2][4], b[2][2];     // [ks][tile]; fp8 uses ks = 0 only
+  };
+  f32x4 acc[4][2];
+  int c0, c1, a_row, b_row;
+  __device__ __forceinline__ void init(int lane, int wr, int wc) {
+    const int fr = lane & 15, fq = lane >> 4, key = lane & 7;
+    c0 = (fq ^ key) << 4;
+    c1 = c0 ^ 64;
+    a_row = (wr * 64 + fr) * 128;
+    b_row = 16384 + (wc * 32 + fr) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void load_frag(frag& f0, frag& f1, const char* base) const {
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(base + c0);
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(base + c1);
+    if constexpr (FMT == 0) {
+      f0 = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else {
+      f0 = lo;
+      f1 = hi;
+    }
+  }
+  __device__ __forceinline__ void read(frags& f, const char* st) const {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) load_frag(f.b[0][ni], f.b[1][ni], st + b_row + ni * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) load_frag(f.a[0][mi], f.a[1][mi], st + a_row + mi * 2048);
+  }
+  // The BUILTIN, not the tied-accumulator asm of klm_op_mx: this kernel's two tails (odd / even K tile count) make the compiler
+  // copy accumulators between register sets, and a VALU read of an accumulator an asm MFMA is still writing is a hazard only
+  // the compiler's recognizer can pad (seen on hardware: wrong sums for odd tile counts). With literal zero scale operands the
+  // compiler selects the plain v_mfma_f32_16x16x128_f8f6f4 (scales 2^0 by definition); 19 register moves in the whole kernel.
+  __device__ __forceinline__ void mfma1(f32x4& c, const frag& x, const frag& y) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (FMT == 0) {
+      c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x, y, c, 0, 0, 0, 0, 0, 0);
+    } else {
+      const i32x8 x8 = i32x8{x[0], x[1], x[2], x[3], 0, 0, 0, 0}, y8 = i32x8{y[0], y[1], y[2], y[3], 0, 0, 0, 0};
+      c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x8, y8, c, 4, 4, 0, 0, 0, 0);
+    }
+#endif
+  }
+  __device__ __forceinline__ void mfma(const frags& f) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < (FMT == 0 ? 1 : 2); ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) mfma1(acc[mi][ni], f.b[ks][ni], f.a[ks][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  }
+};
+
 // K is the row length in BYTES.
 template <int FMT, int SCHED>
 __global__ __launch_bounds__(512) void gemm_mx_256(const uint8_t* __restrict__ A,
@@ -205,6 +269,14 @@ extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N,
                                : klm_launch_quad_asm_p<31>(A, B, C, M, N, K, (hipStream_t)stream)) return e;   // 5: 4 with C streamed (sc1 nt)
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
+  if (variant == 14) {
+    // 128 x 128 tiles on eight waves, four-stage ring (gemm_p128.h): shapes of fewer 256 x 256 tiles than CUs
+    if (!A || !B || !C) return KLM_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
+    if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
+    if (int e = klm_launch_p128<klm_p128_mx<0>>(A, B, C, M, N, K, (hipStream_t)stream)) return e;
+    return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+  }
   if (int e = check_mx(A, B, C, M, N, K, variant)) return e;
   return launch_mx<0>(A, B, C, M, N, K, variant, stream);
 }
@@ -255,6 +327,13 @@ extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N,
                 : variant == 5 ? klm_launch_quad_asm_p<22>(A, B, C, M, N, K >> 1, (hipStream_t)stream)   // 5: 3 on the block-scaled MFMA with unit scales (same bits, slower)
 #endif
                                : klm_launch_quad_asm_p<21>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;   // 4: 3 with C streamed (sc1 nt)
+    return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
+  }
+  if (variant == 14) {
+    if (!A || !B || !C) return KLM_ERR_ARG;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
+    if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
+    if (int e = klm_launch_p128<klm_p128_mx<4>>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
   if (int e = check_mx(A, B, C, M, N, K >> 1, variant)) return e;

@@ -125,7 +125,21 @@ struct KlmQuadPlan {
   int rest;      // r: tiles of the last, partial round (0: none)
   int split;     // S: K slices per tile of the partial round (0 / 1: the partial round runs whole tiles on the first r workgroups)
   int rot;       // K-loop rotation step in passes (0: every tile starts at K = 0)
+  int map;       // 0: tile_of_block (each XCD walks its own contiguous chunk of the tile list); 1: super-blocks (below)
 };
+
+// map 1, for 256 workgroups and tile counts that are multiples of 16 both ways: round w of the chip is ONE 16 x 16 super-block
+// of output tiles (super-blocks row-major, so consecutive rounds share their A panels), inside it XCD x owns an 8 x 4 patch
+// (patches 2 down x 4 across), inside the patch workgroup j = bid >> 3 takes tile (j & 7, j >> 3). What the chip touches in
+// one round is 16 tile rows of A and 16 tile rows of B -- 200 MB at K = 12288 bf16, inside the 256 MB Infinity Cache -- where
+// map 0's eight far-apart chunks touch up to 500 MB.
+__device__ __forceinline__ void klm_quad_superblock_tile(int bid, int w, int tiles_n, int& tm, int& tn) {
+  const int xcd = bid & 7, j = bid >> 3;
+  const int nsc = tiles_n >> 4;
+  const int sr = w / nsc, sc = w - sr * nsc;
+  tm = (sr << 4) + ((xcd & 1) << 3) + (j & 7);
+  tn = (sc << 4) + ((xcd >> 1) << 2) + (j >> 3);
+}
 
 // how many units workgroup `bid` walks under `p` (host and device)
 __host__ __device__ static inline int klm_quad_units_of(const KlmQuadPlan& p, int bid, int passes) {
@@ -162,7 +176,8 @@ __global__ __launch_bounds__(256) void gemm_quad_asm_p(const void* __restrict__ 
     if (i < whole * per_tile) {
       const int w = i / per_tile, seg = i - w * per_tile;
       tile = bid + w * grid;
-      tile_of_block<8>(tile, tiles_m, tiles_n, tm, tn);
+      if (plan.map == 1) klm_quad_superblock_tile(bid, w, tiles_n, tm, tn);
+      else tile_of_block<8>(tile, tiles_m, tiles_n, tm, tn);
       if (per_tile == 1) {
         p0 = 0, np = P;
       } else if (seg == 0) {
@@ -283,7 +298,8 @@ static int klm_quad_p_cus() {
 
 // The plan for an M x N x Kb problem on `cus` workgroups. mode: 0 never split or rotate; 1 split the partial round where the
 // model says it pays; 2 split whenever the shape allows (tests); `rot`: rotate the K loop (camping pitches).
-static inline KlmQuadPlan klm_quad_plan(int M, int N, int Kb, int cus, int mode, int rot, size_t ws_bytes) {
+static inline KlmQuadPlan klm_quad_plan(int M, int N, int Kb, int cus, int mode_flags, int rot, size_t ws_bytes) {
+  const int mode = mode_flags & 3;
   const int ntiles = (M >> 8) * (N >> 8), P = (Kb >> 7) >> 1;
   const int need = (ntiles + KLM_QUAD_P_MAX_TILES - 1) / KLM_QUAD_P_MAX_TILES;     // the table holds 512 units per workgroup
   if (cus < need) cus = need;
@@ -308,6 +324,8 @@ static inline KlmQuadPlan klm_quad_plan(int M, int N, int Kb, int cus, int mode,
     }
   }
   if (rot > 0 && P >= 4 && p.split <= 1) p.rot = rot % P ? rot % P : 1;
+  // mode bit 2: the super-block tile order, where the shape allows it
+  p.map = ((mode_flags & 4) && cus == 256 && p.rest == 0 && p.rounds >= 2 && !((M >> 8) & 15) && !((N >> 8) & 15)) ? 1 : 0;
   return p;
 }
 
@@ -316,7 +334,13 @@ static int klm_launch_quad_asm_p(const void* A, const void* B, void* C, int M, i
                                  int mode = 0, int rot = 0, void* ws = nullptr, size_t ws_bytes = 0) {
   const int cus = klm_quad_p_cus(), P = (Kb >> 7) >> 1;
   if (cus <= 0) return KLM_ERR_HIP;
-  const KlmQuadPlan plan = klm_quad_plan(M, N, Kb, cus, ws ? mode : 0, rot, ws_bytes);
+  const KlmQuadPlan plan = klm_quad_plan(M, N, Kb, cus, ws ? mode : (mode & 4), rot, ws_bytes);
+  if constexpr (BODY == 0 || BODY == 20 || BODY == 30) {
+    // at most one whole tile per workgroup and nothing to split: a persistent workgroup would build a table of one unit.
+    // The one-workgroup-per-tile stream gives the same bits without that (3072^3: +7 %, 4096^3: +1 %, gemm_shape_sweep.json)
+    if ((mode & 3) > 0 && plan.split <= 1 && plan.rot == 0 && plan.rounds + (plan.rest ? 1 : 0) == 1)
+      return klm_launch_quad_asm<BODY>(A, B, C, M, N, Kb, s, ld);
+  }
   const int lds = KLM_QUAD_LDS_BYTES + 32 * KLM_QUAD_P_MAX_TILES;
   if (int e = klm_ensure_dyn_lds<gemm_quad_asm_p<BODY>>(lds)) return e;
   int per = 0;

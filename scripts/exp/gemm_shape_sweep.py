@@ -1,5 +1,8 @@
-"""Square and rectangular shapes: every bf16 kernel next to hipBLASLt (which kernel should `variant=None` pick where?), and
-the fp8 default next to torch._scaled_mm. Interleaved rounds, medians, TFLOP/s."""
+"""The shape sweep the round-2 review asked for: {1024, 2048, 4096, 6144, 8192, 12288}^3 and K in {1024, 2048} at 8192^2
+(plus a few shapes between), `variant=None` of every format next to the vendor library in ONE process, interleaved rounds,
+medians: bf16 against hipBLASLt (torch.matmul), fp8 against torch._scaled_mm; fp4 has no vendor counterpart in this image.
+The forced kernels (persistent stream, 128 x 128 ring kernel) are timed too, so a wrong default shows.
+First: the 128 x 128 ring kernel of the MX formats against the kernels already pinned by the test suite, bit for bit."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -7,27 +10,75 @@ from k8s_llm_monitor_amd import ops
 
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(3)
-shapes = [(1024, 1024, 1024), (2048, 2048, 2048), (3072, 3072, 3072), (4096, 4096, 4096), (6144, 6144, 6144), (8192, 8192, 8192),
-          (12288, 12288, 12288), (16384, 16384, 8192), (8192, 8192, 512), (2048, 8192, 8192), (8192, 28672, 4096), (1024, 16384, 16384),
-          (4096, 4096, 16384), (5120, 5120, 5120)]
+_o = next((x for x in sys.argv[1:] if not x.startswith("--")), "gpurun_out/gemm_shape_sweep.json")
+os.makedirs(os.path.dirname(_o) or ".", exist_ok=True)
+out = {"exact": {}, "shapes": {}}
+for M, N, K in ((128, 128, 128), (128, 256, 256), (256, 384, 384), (640, 384, 640), (1024, 1024, 1024), (2048, 1920, 4224)):
+    a = torch.randint(-3, 4, (M, K), device=dev, generator=g).float()
+    b = torch.randint(-3, 4, (N, K), device=dev, generator=g).float()
+    b[:, 0] = (torch.arange(N, device=dev) % 5).float()
+    want = (a @ b.t()).to(torch.bfloat16)
+    a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+    c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.gemm_fp8(a8, b8, out=c, variant=14)
+    ok8 = bool(torch.equal(c, want))
+    # fp4: codes 0..15 at random, reference through the decode table (exact in fp32 at these sizes)
+    a4 = torch.randint(0, 256, (M, K), device=dev, generator=g, dtype=torch.uint8)       # rows of K bytes = 2 K elements
+    b4 = torch.randint(0, 256, (N, K), device=dev, generator=g, dtype=torch.uint8)
+    want4 = (ops.fp4_decode(a4).double() @ ops.fp4_decode(b4).double().t()).to(torch.bfloat16)
+    c.fill_(float("nan"))
+    ops.gemm_fp4(a4, b4, out=c, variant=14)
+    ok4 = bool(torch.equal(c, want4))
+    torch.cuda.synchronize()
+    out["exact"][f"{M}x{N}x{K}"] = {"fp8_v14": ok8, "fp4_v14": ok4}
+    print(M, N, K, out["exact"][f"{M}x{N}x{K}"], flush=True)
+json.dump(out, open(_o, "w"), indent=1)
+if not all(v for d in out["exact"].values() for v in d.values()):
+    print("MISMATCH")
+    sys.exit(3)
+
+shapes = [(1024, 1024, 1024), (1536, 1536, 1536), (2048, 2048, 2048), (2560, 2560, 2560), (3072, 3072, 3072), (4096, 4096, 4096), (5120, 5120, 5120),
+          (6144, 6144, 6144), (8192, 8192, 8192), (12288, 12288, 12288), (8192, 8192, 1024), (8192, 8192, 2048), (1024, 4096, 4096), (4096, 14336, 4096)]
+if "--quick" in sys.argv:
+    shapes = [s for s in shapes if s[0] <= 4096]
 one = torch.ones((), device=dev)
-out = {}
 for M, N, K in shapes:
     a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
     b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
     c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+    a4 = torch.randint(0, 256, (M, K // 2), device=dev, generator=g, dtype=torch.uint8)
+    b4 = torch.randint(0, 256, (N, K // 2), device=dev, generator=g, dtype=torch.uint8)
     bt, b8t = b.t(), b8.t()
-    cands = {"v0_128": lambda: ops.gemm_bf16(a, b, out=c, variant=0), "v2_ring": lambda: ops.gemm_bf16(a, b, out=c, variant=2),
-             "v4_stream": lambda: ops.gemm_bf16(a, b, out=c, variant=4), "v8_persistent": lambda: ops.gemm_bf16(a, b, out=c, variant=8),
-             "default": lambda: ops.gemm_bf16(a, b, out=c),
-             "hipblaslt": lambda: torch.matmul(a, bt, out=c),
-             "fp8_default": lambda: ops.gemm_fp8(a8, b8, out=c), "fp8_ring": lambda: ops.gemm_fp8(a8, b8, out=c, variant=1),
-             "fp8_scaled_mm": lambda: torch._scaled_mm(a8, b8t, scale_a=one, scale_b=one, out_dtype=torch.bfloat16)}
+    cands = {"bf16": lambda: ops.gemm_bf16(a, b, out=c), "hipblaslt": lambda: torch.matmul(a, bt, out=c),
+             "fp8": lambda: ops.gemm_fp8(a8, b8, out=c), "scaled_mm": lambda: torch._scaled_mm(a8, b8t, scale_a=one, scale_b=one, out_dtype=torch.bfloat16),
+             "fp4": lambda: ops.gemm_fp4(a4, b4, out=c)}
+    if ops.camping_pitch(2 * K) or ops.camping_pitch(K):
+        # the framework's own operand layout (ops.padded_operand: what the load generator allocates): rows 128 bytes further apart
+        pa, pb = ops.padded_operand(M, K, torch.bfloat16, dev), ops.padded_operand(N, K, torch.bfloat16, dev)
+        pa.copy_(a); pb.copy_(b)
+        pa8, pb8 = ops.padded_operand(M, K, torch.float8_e4m3fn, dev), ops.padded_operand(N, K, torch.float8_e4m3fn, dev)
+        pa8.copy_(a8); pb8.copy_(b8)
+        pbt, pb8t = pb.t(), pb8.t()
+        cands["bf16_padded_operands"] = lambda: ops.gemm_bf16(pa, pb, out=c)
+        cands["hipblaslt_padded_operands"] = lambda: torch.matmul(pa, pbt, out=c)
+        cands["fp8_padded_operands"] = lambda: ops.gemm_fp8(pa8, pb8, out=c)
+    if ops.stream_shape_ok(M, N, 2 * K):
+        cands["bf16_stream"] = lambda: ops.gemm_bf16(a, b, out=c, variant=10)
+        cands["bf16_one_wg_per_tile"] = lambda: ops.gemm_bf16(a, b, out=c, variant=4)
+    if ops.stream_shape_ok(M, N, K):
+        cands["fp8_stream"] = lambda: ops.gemm_fp8(a8, b8, out=c, variant=7)
+        cands["fp8_one_wg_per_tile"] = lambda: ops.gemm_fp8(a8, b8, out=c, variant=2)
+    if ops.stream_shape_ok(M, N, K // 2):
+        cands["fp4_stream"] = lambda: ops.gemm_fp4(a4, b4, out=c, variant=6)
+    if (M // 128) * (N // 128) <= 2048:
+        cands["bf16_p128"] = lambda: ops.gemm_bf16(a, b, out=c, variant=14)
+        cands["fp8_p128"] = lambda: ops.gemm_fp8(a8, b8, out=c, variant=14)
+        cands["fp4_p128"] = lambda: ops.gemm_fp4(a4, b4, out=c, variant=14)
     flop = 2.0 * M * N * K
-    iters = max(5, min(50, int(2e13 / flop)))
+    iters = max(5, min(200, int(4e12 / flop)))
     runs = {k: [] for k in cands}
-    for r in range(4):
+    for r in range(6):
         for name, fn in cands.items():
             fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,9 +88,23 @@ for M, N, K in shapes:
             e1.record(); e1.synchronize()
             if r:
                 runs[name].append(flop * iters / (e0.elapsed_time(e1) * 1e-3) / 1e12)
-    out[f"{M}x{N}x{K}"] = {k: sorted(v)[len(v) // 2] for k, v in runs.items()}
-    print(f"{M}x{N}x{K}", {k: round(v) for k, v in out[f"{M}x{N}x{K}"].items()}, flush=True)
-    del a, b, c, a8, b8
-_o = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gemm_shape_sweep.json"
-os.makedirs(os.path.dirname(_o) or ".", exist_ok=True)
+    med = {k: round(sorted(v)[len(v) // 2], 1) for k, v in runs.items()}
+    if "bf16_padded_operands" in med:
+        med["bf16_padded_over_hipblaslt_best"] = round(med["bf16_padded_operands"] / max(med["hipblaslt"], med["hipblaslt_padded_operands"]), 3)
+        med["fp8_padded_over_scaled_mm"] = round(med["fp8_padded_operands"] / med["scaled_mm"], 3)
+    row = {"tflops": med, "bf16_over_hipblaslt": round(med["bf16"] / med["hipblaslt"], 3), "fp8_over_scaled_mm": round(med["fp8"] / med["scaled_mm"], 3),
+           "picked": {"bf16": ops.pick_bf16_variant(M, N, K), "fp8": ops.pick_mx_variant(M, N, K, 0, 7), "fp4": ops.pick_mx_variant(M, N, K // 2, 0, 6)},
+           "us": {k: round(flop / v / 1e6, 1) for k, v in med.items() if "_over_" not in k},
+           "model_us": {f: {"stream": round(ops.stream_time_us(M, N, kb), 1) if ops.stream_shape_ok(M, N, kb) else None, "p128": round(ops.p128_time_us(M, N, kb), 1)}
+                        for f, kb in (("bf16", 2 * K), ("fp8", K), ("fp4", K // 2))}}
+    out["shapes"][f"{M}x{N}x{K}"] = row
+    print(f"{M}x{N}x{K}", json.dumps(row), flush=True)
+    json.dump(out, open(_o, "w"), indent=1)
+    del a, b, c, a8, b8, a4, b4
+    pa = pb = pa8 = pb8 = pbt = pb8t = None
+r = out["shapes"].values()
+out["summary"] = {"bf16_min_ratio": min(x["bf16_over_hipblaslt"] for x in r), "fp8_min_ratio": min(x["fp8_over_scaled_mm"] for x in r),
+                  "bf16_below_0.97": [k for k, x in out["shapes"].items() if x["bf16_over_hipblaslt"] < 0.97],
+                  "fp8_below_0.97": [k for k, x in out["shapes"].items() if x["fp8_over_scaled_mm"] < 0.97]}
+print(json.dumps(out["summary"]))
 json.dump(out, open(_o, "w"), indent=1)

@@ -51,7 +51,7 @@ for M, N, K in ((512, 512, 512), (1024, 1024, 1024), (1536, 1536, 1536), (2048, 
     med = {k: round(sorted(v)[len(v) // 2], 1) for k, v in runs.items()}
     med["tiles_256"] = (M // 256) * (N // 256)
     med["picked"] = ops.pick_bf16_variant(M, N, K)
-    med["model_us"] = {"p128": round(ops.p128_time_us(M, N, K), 1), "stream": round(ops.stream_time_us(M, N, K), 1) if "v10_stream" in cands else None}
+    med["model_us"] = {"p128": round(ops.p128_time_us(M, N, 2 * K), 1), "stream": round(ops.stream_time_us(M, N, 2 * K), 1) if "v10_stream" in cands else None}
     med["measured_us"] = {k: round(flop / v / 1e6, 1) for k, v in med.items() if k in runs}
     med["default_over_hipblaslt"] = round(med["default"] / med["hipblaslt"], 3)
     med["best_klm_over_hipblaslt"] = round(max(v for k, v in med.items() if k.startswith("v")) / med["hipblaslt"], 3)

@@ -76,7 +76,8 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
             assert torch.equal(ops.gemm_bf16(x, y, variant=14), c14), K
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096), (256, 512, 512), (768, 256, 4608)])
+@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096), (256, 512, 512), (768, 256, 4608),
+                                   (128, 128, 128), (384, 640, 640), (128, 256, 4224), (2048, 2048, 2048)])
 def test_gemm_fp8_matches_fp32_reference(env, shape):
     torch, ops, dev = env
     M, N, K = shape
@@ -86,7 +87,11 @@ def test_gemm_fp8_matches_fp32_reference(env, shape):
     c = ops.gemm_fp8(a, b)                               # the hand-scheduled stream where K allows, else the ring kernel
     ref = a.float() @ b.float().t()                      # the fp8 VALUES are exact in fp32
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=2e-3 * K ** 0.5)
-    # every pipeline sums an element's products in the same order: same bits
+    # every pipeline sums an element's products in the same order: same bits (14: the eight-wave 128 x 128 ring kernel, the
+    # default for shapes of few tiles; K tile counts 1, 3, 5, 33 and even ones)
+    assert torch.equal(c, ops.gemm_fp8(a, b, variant=14))
+    if M % 256 or N % 256:
+        return
     assert torch.equal(c, ops.gemm_fp8(a, b, variant=0)) and torch.equal(c, ops.gemm_fp8(a, b, variant=1))
     if K % 256 == 0 and K >= 512:
         assert torch.equal(c, ops.gemm_fp8(a, b, variant=2)) and torch.equal(c, ops.gemm_fp8(a, b, variant=7))
@@ -107,7 +112,8 @@ def test_gemm_fp8_exact_on_small_integers(env):
     assert torch.equal(c, (a @ b.t()).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 512), (512, 768, 1024), (1024, 512, 8192), (256, 512, 1536), (512, 256, 768)])
+@pytest.mark.parametrize("shape", [(256, 256, 512), (512, 768, 1024), (1024, 512, 8192), (256, 512, 1536), (512, 256, 768),
+                                   (128, 128, 256), (384, 640, 1280), (128, 256, 8448), (2048, 2048, 2048)])
 def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     """e2m1 values are multiples of 0.5 up to 6: products and fp32 sums of a few thousand of them are
     exact, so the only rounding is the bf16 store."""
@@ -118,15 +124,18 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     b = torch.randint(0, 256, (N, K // 2), device=dev, generator=g, dtype=torch.uint8)
     a[:, 3] = (torch.arange(M, device=dev) % 251).to(torch.uint8)            # position- and row-dependent bytes
     b[:, K // 2 - 5] = (torch.arange(N, device=dev) % 239).to(torch.uint8)
-    c = ops.gemm_fp4(a, b)                                                    # the hand-scheduled stream where the shape allows
+    c = ops.gemm_fp4(a, b)                                                    # the hand-scheduled stream / the 128 x 128 ring kernel, by shape
+    ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
+    assert torch.equal(c, ref.float().to(torch.bfloat16))
+    assert torch.equal(c, ops.gemm_fp4(a, b, variant=14))                     # the eight-wave 128 x 128 ring kernel: K tile counts 1, 5, 33, even
+    if M % 256 or N % 256:
+        return
     assert torch.equal(c, ops.gemm_fp4(a, b, variant=0)) and torch.equal(c, ops.gemm_fp4(a, b, variant=1))
     if (K // 2) % 256 == 0 and K // 2 >= 512:
         assert torch.equal(c, ops.gemm_fp4(a, b, variant=2)) and torch.equal(c, ops.gemm_fp4(a, b, variant=3))
         assert torch.equal(c, ops.gemm_fp4(a, b, variant=4)) and torch.equal(c, ops.gemm_fp4(a, b, variant=6))
         if ops.gemm_has_diag():
             assert torch.equal(c, ops.gemm_fp4(a, b, variant=5))
-    ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
-    assert torch.equal(c, ref.float().to(torch.bfloat16))
     if hasattr(torch, "float4_e2m1fn_x2"):
         assert torch.equal(ops.gemm_fp4(a.view(torch.float4_e2m1fn_x2), b.view(torch.float4_e2m1fn_x2)), c)
 
@@ -200,6 +209,30 @@ def test_gemm_streams_take_row_pitched_operands(env, pad_bytes):
     assert ops.padded_operand(256, 8192, torch.bfloat16, dev).is_contiguous() and ops.padded_operand(256, 12032, torch.bfloat16, dev).is_contiguous()
 
 
+def test_superblock_tile_order_gives_the_same_product(env):
+    """The persistent streams' second tile order (KlmQuadPlan.map = 1: one 16 x 16 super-block of tiles per round of the chip,
+    an 8 x 4 patch per XCD; picked by itself for operands well past the Infinity Cache): every tile exactly once, the same bits
+    as the chunked order."""
+    torch, ops, dev = env
+    if torch.cuda.get_device_properties(dev).multi_processor_count != 256:
+        pytest.skip("the super-block order is defined for 256 workgroups")
+    g = torch.Generator(device=dev).manual_seed(15)
+    for M, N, K in ((4096, 8192, 512), (8192, 4096, 768)):
+        assert ops.gemm_stream_plan(M, N, 2 * K, mode=5)["map"] == 1
+        a = torch.randint(-3, 4, (M, K), device=dev, generator=g).float()
+        b = torch.randint(-3, 4, (N, K), device=dev, generator=g).float()
+        b[:, 0] = (torch.arange(N, device=dev) % 5).float()
+        a[:, 1] = (torch.arange(M, device=dev) % 7).float() - 3
+        want = (a @ b.t()).to(torch.bfloat16)
+        c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        assert torch.equal(ops.gemm_bf16(a.to(torch.bfloat16), b.to(torch.bfloat16), out=c, variant=15), want)
+        c.fill_(float("nan"))
+        assert torch.equal(ops.gemm_fp8(a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn), out=c, variant=9), want)
+        x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        y = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+        assert torch.equal(ops.gemm_bf16(x, y, variant=15), ops.gemm_bf16(x, y, variant=13))
+
+
 def test_default_dispatch_over_random_shapes(env):
     """`variant=None` over random tile-aligned shapes (every kernel family gets picked: 128 x 128, ring, persistent stream,
     padded operands): bf16 against the fp32 product, fp8 / fp4 against their ring kernels bit for bit."""
@@ -214,6 +247,13 @@ def test_default_dispatch_over_random_shapes(env):
         b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
         c = ops.gemm_bf16(a, b)
         torch.testing.assert_close(c.float(), a.float() @ b.float().t(), rtol=1.6e-2, atol=6e-3 * K ** 0.5, msg=lambda m: f"{M}x{N}x{K}: {m}")
+        if K % 128 == 0 and (M % 256 or N % 256):
+            # only the 128 x 128 ring kernel takes these: fp8 against the fp32 product, fp4 (rows of K bytes) against its decode
+            a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+            torch.testing.assert_close(ops.gemm_fp8(a8, b8).float(), a8.float() @ b8.float().t(), rtol=1.6e-2, atol=2e-3 * K ** 0.5)
+            a4 = torch.randint(0, 256, (M, K), device=dev, generator=g, dtype=torch.uint8)
+            b4 = torch.randint(0, 256, (N, K), device=dev, generator=g, dtype=torch.uint8)
+            assert torch.equal(ops.gemm_fp4(a4, b4), (ops.fp4_decode(a4).double() @ ops.fp4_decode(b4).double().t()).float().to(torch.bfloat16)), (M, N, K)
         if M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and K >= 256:
             a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
             assert torch.equal(ops.gemm_fp8(a8, b8), ops.gemm_fp8(a8, b8, variant=1)), (M, N, K)
@@ -357,6 +397,46 @@ def test_hbm_kernels(env):
     odd = torch.zeros(16 * 3, dtype=torch.uint8, device=dev)                   # smaller than one grid pass
     ops.hbm_fill(odd, 0xFFFFFFFF)
     assert bool((odd == 255).all())
+
+
+def test_hbm_kernels_past_one_launch_of_the_grid_limit(env):
+    """64 GiB and more cannot be one launch (HIP bounds gridDim.x * blockDim.x by 2^32 - 1): the default kernels walk such a
+    buffer in sub-range launches (klm_hbm_launch_plan). 66 GiB here: filled, summed, copied, spot-checked on both sides of
+    every launch boundary and at the very end."""
+    torch, ops, dev = env
+    GIB = 1 << 30
+    n = 66 * GIB
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 2 * n + 8 * GIB:
+        pytest.skip(f"needs {2 * n >> 30} GiB of free HBM, {free >> 30} GiB are")
+    launches, first, last = ops.hbm_launch_plan(n)
+    assert launches == 2 and first * 256 <= 0xFFFFFFFF and (launches - 1) * first + last == n // 4096
+    x = torch.empty(n, dtype=torch.uint8, device=dev)
+    try:
+        ops.hbm_fill(x, 0x0A0B0C0D)
+        w = x.view(torch.int32)
+        edge = first * 4096 // 4                                   # first int32 of the second launch
+        for i in (0, 1, edge - 1, edge, edge + 1, n // 4 - 1):
+            assert int(w[i]) == 0x0A0B0C0D, i
+        assert ops.hbm_checksum(x) == 0x0A0B0C0D * (n // 4)
+        # a copy across the boundary: mark positions on both sides, copy, read them back
+        marks = {0: 1, edge - 1: 2, edge: 3, n // 4 - 1: 4, (n // 4) // 3: 5}
+        for i, v in marks.items():
+            w[i] = v
+        y = torch.empty(n, dtype=torch.uint8, device=dev)
+        ops.hbm_copy(y, x)
+        wy = y.view(torch.int32)
+        for i, v in marks.items():
+            assert int(wy[i]) == v, i
+        assert int(wy[edge + 1]) == 0x0A0B0C0D
+        assert ops.hbm_checksum(y) == ops.hbm_checksum(x)
+        sink = torch.zeros(4, dtype=torch.int32, device=dev)
+        ops.hbm_read(y, sink)
+        torch.cuda.synchronize()
+    finally:
+        del x
+        y = w = wy = None
+        torch.cuda.empty_cache()
 
 
 def test_kernels_run_on_the_current_stream_and_capture_into_a_graph(env):

@@ -97,14 +97,19 @@ def test_stream_plan_splits_the_partial_round_only_where_it_pays():
         pytest.skip("hipcc not installed")
     build.build_all(only=["klm_ops"], verbose=False)
     plan = lambda M, N, K, **kw: ops.gemm_stream_plan(M, N, 2 * K, cus=256, **kw)
-    assert plan(8192, 8192, 8192) == {"grid": 256, "rounds": 4, "rest": 0, "split": 0, "rot": 0}
-    assert plan(6144, 6144, 6144) == {"grid": 256, "rounds": 2, "rest": 64, "split": 4, "rot": 0}
+    assert plan(8192, 8192, 8192) == {"grid": 256, "rounds": 4, "rest": 0, "split": 0, "rot": 0, "map": 0}
+    assert plan(6144, 6144, 6144) == {"grid": 256, "rounds": 2, "rest": 64, "split": 4, "rot": 0, "map": 0}
     assert plan(6144, 6144, 1536)["split"] == 0 and plan(6144, 6144, 1536, mode=2)["split"] == 4       # K too short to pay for the partial sums
-    assert plan(2048, 2048, 2048) == {"grid": 64, "rounds": 0, "rest": 64, "split": 0, "rot": 0}       # 64 MB of partial sums cost more than they save
-    assert plan(2048, 2048, 2048, mode=2) == {"grid": 256, "rounds": 0, "rest": 64, "split": 4, "rot": 0}
+    assert plan(2048, 2048, 2048) == {"grid": 64, "rounds": 0, "rest": 64, "split": 0, "rot": 0, "map": 0}       # 64 MB of partial sums cost more than they save
+    assert plan(2048, 2048, 2048, mode=2) == {"grid": 256, "rounds": 0, "rest": 64, "split": 4, "rot": 0, "map": 0}
     assert plan(4096, 6144, 4096)["split"] == 2 and plan(4096, 6144, 4096, mode=0)["split"] == 0
     assert plan(6144, 6144, 6144, ws_bytes=64 * 2 * ops.SLOT_BYTES)["split"] == 2 and plan(6144, 6144, 6144, ws_bytes=0)["split"] == 0   # bounded by the scratch
     assert plan(5120, 5120, 5120)["split"] == 0                                                        # 144 left of 256: nothing to split into
+    # + 4: the super-block tile order, for 256 workgroups and tile counts that are multiples of 16 both ways, from two rounds on
+    assert plan(8192, 8192, 8192, mode=5)["map"] == 1 and plan(12288, 12288, 4096, mode=5)["map"] == 1 and plan(8192, 8192, 8192, mode=1)["map"] == 0
+    # the automatic plan takes it once the operands are well past the Infinity Cache
+    assert plan(12288, 12288, 12288)["map"] == 1 and plan(16384, 16384, 8192)["map"] == 1 and plan(12288, 12288, 6144)["map"] == 0 and plan(12288, 12288, 12288, mode=0)["map"] == 0
+    assert plan(4096, 4096, 4096, mode=5)["map"] == 0 and plan(6144, 6144, 6144, mode=5)["map"] == 0 and plan(8192, 12288, 4096, mode=4)["map"] == 1
     assert plan(8192, 8192, 8192, mode=0, rot=16)["rot"] == 16 and plan(8192, 8192, 8192, mode=0, rot=64)["rot"] == 1
     # every slice gets at least two passes, at most 8 slices, and the slices' passes add up (the kernel's arithmetic, mirrored)
     for M, N, K in ((256, 256, 512), (256, 512, 1024), (768, 768, 1024), (1536, 1536, 12288)):
@@ -137,11 +142,15 @@ def test_default_bf16_kernel_follows_the_cost_model_and_the_measurements():
     assert pick(2048, 2048, 8192) == 10 and pick(1024, 1024, 16384) == 10 and pick(2048, 6144, 4096) == 10 and pick(8192, 8192, 1024) == 10
     assert pick(2048, 2048, 2048, pitch=4352) == 10                 # pitched operands: only the streams take them
     assert pick(100, 128, 64) == 0 and pick(4096, 4096, 192) == 1 and pick(1024, 1024, 192) == 14
+    # fp8 / fp4 go by the bytes of a row: the same rule, their own stream variants
+    assert ops.pick_mx_variant(2048, 2048, 2048, 0, 7) == 14 and ops.pick_mx_variant(8192, 8192, 8192, 0, 7) == 7 and ops.pick_mx_variant(4096, 4096, 2048, 0, 6) == 6
+    assert ops.pick_mx_variant(2048, 2048, 2048, 4352, 7) == 7 and ops.pick_mx_variant(256, 256, 384, 0, 7) == 14 and ops.pick_mx_variant(4096, 4096, 384, 0, 7) == 1
+    assert ops.pick_mx_variant(384, 128, 128, 0, 6) == 14
     # the modelled times are the measured ones to ~15 %
     for (M, N, K), us in (((2048, 2048, 2048), 22.4), ((1024, 1024, 1024), 10.6), ((2048, 2048, 8192), 70.2)):
-        assert abs(ops.p128_time_us(M, N, K) - us) / us < 0.15
+        assert abs(ops.p128_time_us(M, N, 2 * K) - us) / us < 0.15
     for (M, N, K), us in (((4096, 4096, 4096), 94.8), ((3072, 3072, 3072), 57.5), ((8192, 8192, 8192), 687.0)):
-        assert abs(ops.stream_time_us(M, N, K) - us) / us < 0.15
+        assert abs(ops.stream_time_us(M, N, 2 * K) - us) / us < 0.15
 
 
 def test_repack_rule_and_camping_pitch_are_pure_and_selective():

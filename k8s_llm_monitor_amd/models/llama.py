@@ -149,7 +149,10 @@ class PrefillMeta:
 
 class LlamaModel:
     WIDE_ROWS = 256      # largest row count an 8B-class model sends to the K-split tiled GEMM (see lib_projections)
-    OWN_GEMM_MIN_ROWS = 2048   # rows from which `_stack`'s projections run on ops.gemm_bf16 (token rows padded to 256)
+    # rows from which `_stack`'s projections run on ops.gemm_bf16 (token rows padded to 256). 256: whole prefills of 256 .. 2048
+    # tokens are 1.00 - 1.08x the hipBLASLt path since the 128 x 128 ring kernel took the few-tile shapes
+    # (profiles/r3_llm/prefill_small_rows.json; 2048 before)
+    OWN_GEMM_MIN_ROWS = 256
 
     """`tp`: a parallel.tp group. With more than one rank this instance holds ONE shard (Megatron layout: q/k/v
     heads, gate/up rows and vocabulary rows split by rank; wo and w_down split along their input, their partial
@@ -190,7 +193,7 @@ class LlamaModel:
         self.lib_proj: Optional[frozenset] = None                 # overrides lib_projections() (benchmarks)
         self.wide = True                                           # 129 - 256 rows on the K-split tiled GEMM (else hipBLASLt)
         # the library path's projections (`_stack`: prefill, batches beyond 256 rows) on this repo's persistent bf16 stream
-        # from OWN_GEMM_MIN_ROWS rows on (below, a few dozen 256 x 256 tiles leave most CUs idle: hipBLASLt, labelled)
+        # from OWN_GEMM_MIN_ROWS rows on
         self.own_gemm = True
         self._pad: Dict[tuple, torch.Tensor] = {}                  # token-dimension padding scratch, per (rows, K)
         self.fused_rope = True                                     # skinny decode path: RoPE + cache write inside the attention kernel

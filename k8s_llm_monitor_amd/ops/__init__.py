@@ -206,9 +206,9 @@ _SPLIT_PASS_US, _SPLIT_MB_US, _SPLIT_LAUNCH_US = 2.2, 0.30, 8.0      # klm_quad_
 _SPLIT_TIME_MB_US = 0.13               # what the partial sums were measured to add (64 MB: 8 us on top of the reduce launch)
 
 
-def _per_kb(pair, occupancy: float) -> float:
+def _per_kb(pair, occupancy: float, power: int = 1) -> float:
     lo, hi = pair
-    return lo + (hi - lo) * min(1.0, max(0.0, (occupancy - 0.25) / 0.75))
+    return lo + (hi - lo) * min(1.0, max(0.0, (occupancy - 0.25) / 0.75)) ** power
 
 
 def stream_plan_py(M: int, N: int, Kbytes: int, cus: int = 256, mode: int = 1):
@@ -232,9 +232,9 @@ def stream_time_us(M: int, N: int, Kbytes: int, cus: int = 256) -> float:
     t = _STREAM_FIXED_US + rounds * Kbytes * _STREAM_US_PER_KB[1]
     if rest:
         if S > 1:
-            t += Kbytes * _per_kb(_STREAM_US_PER_KB, rest * S / cus) / S + _SPLIT_LAUNCH_US + _SPLIT_TIME_MB_US * rest * S * 0.25
+            t += Kbytes * _per_kb(_STREAM_US_PER_KB, rest * S / cus, 2) / S + _SPLIT_LAUNCH_US + _SPLIT_TIME_MB_US * rest * S * 0.25
         else:
-            t += Kbytes * _per_kb(_STREAM_US_PER_KB, rest / cus)
+            t += Kbytes * _per_kb(_STREAM_US_PER_KB, rest / cus, 2)      # measured convex in the occupancy (3072^3, 3584^3)
     return t
 
 

@@ -211,6 +211,6 @@ def test_bench_value_does_not_move_with_steps(tmp_path):
                             "--detail-out", str(tmp_path / f"d{steps}.json")], cwd=ROOT, capture_output=True, text=True, timeout=180)
         assert r.returncode == 0, r.stderr[-2000:]
         d, _ = check_bench_line(r.stdout, 1, steps, warm)
-        assert d["gemm_variant"] == 8 and d["gemm_variant_dp_kernel"] == 4 and d["value_dp_kernel"] > 0.9 * d["value"]
+        assert d["gemm_variant"] == 10 and d["gemm_variant_dp_kernel"] == 4 and d["value_dp_kernel"] > 0.9 * d["value"]
         vals[steps] = d["value"]
     assert abs(vals[20] - vals[100]) / vals[100] < 0.015, vals

@@ -11,6 +11,7 @@ load generators of SURVEY.md 2.4 (N2 GEMM burner, N3 HBM fill, N4 bandwidth burn
 from __future__ import annotations
 
 import ctypes
+import functools
 import threading
 from pathlib import Path
 from typing import Optional
@@ -201,6 +202,8 @@ def hbm_launch_plan(nbytes: int, accesses_per_thread: int = 1):
 #: CUs: higher clocks, more L2 bandwidth each); per byte, because both kernels stage 128-byte K tiles whatever the format:
 _STREAM_US_PER_KB = (0.0073, 0.0106)    # 256 x 256 tile, persistent stream (bf16 10, fp8 7, fp4 6)
 _P128_US_PER_KB = (0.0020, 0.0039)      # 128 x 128 tile, eight-wave ring kernel (14)
+_P256_US_PER_KB = (0.0056, 0.0070)      # 256 x 128 / 128 x 256 tile, the same kernel (16 / 17): 7 % less per FLOP than 14 on a full chip
+_P128_SECOND_ROUND_US_PER_KB = 0.0032   # measured: 2304^3, 2560^3, 1024 x 6144 x 4096 (profiles/r3_prof/gemm_mid.json)
 _STREAM_FIXED_US, _P128_FIXED_US = 8.0, 6.5
 _SPLIT_PASS_US, _SPLIT_MB_US, _SPLIT_LAUNCH_US = 2.2, 0.30, 8.0      # klm_quad_plan's decision rule (gemm_quad_asm.h)
 _SPLIT_TIME_MB_US = 0.13               # what the partial sums were measured to add (64 MB: 8 us on top of the reduce launch)
@@ -241,7 +244,20 @@ def stream_time_us(M: int, N: int, Kbytes: int, cus: int = 256) -> float:
 def p128_time_us(M: int, N: int, Kbytes: int, cus: int = 256) -> float:
     """Modelled time of the eight-wave 128 x 128 ring kernel (one workgroup per CU at a time: 128 KiB of LDS each)."""
     rounds, rest = divmod((M // 128) * (N // 128), cus)
-    return _P128_FIXED_US + rounds * Kbytes * _P128_US_PER_KB[1] + (Kbytes * _per_kb(_P128_US_PER_KB, rest / cus) if rest else 0.0)
+    per = _per_kb(_P128_US_PER_KB, rest / cus)
+    if rounds:
+        per = max(per, _P128_SECOND_ROUND_US_PER_KB)      # a partial round BEHIND a full one never runs at the empty chip's rate
+    return _P128_FIXED_US + rounds * Kbytes * _P128_US_PER_KB[1] + (Kbytes * per if rest else 0.0)
+
+
+def p256_time_us(M: int, N: int, Kbytes: int, cus: int = 256) -> float:
+    """Modelled time of the ring kernel on 256 x 128 (or 128 x 256) tiles: three 48 KiB stages, one workgroup per CU."""
+    rounds, rest = divmod((M * N) // (256 * 128), cus)
+    return _P128_FIXED_US + rounds * Kbytes * _P256_US_PER_KB[1] + (Kbytes * _per_kb(_P256_US_PER_KB, rest / cus) if rest else 0.0)
+
+
+def p256_shape_ok(M: int, N: int, Kbytes: int) -> bool:
+    return p128_shape_ok(M, N, Kbytes) and (M % 256 == 0 or N % 256 == 0)
 
 
 def stream_shape_ok(M: int, N: int, Kbytes: int) -> bool:
@@ -252,40 +268,53 @@ def p128_shape_ok(M: int, N: int, Kbytes: int) -> bool:
     return M > 0 and N > 0 and M % 128 == 0 and N % 128 == 0 and Kbytes % 128 == 0 and Kbytes >= 128
 
 
+@functools.lru_cache(maxsize=4096)
 def pick_tile_kernel(M: int, N: int, Kbytes: int, cus: int = 256) -> Optional[str]:
-    """"stream" (256 x 256 persistent), "p128" (128 x 128 eight-wave ring) or None (neither takes the shape): whichever the
-    cost model prices lower. Pure: no device, no library."""
-    s_ok, p_ok = stream_shape_ok(M, N, Kbytes), p128_shape_ok(M, N, Kbytes)
-    if s_ok and p_ok:
-        return "p128" if p128_time_us(M, N, Kbytes, cus) < stream_time_us(M, N, Kbytes, cus) else "stream"
-    return "stream" if s_ok else "p128" if p_ok else None
+    """"stream" (256 x 256 persistent), "p128" / "p256" (the eight-wave ring kernel on 128 x 128 / 256 x 128 tiles) or None (none
+    takes the shape): whichever the cost model prices lowest. Pure: no device, no library."""
+    cands = []
+    if stream_shape_ok(M, N, Kbytes):
+        cands.append((stream_time_us(M, N, Kbytes, cus), 0, "stream"))
+    if p256_shape_ok(M, N, Kbytes):
+        cands.append((p256_time_us(M, N, Kbytes, cus), 1, "p256"))
+    if p128_shape_ok(M, N, Kbytes):
+        cands.append((p128_time_us(M, N, Kbytes, cus), 2, "p128"))
+    return min(cands)[2] if cands else None
+
+
+def _ring_fallback(M: int, N: int, Kbytes: int, cus: int) -> bool:
+    """Whole 256 x 256 tiles with an odd number of K tiles: the 256 x 256 ring kernel's schedule 0 takes them, and wins once
+    its tiles fill half the chip."""
+    return (not stream_shape_ok(M, N, Kbytes) and M % 256 == 0 and N % 256 == 0 and Kbytes >= 256 and (M // 256) * (N // 256) >= cus // 2)
 
 
 def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0, cus: int = 256) -> int:
     """The kernel `gemm_bf16(variant=None)` runs for a shape (pure: no device, no library): the persistent 256 x 256 stream
-    (10) or, where fewer 256 x 256 tiles than CUs leave most of the chip idle, the 128 x 128 ring kernel (14: 2048^3 807
-    TFLOP/s against 465), whichever the cost model prices lower; the ring / old 128 x 128 kernels for shapes neither takes."""
+    (10) or, where too few 256 x 256 tiles leave most of the chip idle, the eight-wave ring kernel on 128 x 128 tiles (14: 2048^3
+    807 TFLOP/s against 465) or on 256 x 128 / 128 x 256 tiles (16 / 17: 2560^3 43.4 -> 38.8 us), whichever the cost model prices
+    lowest; the 256 x 256 ring / old 128 x 128 kernels for shapes none of them takes."""
     if pitch:
         return 10              # row-pitched operands: the streams are the kernels that take a pitch
     kind = pick_tile_kernel(M, N, 2 * K, cus)
     if kind == "stream":
         return 10
-    if kind == "p128":
-        # the ring's schedule 0 takes whole 256 x 256 tiles with an odd number of K tiles; it wins once its tiles fill half the chip
-        if not stream_shape_ok(M, N, 2 * K) and M % 256 == 0 and N % 256 == 0 and K >= 128 and (M // 256) * (N // 256) >= cus // 2:
+    if kind in ("p128", "p256"):
+        if _ring_fallback(M, N, 2 * K, cus):
             return 1
-        return 14
+        return 14 if kind == "p128" else (16 if M % 256 == 0 else 17)
     return 0
 
 
 def pick_mx_variant(M: int, N: int, Kbytes: int, pitch: int, stream_variant: int, cus: int = 256) -> int:
-    """fp8 / fp4 (`Kbytes`: a row's bytes): the persistent stream with its plan, the 128 x 128 ring kernel (14) where the
-    model prices it lower, else the 256 x 256 ring kernel (1)."""
+    """fp8 / fp4 (`Kbytes`: a row's bytes): the persistent stream with its plan, the ring kernel on 128 x 128 (14) or 128 x 256 /
+    256 x 128 tiles (17 / 16) where the model prices it lower, else the 256 x 256 ring kernel (1)."""
     if pitch:
         return stream_variant
     kind = pick_tile_kernel(M, N, Kbytes, cus)
-    if kind == "p128" and not stream_shape_ok(M, N, Kbytes) and M % 256 == 0 and N % 256 == 0 and Kbytes >= 256 and (M // 256) * (N // 256) >= cus // 2:
+    if kind in ("p128", "p256") and _ring_fallback(M, N, Kbytes, cus):
         return 1
+    if kind == "p256":
+        return 17 if N % 256 == 0 else 16
     return {"stream": stream_variant, "p128": 14, None: 1}[kind]
 
 
@@ -301,6 +330,8 @@ def stream_workspace(device, nbytes: int = 0):
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _ws_cache.get(key)
+    if ws is not None and ws.numel() >= nbytes:
+        return ws
     need = max(int(nbytes), torch.cuda.get_device_properties(dev).multi_processor_count * SLOT_BYTES)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)

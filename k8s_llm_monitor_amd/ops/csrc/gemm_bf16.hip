@@ -94,31 +94,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const uint16_t* __restrict_
 
 
 // The 128 x 128 eight-wave ring kernel for shapes of few tiles (variant 14) is gemm_p128.h, shared with the MX formats.
+template <int NI_>
 struct klm_p128_bf16 {
+  static constexpr int NI = NI_;
   struct frags {
-    bf16x8 a[2][4], b[2][2];   // [k step][tile]
+    bf16x8 a[2][4], b[2][NI_];   // [k step][tile]
   };
-  f32x4 acc[4][2];
+  f32x4 acc[4][NI_];
   int a_off[2], b_off[2];
   // fragment reads: row = base + tile * 16 + (lane & 15); 16-byte chunk = ks * 4 + (lane >> 4), swizzled by row & 7
-  __device__ __forceinline__ void init(int lane, int wr, int wc) {
+  __device__ __forceinline__ void init(int lane, int wr, int wc, int b_base) {
     const int fr = lane & 15, fq = lane >> 4, key = lane & 7;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = ((ks * 4 + fq) ^ key) << 4;
       a_off[ks] = (wr * 64 + fr) * 128 + ch;
-      b_off[ks] = 16384 + (wc * 32 + fr) * 128 + ch;
+      b_off[ks] = b_base + (wc * 16 * NI_ + fr) * 128 + ch;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ void read(frags& f, const char* st) const {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) f.b[ks][ni] = *reinterpret_cast<const bf16x8*>(st + b_off[ks] + ni * 2048);
+      for (int ni = 0; ni < NI_; ++ni) f.b[ks][ni] = *reinterpret_cast<const bf16x8*>(st + b_off[ks] + ni * 2048);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) f.a[ks][mi] = *reinterpret_cast<const bf16x8*>(st + a_off[ks] + mi * 2048);
     }
@@ -130,7 +132,7 @@ struct klm_p128_bf16 {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI_; ++ni)
           // X = B rows (n), Y = A rows (m): D[n][m]; a lane holds 4 consecutive n of one m
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ks][ni], f.a[ks][mi], acc[mi][ni], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
@@ -452,10 +454,10 @@ extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N
     const int grid = (M >> 7) * (N >> 7);
     hipLaunchKernelGGL(gemm_bf16_128, dim3(grid), dim3(256), 32768, s, (const uint16_t*)A,
                        (const uint16_t*)B, (uint16_t*)C, M, N, K);
-  } else if (variant == 14) {
-    // 128 x 128 tiles on eight waves, four-stage ring: shapes of fewer 256 x 256 tiles than CUs
+  } else if (variant == 14 || variant == 16 || variant == 17) {
+    // 128 x 128 / 256 x 128 / 128 x 256 tiles on eight waves, LDS-DMA ring: shapes of too few 256 x 256 tiles to fill the chip
     if ((K & 63) || K > 0x3fffffff) return KLM_ERR_SHAPE;
-    if (int e = klm_launch_p128<klm_p128_bf16>(A, B, C, M, N, K * 2, s)) return e;
+    if (int e = klm_launch_p128_variant<klm_p128_bf16>(variant, A, B, C, M, N, K * 2, s)) return e;
   } else if (variant == 3) {
     // 4 waves of 128x128; an even number of K tiles >= 4
     if ((M & 255) || (N & 255) || (K & 127) || K < 256) return KLM_ERR_SHAPE;

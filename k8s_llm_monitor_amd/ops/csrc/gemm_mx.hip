@@ -121,24 +121,25 @@ struct klm_op_mx {
 
 // The operand policy of the 128 x 128 eight-wave ring kernel (gemm_p128.h) for the MX formats: the same chunks as klm_op_mx
 // above; an accumulator is touched once (fp8) or twice, eight MFMAs apart (fp4), per K tile.
-template <int FMT>
+template <int FMT, int NI_>
 struct klm_p128_mx {
+  static constexpr int NI = NI_;
   typedef typename klm_mx_frag<FMT>::type frag;
   struct frags {
-    frag a[2][4], b[2][2];     // [ks][tile]; fp8 uses ks = 0 only
+    frag a[2][4], b[2][NI_];     // [ks][tile]; fp8 uses ks = 0 only
   };
-  f32x4 acc[4][2];
+  f32x4 acc[4][NI_];
   int c0, c1, a_row, b_row;
-  __device__ __forceinline__ void init(int lane, int wr, int wc) {
+  __device__ __forceinline__ void init(int lane, int wr, int wc, int b_base) {
     const int fr = lane & 15, fq = lane >> 4, key = lane & 7;
     c0 = (fq ^ key) << 4;
     c1 = c0 ^ 64;
     a_row = (wr * 64 + fr) * 128;
-    b_row = 16384 + (wc * 32 + fr) * 128;
+    b_row = b_base + (wc * 16 * NI_ + fr) * 128;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __device__ __forceinline__ void load_frag(frag& f0, frag& f1, const char* base) const {
     const i32x4 lo = *reinterpret_cast<const i32x4*>(base + c0);
@@ -152,7 +153,7 @@ struct klm_p128_mx {
   }
   __device__ __forceinline__ void read(frags& f, const char* st) const {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) load_frag(f.b[0][ni], f.b[1][ni], st + b_row + ni * 2048);
+    for (int ni = 0; ni < NI_; ++ni) load_frag(f.b[0][ni], f.b[1][ni], st + b_row + ni * 2048);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) load_frag(f.a[0][mi], f.a[1][mi], st + a_row + mi * 2048);
   }
@@ -177,10 +178,14 @@ struct klm_p128_mx {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) mfma1(acc[mi][ni], f.b[ks][ni], f.a[ks][mi]);
+        for (int ni = 0; ni < NI_; ++ni) mfma1(acc[mi][ni], f.b[ks][ni], f.a[ks][mi]);
     __builtin_amdgcn_s_setprio(0);
   }
 };
+template <int NI_>
+using klm_p128_fp8 = klm_p128_mx<0, NI_>;
+template <int NI_>
+using klm_p128_fp4 = klm_p128_mx<4, NI_>;
 
 // K is the row length in BYTES.
 template <int FMT, int SCHED>
@@ -269,12 +274,12 @@ extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N,
                                : klm_launch_quad_asm_p<31>(A, B, C, M, N, K, (hipStream_t)stream)) return e;   // 5: 4 with C streamed (sc1 nt)
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
-  if (variant == 14) {
-    // 128 x 128 tiles on eight waves, four-stage ring (gemm_p128.h): shapes of fewer 256 x 256 tiles than CUs
+  if (variant == 14 || variant == 16 || variant == 17) {
+    // 128 x 128 / 256 x 128 / 128 x 256 tiles on eight waves, LDS-DMA ring (gemm_p128.h): shapes of too few 256 x 256 tiles
     if (!A || !B || !C) return KLM_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
     if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
-    if (int e = klm_launch_p128<klm_p128_mx<0>>(A, B, C, M, N, K, (hipStream_t)stream)) return e;
+    if (int e = klm_launch_p128_variant<klm_p128_fp8>(variant, A, B, C, M, N, K, (hipStream_t)stream)) return e;
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
   if (int e = check_mx(A, B, C, M, N, K, variant)) return e;
@@ -329,11 +334,11 @@ extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N,
                                : klm_launch_quad_asm_p<21>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;   // 4: 3 with C streamed (sc1 nt)
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
-  if (variant == 14) {
+  if (variant == 14 || variant == 16 || variant == 17) {
     if (!A || !B || !C) return KLM_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return KLM_ERR_ALIGN;
     if (!klm_stream_on_current_device((hipStream_t)stream)) return KLM_ERR_ARG;
-    if (int e = klm_launch_p128<klm_p128_mx<4>>(A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;
+    if (int e = klm_launch_p128_variant<klm_p128_fp4>(variant, A, B, C, M, N, K >> 1, (hipStream_t)stream)) return e;
     return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
   }
   if (int e = check_mx(A, B, C, M, N, K >> 1, variant)) return e;

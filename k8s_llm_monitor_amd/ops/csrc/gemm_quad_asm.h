@@ -336,10 +336,13 @@ static int klm_launch_quad_asm_p(const void* A, const void* B, void* C, int M, i
   if (cus <= 0) return KLM_ERR_HIP;
   const KlmQuadPlan plan = klm_quad_plan(M, N, Kb, cus, ws ? mode : (mode & 4), rot, ws_bytes);
   if constexpr (BODY == 0 || BODY == 20 || BODY == 30) {
-    // at most one whole tile per workgroup and nothing to split: a persistent workgroup would build a table of one unit.
-    // The one-workgroup-per-tile stream gives the same bits without that (3072^3: +7 %, 4096^3: +1 %, gemm_shape_sweep.json)
+    // At most one whole tile per workgroup and nothing to split: every workgroup stores its 128 KiB of C at the same moment, at
+    // the very end, and nothing follows that could use C from the caches. Stored with `sc1 nt` (BODY + 1; the same bits) the
+    // round ends earlier: fp8 4096 x 4096 x 512 / 1024 / 4096: 14.8 -> 13.5, 19.0 -> 17.7, 47.3 -> 46.5 us; 3584^3 36.8 -> 35.2;
+    // bf16 3072^3 54.2 -> 52.5 (scripts/exp/gemm_one_round_variants.py). In a multi-round problem the same stores cost up to
+    // 12 % at small K (docs/KERNELS.md), so only here.
     if ((mode & 3) > 0 && plan.split <= 1 && plan.rot == 0 && plan.rounds + (plan.rest ? 1 : 0) == 1)
-      return klm_launch_quad_asm<BODY>(A, B, C, M, N, Kb, s, ld);
+      return klm_launch_quad_asm_p<BODY + 1>(A, B, C, M, N, Kb, s, ld, 0, 0, nullptr, 0);
   }
   const int lds = KLM_QUAD_LDS_BYTES + 32 * KLM_QUAD_P_MAX_TILES;
   if (int e = klm_ensure_dyn_lds<gemm_quad_asm_p<BODY>>(lds)) return e;

@@ -24,6 +24,8 @@ def env():
                                            (8, (256, 256, 256)), (8, (512, 768, 384)), (8, (2048, 1024, 4096)), (8, (256, 512, 4352)),
                                            (9, (512, 768, 384)), (9, (2048, 1024, 4096)),
                                            (14, (128, 128, 64)), (14, (256, 384, 128)), (14, (384, 640, 192)), (14, (1024, 512, 2048)), (14, (128, 256, 4160)),
+                                           (16, (256, 128, 64)), (16, (512, 384, 192)), (16, (1024, 640, 2048)), (17, (128, 256, 128)), (17, (384, 512, 320)), (17, (640, 1024, 2112)),
+                                           (None, (2560, 2560, 512)),
                                            (None, (1024, 1024, 1024)), (None, (2048, 2048, 2048)), (None, (384, 128, 64)), (None, (256, 256, 192))])
 def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch, ops, dev = env
@@ -37,7 +39,7 @@ def test_gemm_bf16_matches_fp32_reference(env, variant, shape):
     torch.testing.assert_close(c.float(), ref, rtol=1.6e-2, atol=1e-2 * K ** 0.5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14, 16, 17])
 def test_gemm_bf16_exact_on_small_integers_with_asymmetric_operands(env, variant):
     torch, ops, dev = env
     M, N, K = 512, 256, (192 if variant < 2 else 384)
@@ -55,7 +57,7 @@ def test_gemm_bf16_identity_picks_rows_not_columns(env):
     n = 256
     eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
     b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).to(torch.bfloat16)      # asymmetric
-    for v in (0, 1, 2, 3, 4, 8, 10, 13, 14):
+    for v in (0, 1, 2, 3, 4, 8, 10, 13, 14, 16, 17):
         assert torch.equal(ops.gemm_bf16(eye, b, variant=v), b.t().contiguous())      # C = I @ B^T
 
 
@@ -74,6 +76,9 @@ def test_gemm_bf16_is_deterministic_run_to_run(env):
         torch.testing.assert_close(c14.float(), x.float() @ y.float().t(), rtol=1.6e-2, atol=1e-2 * K ** 0.5)
         for _ in range(20):
             assert torch.equal(ops.gemm_bf16(x, y, variant=14), c14), K
+        # its 256 x 128 / 128 x 256 forms (three-stage ring) sum in the same order: the same bits
+        for _ in range(10):
+            assert torch.equal(ops.gemm_bf16(x, y, variant=16), c14) and torch.equal(ops.gemm_bf16(x, y, variant=17), c14), K
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 384), (1024, 2048, 4096), (256, 512, 512), (768, 256, 4608),
@@ -90,6 +95,10 @@ def test_gemm_fp8_matches_fp32_reference(env, shape):
     # every pipeline sums an element's products in the same order: same bits (14: the eight-wave 128 x 128 ring kernel, the
     # default for shapes of few tiles; K tile counts 1, 3, 5, 33 and even ones)
     assert torch.equal(c, ops.gemm_fp8(a, b, variant=14))
+    if N % 256 == 0:
+        assert torch.equal(c, ops.gemm_fp8(a, b, variant=17))              # ... and its 128 x 256 / 256 x 128 forms
+    if M % 256 == 0:
+        assert torch.equal(c, ops.gemm_fp8(a, b, variant=16))
     if M % 256 or N % 256:
         return
     assert torch.equal(c, ops.gemm_fp8(a, b, variant=0)) and torch.equal(c, ops.gemm_fp8(a, b, variant=1))
@@ -128,6 +137,10 @@ def test_gemm_fp4_is_exact_against_the_decoded_reference(env, shape):
     ref = ops.fp4_decode(a).double() @ ops.fp4_decode(b).double().t()
     assert torch.equal(c, ref.float().to(torch.bfloat16))
     assert torch.equal(c, ops.gemm_fp4(a, b, variant=14))                     # the eight-wave 128 x 128 ring kernel: K tile counts 1, 5, 33, even
+    if N % 256 == 0:
+        assert torch.equal(c, ops.gemm_fp4(a, b, variant=17))
+    if M % 256 == 0:
+        assert torch.equal(c, ops.gemm_fp4(a, b, variant=16))
     if M % 256 or N % 256:
         return
     assert torch.equal(c, ops.gemm_fp4(a, b, variant=0)) and torch.equal(c, ops.gemm_fp4(a, b, variant=1))

@@ -135,11 +135,15 @@ def test_default_bf16_kernel_follows_the_cost_model_and_the_measurements():
         assert ops.stream_plan_py(M, N, 2 * K) == (p["rounds"], p["rest"], p["split"]), (M, N, K)
     pick = ops.pick_bf16_variant
     # fewer 256 x 256 tiles than CUs and a short K: the 128 x 128 ring kernel (2048^3: 768 TFLOP/s against the stream's 453)
-    assert [pick(n, n, n) for n in (512, 1024, 1536, 2048, 2560)] == [14] * 5
+    assert [pick(n, n, n) for n in (512, 1024, 1536, 2048)] == [14] * 4
+    # between the two: 256 x 128 tiles of the same ring kernel (2560^3: 200 of them, one round at 78 %: 43.4 -> 38.8 us)
+    assert [pick(n, n, n) for n in (2304, 2560, 2816)] == [16] * 3 and pick(2048, 4096, 4096) == 16 and pick(2176, 2560, 2560) == 17
+    assert ops.pick_mx_variant(2560, 2560, 2560, 0, 7) == 17 and ops.pick_mx_variant(2560, 2176, 2560, 0, 7) == 16
     assert pick(1024, 4096, 4096) == 14 and pick(4096, 1024, 1024) == 14 and pick(128, 384, 64) == 14 and pick(384, 128, 64) == 14
     # from 144 tiles on, and on a long K (the split fills the chip), the stream
     assert [pick(n, n, n) for n in (3072, 3584, 4096, 5120, 6144, 8192, 12288)] == [10] * 7
     assert pick(2048, 2048, 8192) == 10 and pick(1024, 1024, 16384) == 10 and pick(2048, 6144, 4096) == 10 and pick(8192, 8192, 1024) == 10
+    assert pick(1024, 6144, 4096) == 10 and pick(1536, 4096, 4096) == 10          # 96 tiles, K = 4096: the split stream (54 us) beats both ring forms (56, 63)
     assert pick(2048, 2048, 2048, pitch=4352) == 10                 # pitched operands: only the streams take them
     assert pick(100, 128, 64) == 0 and pick(4096, 4096, 192) == 1 and pick(1024, 1024, 192) == 14
     # fp8 / fp4 go by the bytes of a row: the same rule, their own stream variants
@@ -147,8 +151,10 @@ def test_default_bf16_kernel_follows_the_cost_model_and_the_measurements():
     assert ops.pick_mx_variant(2048, 2048, 2048, 4352, 7) == 7 and ops.pick_mx_variant(256, 256, 384, 0, 7) == 14 and ops.pick_mx_variant(4096, 4096, 384, 0, 7) == 1
     assert ops.pick_mx_variant(384, 128, 128, 0, 6) == 14
     # the modelled times are the measured ones to ~15 %
-    for (M, N, K), us in (((2048, 2048, 2048), 22.4), ((1024, 1024, 1024), 10.6), ((2048, 2048, 8192), 70.2)):
+    for (M, N, K), us in (((2048, 2048, 2048), 22.4), ((1024, 1024, 1024), 10.6), ((2048, 2048, 8192), 70.2), ((2560, 2560, 2560), 43.4), ((2304, 2304, 2304), 39.2)):
         assert abs(ops.p128_time_us(M, N, 2 * K) - us) / us < 0.15
+    for (M, N, K), us in (((2560, 2560, 2560), 38.8), ((2048, 4096, 4096), 62.7), ((3072, 3072, 3072), 86.8), ((8192, 8192, 8192), 952.0)):
+        assert abs(ops.p256_time_us(M, N, 2 * K) - us) / us < 0.15
     for (M, N, K), us in (((4096, 4096, 4096), 94.8), ((3072, 3072, 3072), 57.5), ((8192, 8192, 8192), 687.0)):
         assert abs(ops.stream_time_us(M, N, 2 * K) - us) / us < 0.15
 

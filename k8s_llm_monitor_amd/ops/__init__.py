@@ -413,18 +413,23 @@ def _stream(dtype_code: int, a, b, out, M, N, Kbytes, pitch, store=0, mode=1, ro
 
 
 def gemm_bf16(a, b, out=None, variant: Optional[int] = None):
-    """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernel.
+    """``out[M,N] = a[M,K] @ b[N,K].T`` in bf16 with fp32 accumulation on the MFMA kernels.
 
-    variant None picks the fastest kernel the shape allows: the hand-scheduled 4-wave 256x256 stream in its persistent
-    form (10; or, for shapes of fewer 256 x 256 tiles than CUs, the eight-wave 128 x 128 ring kernel 14, whichever
-    `pick_bf16_variant` prices lower; 10: one workgroup per CU walks its output tiles, the next tile's operands fetched under the epilogue; a last,
-    partial round of tiles is cut into K slices where that pays -- `gemm_stream_plan` -- and the K loops are staggered on a
-    row pitch the memory channels camp on; 8: the same without either, 11 / 12: with one of them forced) for whole
-    256 x 256 tiles and an even number of K tiles >= 4, else the 8-wave ring kernel (2, or 1 for an odd tile count), else
-    the 128x128 one (0; also for shapes of at most 32 tiles of 256 x 256, which would leave most CUs idle). 4: the same stream, one workgroup per tile; 9: 8 with C stored past the caches (`sc1 nt`: +1.6 - 2.7 %
-    when one 8192^3 GEMM repeats on the same operands, which then stay in the Infinity Cache; -0.8 % in the training step,
-    -12 % at K = 1024: not a default); 48 / 49: 8 without its stores / epilogue (diagnostic); 3: the compiler-scheduled 4-wave kernel
-    (gemm_quad128.h); 5..7: earlier placements of the hand-scheduled stream; 40..43: diagnostic streams whose RESULT IS MEANINGLESS (scripts/exp/quad_asm_ablate.py).
+    variant None picks the fastest kernel the shape allows (`pick_bf16_variant`, a cost model fitted to measurements):
+      10  the hand-scheduled 4-wave 256 x 256 stream in its persistent form with its plan (`gemm_stream_plan`): one workgroup
+          per CU walks units (K ranges of output tiles), the next unit's operands fetched under the epilogue; a last, partial
+          round of tiles is cut into K slices (fp32 partial sums + a reduce kernel) where that pays; a one-round problem stores
+          C past the caches; operands well past the Infinity Cache are walked in 16 x 16 super-blocks of tiles; dense
+          operands on a badly camping row pitch are copied into padded scratch first (`repack_worthwhile`)
+      14 / 16 / 17  the eight-wave LDS-DMA ring kernel on 128 x 128 / 256 x 128 / 128 x 256 tiles, for shapes of too few
+          256 x 256 tiles to fill the chip
+      1   the 8-wave 256 x 256 ring kernel (whole 256 x 256 tiles with an odd number of K tiles); 0: the round-1 128 x 128 kernel
+    Explicit variants: 8 the persistent stream without a plan, 13 the same through the plan machinery, 11 the split forced
+    wherever the shape allows, 12 the K loops staggered per XCD, 15 the super-block order forced, 4 the stream with one workgroup
+    per tile (what `LinearLayerStep` runs under data parallelism), 9: 8 with C stored past the caches (`sc1 nt`), 2 the ring
+    kernel's schedule 1, 3 the compiler-scheduled 4-wave kernel (gemm_quad128.h). Diagnostic builds (-DKLM_GEMM_DIAG) add 5 .. 7
+    (earlier placements of the stream), 48 / 49 (8 without its stores / epilogue) and 40 .. 43, whose RESULT IS MEANINGLESS
+    (scripts/exp/quad_asm_ablate.py).
     """
     import torch
     _require_rows(a, b)

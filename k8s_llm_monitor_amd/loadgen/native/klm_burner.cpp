@@ -134,6 +134,14 @@ static int selftest() {
       first = false;
     }
   printf("]}\n");
+  // the library's default dispatch for a square problem of each size on 256 CUs (no device needed: the CU count is given):
+  // [size, bf16 kind, fp8 kind, fp4 kind], 0 none / 1 persistent stream / 2 ring kernel 128 x 128 / 3 ring kernel 256 x 128
+  printf("{\"selftest\":\"gemm_pick\",\"cus\":256,\"rows\":[");
+  const int sizes[] = {256, 1024, 2048, 2560, 3072, 4096, 6144, 8192, 12288};
+  for (size_t i = 0; i < sizeof sizes / sizeof *sizes; ++i)
+    printf("%s[%d,%d,%d,%d]", i ? "," : "", sizes[i], klm_gemm_pick(sizes[i], sizes[i], 2 * sizes[i], 256), klm_gemm_pick(sizes[i], sizes[i], sizes[i], 256),
+           klm_gemm_pick(sizes[i], sizes[i], sizes[i] / 2, 256));
+  printf("]}\n");
   printf("{\"selftest\":\"camping_pitch\",\"rows\":[");
   const long pitches[] = {512, 4096, 6144, 8192, 12288, 16384, 20480, 24064, 24576, 28672, 32768, 49152};
   for (size_t i = 0; i < sizeof pitches / sizeof *pitches; ++i) printf("%s[%ld,%d]", i ? "," : "", pitches[i], camping_pitch(pitches[i]) ? 1 : 0);
@@ -246,13 +254,25 @@ int main(int argc, char** argv) {
     fflush(stdout);
   }
 
+  // scratch for the streams' split of a last partial round: one 256 KiB slot per CU
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  int picked = -1;
+  if (gemm) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a.device) == hipSuccess && cus > 0) {
+      ws_bytes = (size_t)cus << 18;
+      if (hipMalloc(&ws, ws_bytes) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; ws_bytes = 0; }
+    }
+  }
   auto launch = [&]() -> int {
-    // the persistent hand-scheduled streams (bf16 8, fp8 4, fp4 3) where the size allows, else the ring kernels
+    // padded operands (a camping pitch): the persistent hand-scheduled streams, which take a row pitch
     if (pitch != row_bytes)
       return fp4 || fp8 ? klm_gemm_mx_pitched(fp8 ? 1 : 2, A, B, C, a.size, a.size, row_bytes, pitch, 1, s)
                         : klm_gemm_bf16_pitched(A, B, C, a.size, a.size, a.size, pitch, 1, s);
-    if (fp4) return klm_gemm_fp4(A, B, C, a.size, a.size, a.size, (a.size % 512 == 0 && a.size >= 1024) ? 3 : 1, s);
-    if (gemm) return fp8 ? klm_gemm_fp8(A, B, C, a.size, a.size, a.size, a.size >= 512 ? 4 : 1, s) : klm_gemm_bf16(A, B, C, a.size, a.size, a.size, 8, s);
+    // dense operands: the library's default dispatch (cost model: the persistent stream with its plan, or the eight-wave ring
+    // kernel on 128 x 128 / 256 x 128 tiles for sizes of too few 256 x 256 tiles to fill the chip)
+    if (gemm) return klm_gemm_auto(fp4 ? 2 : fp8 ? 1 : 0, A, B, C, a.size, a.size, (int)row_bytes, ws, ws_bytes, s, &picked);
     if (a.kind == "hbm_copy") return klm_hbm_copy(Y, X, (size_t)2 << 30, s);
     if (a.kind == "hbm_read") return klm_hbm_read(X, (size_t)2 << 30, sink, s);
     if (a.kind == "hbm_fill") return klm_hbm_fill(X, (size_t)2 << 30, 0x5A5A5A5Au, s);
@@ -336,6 +356,6 @@ int main(int argc, char** argv) {
   while (!pending.empty()) retire(true);
   print_summary(a, kernel_s, kernels, now_s() - t_start, busy_s, flops, bytes, held);
   for (void* p : hold) (void)hipFree(p);
-  for (void* p : {A, B, C, X, Y, sink}) if (p) (void)hipFree(p);
+  for (void* p : {A, B, C, X, Y, sink, ws}) if (p) (void)hipFree(p);
   return 0;
 }

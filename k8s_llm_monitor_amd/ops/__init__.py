@@ -62,6 +62,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
             lib.klm_gemm_stream.argtypes = [i, vp, vp, vp, i, i, i, i, i, i, i, vp, sz, vp]
             lib.klm_gemm_stream.restype = i
             lib.klm_gemm_stream_plan.argtypes = [i, i, i, i, i, i, sz, ctypes.POINTER(ctypes.c_int)]
+            if hasattr(lib, "klm_gemm_pick"):
+                lib.klm_gemm_pick.argtypes = [i, i, i, i]
+                lib.klm_gemm_pick.restype = i
             lib.klm_gemm_stream_plan.restype = i
             lib.klm_gemm_has_diag.restype = i
         if hasattr(lib, "klm_gemm_fp8"):
@@ -286,6 +289,11 @@ def _ring_fallback(M: int, N: int, Kbytes: int, cus: int) -> bool:
     """Whole 256 x 256 tiles with an odd number of K tiles: the 256 x 256 ring kernel's schedule 0 takes them, and wins once
     its tiles fill half the chip."""
     return (not stream_shape_ok(M, N, Kbytes) and M % 256 == 0 and N % 256 == 0 and Kbytes >= 256 and (M // 256) * (N // 256) >= cus // 2)
+
+
+def native_pick(M: int, N: int, Kbytes: int, cus: int = 256) -> Optional[str]:
+    """The library's own copy of `pick_tile_kernel` (klm_gemm_pick: what klm_gemm_auto and the C++ burner dispatch by)."""
+    return {0: None, 1: "stream", 2: "p128", 3: "p256"}[int(load().klm_gemm_pick(M, N, Kbytes, cus))]
 
 
 def pick_bf16_variant(M: int, N: int, K: int, pitch: int = 0, cus: int = 256) -> int:

@@ -426,6 +426,102 @@ extern "C" int klm_gemm_stream(int dtype, const void* A, const void* B, void* C,
   return hipGetLastError() == hipSuccess ? KLM_OK : KLM_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------
+// Which kernel for a shape: the cost model of ops/__init__.py (`pick_tile_kernel`: the Python side is the reference, fitted to
+// profiles/r3_prof/gemm_small.json, gemm_mid.json, gemm_units_first.json; tests/test_ops_layout.py holds the two against each
+// other over a grid of shapes), so that native callers -- klm_burner -- dispatch like `variant=None` does.
+// Times in microseconds per BYTE of a row's K extent: {quarter-full chip, full chip}.
+// ------------------------------------------------------------------------------------
+namespace klm_pick {
+constexpr double kStream[2] = {0.0073, 0.0106}, kP128[2] = {0.0020, 0.0039}, kP256[2] = {0.0056, 0.0070};
+constexpr double kP128SecondRound = 0.0032, kStreamFixed = 8.0, kRingFixed = 6.5, kSplitTimeMB = 0.13;
+
+static inline double per_kb(const double* pair, double occ, int power) {
+  double x = (occ - 0.25) / 0.75;
+  x = x < 0 ? 0 : (x > 1 ? 1 : x);
+  return pair[0] + (pair[1] - pair[0]) * (power == 2 ? x * x : x);
+}
+static inline bool stream_ok(int M, int N, int Kb) { return M > 0 && N > 0 && !(M & 255) && !(N & 255) && !(Kb & 255) && Kb >= 512; }
+static inline bool p128_ok(int M, int N, int Kb) { return M > 0 && N > 0 && !(M & 127) && !(N & 127) && !(Kb & 127) && Kb >= 128; }
+static inline bool p256_ok(int M, int N, int Kb) { return p128_ok(M, N, Kb) && (!(M & 255) || !(N & 255)); }
+
+static double stream_us(int M, int N, int Kb, int cus) {
+  const KlmQuadPlan p = klm_quad_plan(M, N, Kb, cus, 1, 0, (size_t)cus * KLM_QUAD_SLOT_BYTES);
+  double t = kStreamFixed + (double)p.rounds * Kb * kStream[1];
+  if (p.rest) {
+    if (p.split > 1)
+      t += Kb * per_kb(kStream, (double)p.rest * p.split / cus, 2) / p.split + KLM_SPLIT_LAUNCH_US + kSplitTimeMB * p.rest * p.split * 0.25;
+    else
+      t += Kb * per_kb(kStream, (double)p.rest / cus, 2);
+  }
+  return t;
+}
+static double p128_us(int M, int N, int Kb, int cus) {
+  const long tiles = (long)(M >> 7) * (N >> 7);
+  const long rounds = tiles / cus, rest = tiles % cus;
+  double per = per_kb(kP128, (double)rest / cus, 1);
+  if (rounds && per < kP128SecondRound) per = kP128SecondRound;
+  return kRingFixed + (double)rounds * Kb * kP128[1] + (rest ? Kb * per : 0.0);
+}
+static double p256_us(int M, int N, int Kb, int cus) {
+  const long tiles = ((long)M * N) / (256 * 128);
+  const long rounds = tiles / cus, rest = tiles % cus;
+  return kRingFixed + (double)rounds * Kb * kP256[1] + (rest ? Kb * per_kb(kP256, (double)rest / cus, 1) : 0.0);
+}
+// 0: none of the three takes the shape; 1: the persistent 256 x 256 stream; 2: the ring kernel on 128 x 128 tiles; 3: on 256 x 128
+static int kind(int M, int N, int Kb, int cus) {
+  int best = 0;
+  double t = 0;
+  if (stream_ok(M, N, Kb)) best = 1, t = stream_us(M, N, Kb, cus);
+  if (p256_ok(M, N, Kb)) {
+    const double x = p256_us(M, N, Kb, cus);
+    if (!best || x < t) best = 3, t = x;
+  }
+  if (p128_ok(M, N, Kb)) {
+    const double x = p128_us(M, N, Kb, cus);
+    if (!best || x < t) best = 2, t = x;
+  }
+  return best;
+}
+}  // namespace klm_pick
+
+extern "C" int klm_gemm_pick(int M, int N, int Kbytes, int cus) {
+  if (cus <= 0) cus = klm_quad_p_cus();
+  if (cus <= 0) return KLM_ERR_HIP;
+  return klm_pick::kind(M, N, Kbytes, cus);
+}
+
+extern "C" int klm_gemm_fp8(const void* A, const void* B, void* C, int M, int N, int K, int variant, void* stream);
+extern "C" int klm_gemm_fp4(const void* A, const void* B, void* C, int M, int N, int K, int variant, void* stream);
+extern "C" int klm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int variant, void* stream);
+
+// `variant=None` for native callers: dense operands, dtype 0 bf16 / 1 fp8 / 2 fp4 (rows of `Kbytes` bytes), `ws` the scratch of
+// klm_gemm_stream (may be null: then no round is split). Returns the status; *picked (may be null) = the klm_gemm_<dtype> variant
+// that ran (bf16 10 / fp8 7 / fp4 6 stand for the plan-driven stream).
+extern "C" int klm_gemm_auto(int dtype, const void* A, const void* B, void* C, int M, int N, int Kbytes, void* ws, size_t ws_bytes,
+                             void* stream, int* picked) {
+  if (dtype < 0 || dtype > 2) return KLM_ERR_VARIANT;
+  const int cus = klm_quad_p_cus();
+  if (cus <= 0) return KLM_ERR_HIP;
+  const int k = klm_pick::kind(M, N, Kbytes, cus);
+  const int elems = dtype == 0 ? Kbytes / 2 : dtype == 1 ? Kbytes : Kbytes * 2;
+  auto ring = [&](int v) {
+    if (picked) *picked = v;
+    return dtype == 0 ? klm_gemm_bf16(A, B, C, M, N, elems, v, stream) : dtype == 1 ? klm_gemm_fp8(A, B, C, M, N, elems, v, stream)
+                                                                                    : klm_gemm_fp4(A, B, C, M, N, elems, v, stream);
+  };
+  // whole 256 x 256 tiles with an odd number of K tiles, filling half the chip: the 256 x 256 ring kernel's schedule 0
+  const bool ring256 = !klm_pick::stream_ok(M, N, Kbytes) && !(M & 255) && !(N & 255) && Kbytes >= 256 && (M >> 8) * (N >> 8) >= cus / 2;
+  if (k == 1) {
+    if (picked) *picked = dtype == 0 ? 10 : dtype == 1 ? 7 : 6;
+    return klm_gemm_stream(dtype, A, B, C, M, N, Kbytes, 0, 0, 1, 0, ws, ws ? ws_bytes : 0, stream);
+  }
+  if ((k == 2 || k == 3) && ring256) return ring(1);
+  if (k == 2) return ring(14);
+  if (k == 3) return ring(dtype == 0 ? (!(M & 255) ? 16 : 17) : (!(N & 255) ? 17 : 16));
+  return ring(dtype == 0 ? 0 : 1);
+}
+
 // The hand-scheduled stream on operands whose rows are `ld_bytes` apart (>= 2 K, a multiple of 16; A and B alike).
 extern "C" int klm_gemm_bf16_pitched(const void* A, const void* B, void* C, int M, int N, int K, int ld_bytes, int persistent,
                                      void* stream) {

@@ -64,7 +64,13 @@ int klm_gemm_has_diag(void);    // 1: built with -DKLM_GEMM_DIAG (A/B-record and
 // can; rot > 0 staggers the workgroups' K loops (dense operands on a camping row pitch). klm_gemm_stream_plan: the plan alone.
 int klm_gemm_stream(int dtype, const void* A, const void* B, void* C, int M, int N, int Kbytes, int ld_bytes, int store, int mode,
                     int rot, void* ws, size_t ws_bytes, void* stream);
-int klm_gemm_stream_plan(int M, int N, int Kbytes, int cus, int mode, int rot, size_t ws_bytes, int* out5);
+int klm_gemm_stream_plan(int M, int N, int Kbytes, int cus, int mode, int rot, size_t ws_bytes, int* out6);
+// The default dispatch for native callers (the cost model of ops/__init__.py, mirrored): klm_gemm_pick -> 0 none / 1 the persistent
+// 256 x 256 stream / 2 the ring kernel on 128 x 128 tiles / 3 on 256 x 128 tiles (cus 0: this device's); klm_gemm_auto runs it
+// (dtype 0 bf16 / 1 fp8 / 2 fp4, dense rows of Kbytes bytes; ws: the scratch of klm_gemm_stream or null).
+int klm_gemm_pick(int M, int N, int Kbytes, int cus);
+int klm_gemm_auto(int dtype, const void* A, const void* B, void* C, int M, int N, int Kbytes, void* ws, size_t ws_bytes, void* stream,
+                  int* picked);
 
 // HBM helpers. `bytes` must be a multiple of 16 and pointers 16-byte aligned.
 int klm_hbm_fill(void* dst, size_t bytes, uint32_t pattern, void* stream);   // write-only

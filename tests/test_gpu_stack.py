@@ -230,6 +230,14 @@ def test_standalone_cpp_burner(torch_dev):
     assert fin["duty_achieved"] > 97.0 and fin["tflops_avg"] > 2500
     out = run("--kind", "hbm_copy", "--seconds", "1.5", "--hbm-gib", "8")
     assert out[0] == {"hbm_hold_gib": 8.0} and out[-1]["TBps_busy"] > 3.5
+    # sizes of too few 256 x 256 tiles to fill the chip go through the library's default dispatch (klm_gemm_auto): 2048^3 runs the
+    # eight-wave 128 x 128 ring kernel (~800 TFLOP/s; the 256 x 256 stream it ran before: ~460), 6144^3 splits its last round
+    fin = run("--kind", "gemm_bf16", "--size", "2048", "--seconds", "1.0")[-1]
+    assert fin["tflops_busy"] > 600, fin
+    fin = run("--kind", "gemm_fp8", "--size", "2048", "--seconds", "1.0")[-1]
+    assert fin["tflops_busy"] > 1000, fin
+    fin = run("--kind", "gemm_bf16", "--size", "6144", "--seconds", "1.0")[-1]
+    assert fin["tflops_busy"] > 1250, fin
 
 
 def test_power_gauge_agrees_with_the_energy_accumulator_and_temperature_follows_the_load(torch_dev):

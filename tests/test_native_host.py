@@ -187,7 +187,13 @@ def test_burner_selftest_planner_matches_the_python_planner(asan_bins):
     for duty, kernel_s, n in rows:
         assert n == plan_window(duty, lines[0]["period_s"], kernel_s), (duty, kernel_s, n)
     # which dense row pitches get padded: the same rule in both burners
-    from k8s_llm_monitor_amd.ops import camping_pitch
+    from k8s_llm_monitor_amd.ops import camping_pitch, pick_tile_kernel
+    # which kernel a square problem of each size runs on: the library's dispatch (klm_gemm_pick) = the Python cost model
+    assert lines[1]["selftest"] == "gemm_pick" and lines[1]["cus"] == 256 and len(lines[1]["rows"]) == 9
+    code = {None: 0, "stream": 1, "p128": 2, "p256": 3}
+    for n, bf16, fp8, fp4 in lines[1]["rows"]:
+        assert (bf16, fp8, fp4) == tuple(code[pick_tile_kernel(n, n, kb)] for kb in (2 * n, n, n // 2)), n
+    lines = [lines[0]] + lines[2:]
     assert lines[1]["selftest"] == "camping_pitch" and len(lines[1]["rows"]) == 12
     for nbytes, bad in lines[1]["rows"]:
         assert bool(bad) == camping_pitch(nbytes), nbytes

@@ -150,6 +150,13 @@ def test_default_bf16_kernel_follows_the_cost_model_and_the_measurements():
     assert ops.pick_mx_variant(2048, 2048, 2048, 0, 7) == 14 and ops.pick_mx_variant(8192, 8192, 8192, 0, 7) == 7 and ops.pick_mx_variant(4096, 4096, 2048, 0, 6) == 6
     assert ops.pick_mx_variant(2048, 2048, 2048, 4352, 7) == 7 and ops.pick_mx_variant(256, 256, 384, 0, 7) == 14 and ops.pick_mx_variant(4096, 4096, 384, 0, 7) == 1
     assert ops.pick_mx_variant(384, 128, 128, 0, 6) == 14
+    # the library carries the same model for native callers (klm_gemm_pick / klm_gemm_auto, the C++ burner): equal over a grid
+    import random
+    rnd = random.Random(7)
+    grid = [(128 * rnd.randint(1, 100), 128 * rnd.randint(1, 100), 128 * rnd.randint(1, 192)) for _ in range(600)]
+    grid += [(n, n, kb) for n in range(256, 12289, 256) for kb in (n // 2, n, 2 * n)]
+    diff = [(M, N, Kb, ops.pick_tile_kernel(M, N, Kb), ops.native_pick(M, N, Kb)) for M, N, Kb in grid if ops.pick_tile_kernel(M, N, Kb) != ops.native_pick(M, N, Kb)]
+    assert not diff, diff[:5]
     # the modelled times are the measured ones to ~15 %
     for (M, N, K), us in (((2048, 2048, 2048), 22.4), ((1024, 1024, 1024), 10.6), ((2048, 2048, 8192), 70.2), ((2560, 2560, 2560), 43.4), ((2304, 2304, 2304), 39.2)):
         assert abs(ops.p128_time_us(M, N, 2 * K) - us) / us < 0.15

@@ -772,13 +772,16 @@ def throttle_alerts(torch, dev, src, smi_idx: int, burn_s: float = 12.0, period_
         idle = [r for r in trace if r["phase"] == "idle"]
         burn = [r for r in trace if r["phase"] == "burn" and r["t"] - t_start >= 2 * period_s + 1.0]     # steady state
         ppt = [r["ppt_residency_pct"] for r in burn if r["ppt_residency_pct"] is not None]
-        clk_idle, clk_burn = _mean([r["clock_gfx_mhz"] for r in idle]), _mean([r["clock_gfx_mhz"] for r in burn])
+        # the clock the card runs when power does not limit it: the HIGHEST reading outside the load (an unloaded card
+        # reports its boost clock or, parked, ~150 MHz: a mean of the two says nothing)
+        free = [r["clock_gfx_mhz"] for r in trace if r["phase"] in ("idle", "cool") and r["clock_gfx_mhz"]]
+        clk_idle, clk_burn = (max(free) if free else None), _mean([r["clock_gfx_mhz"] for r in burn])
         pw, cap = _mean([r["power_w"] for r in burn]), next((r["power_cap_w"] for r in burn if r["power_cap_w"]), None)
         res.update({
             "tflops_busy": out.get("tflops_busy"), "duty_achieved": out.get("duty_achieved"),
             "power_mean_w": pw, "power_cap_w": cap, "power_pct_of_cap": (pw / cap * 100.0) if pw and cap else None,
             "ppt_residency_mean_pct": _mean(ppt), "ppt_residency_min_pct": min(ppt) if ppt else None,
-            "clock_idle_mhz": clk_idle, "clock_under_cap_mhz": clk_burn,
+            "clock_idle_mhz": clk_idle, "clock_idle_samples_mhz": [r["clock_gfx_mhz"] for r in idle], "clock_under_cap_mhz": clk_burn,
             "clock_dropped": bool(clk_idle and clk_burn and clk_burn < clk_idle - 50.0),
             "power_alert_latency_s": None if first[k_power] is None else first[k_power] - t_start,
             "throttle_alert_latency_s": None if first[k_ppt] is None else first[k_ppt] - t_start,

@@ -164,6 +164,18 @@ def test_throttle_phase_sees_both_alerts_appear_and_clear():
     assert 0 < r["power_alert_clear_s"] <= 0.5 and 0 < r["throttle_alert_clear_s"] <= 0.5 and r["power_alert_sse_clear_s"] is not None
     s = phases.summarize({"throttle_alerts": r})
     assert s["pass"] == {"power_alert": True, "throttle_alert": True} and s["power_alert"] is True
+    # an unloaded card may report its PARKED clock (~150 MHz) instead of its boost clock (seen on the MI355X: idle samples 2403
+    # and 158 MHz): the reference for "the clock dropped" is the highest reading outside the load, not the idle mean
+    calls = {"n": 0}
+
+    def parked(t, i):
+        if on["burn"]:
+            return GpuState(power_w=1390.0, ppt_throttle=1.0, clk_gfx=1760.0, gfx=100.0)
+        calls["n"] += 1
+        return GpuState(power_w=260.0, clk_gfx=158.0 if calls["n"] % 2 else 2403.0)
+
+    r = phases.throttle_alerts(None, None, None, 0, burn_s=2.0, idle_s=0.8, timeout_s=4.0, monitor=_fake_monitor(parked, realtime=0.25), burner=FakeBurner())
+    assert r["throttle_alert"] and r["clock_dropped"] and r["clock_idle_mhz"] == 2403.0 and 158.0 in r["clock_idle_samples_mhz"], r
     # a card that never reaches its cap fails both flags, and says why
     r = phases.throttle_alerts(None, None, None, 0, burn_s=1.0, idle_s=0.3, timeout_s=1.0, burner=FakeBurner(),
                                monitor=_fake_monitor(lambda t, i: GpuState(power_w=900.0, clk_gfx=2400.0), realtime=0.25))

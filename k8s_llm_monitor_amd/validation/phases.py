@@ -746,6 +746,12 @@ def throttle_alerts(torch, dev, src, smi_idx: int, burn_s: float = 12.0, period_
     res: Dict[str, Any] = {"period_s": period_s, "burn_s": burn_s}
     try:
         watch(idle_s, "idle")
+        # a previous phase's load may still show in the first window (residency is a delta over the sampler period): give the
+        # alerts three more periods to clear; what is still there then is reported and fails the flags
+        quiet = lambda: not any(_alerts_have(srv.url, k, None) for k in (k_power, k_ppt))
+        res["alerts_at_first_look"] = [k for k in (k_power, k_ppt) if _alerts_have(srv.url, k, None)]
+        if res["alerts_at_first_look"]:
+            watch(3.0 * period_s, "idle", until=quiet)
         res["alerts_before_load"] = [k for k in (k_power, k_ppt) if _alerts_have(srv.url, k, None)]
         t_start = time.perf_counter()
         b.start(burn_s + 60.0)

@@ -239,6 +239,9 @@ class GpuNormalizer:
                      "linkSpeedGTs": (_num(raw.get("pcie_link_speed")) or 0) / 10.0 or None,
                      "linkWidth": _int(raw.get("pcie_link_width")),
                      "errors": pcie_err},
+            # what this device is a slice of: compute partition mode (SPX: the whole GPU; CPX: one XCD per device, ...) and
+            # memory partition mode (NPS1 ...); None where the driver does not say
+            "partition": {"compute": raw.get("compute_partition"), "memory": raw.get("memory_partition")},
             "xcdActivity": xcd_inst,
             "xcdActivityAvg": xcd_avg,
             "processes": raw.get("processes"),
@@ -373,6 +376,7 @@ class AmdSmiReader(GpuReader):
             self.topology = [{"links": [], "hive_id": None, "node_id": None, "nearest": None, "pair_type": {},
                               "note": f"topology unavailable: {type(e).__name__}: {e}"} for _ in self._handles]
         self._xgmi_err_supported = [True] * len(self._handles)
+        self._partition_supported = [True] * len(self._handles)
         self._slow_every = 12       # ECC and process list change rarely: read every Nth sample
         self._n = 0
         self._slow_cache: Dict[int, Dict[str, Any]] = {}
@@ -432,6 +436,18 @@ class AmdSmiReader(GpuReader):
                             sc["xgmi_error_status"] = "not_supported" if "NOT_SUPPORTED" in str(e) else f"error: {type(e).__name__}"
                     else:
                         sc["xgmi_error_status"] = (self._slow_cache.get(i) or {}).get("xgmi_error_status", "not_supported")
+                    # compute / memory partition modes (SPX / CPX ..., NPS1 / NPS4 ...): what one "GPU" of this list is a slice of.
+                    # They change only through an administrator's call: the slow path, and asked once where unsupported
+                    if self._partition_supported[i]:
+                        try:
+                            sc["compute_partition"] = _partition_name(smi.amdsmi_get_gpu_compute_partition(h))
+                            sc["memory_partition"] = _partition_name(smi.amdsmi_get_gpu_memory_partition(h))
+                        except Exception:
+                            self._partition_supported[i] = False
+                    else:
+                        for k in ("compute_partition", "memory_partition"):
+                            if (self._slow_cache.get(i) or {}).get(k) is not None:
+                                sc[k] = self._slow_cache[i][k]
                     try:
                         e = smi.amdsmi_get_gpu_total_ecc_count(h)
                         sc.update(ecc_correctable=e.get("correctable_count"),
@@ -458,6 +474,14 @@ class AmdSmiReader(GpuReader):
             self._smi.amdsmi_shut_down()
         except Exception:
             pass
+
+
+def _partition_name(v: Any) -> Optional[str]:
+    """amdsmi returns the mode as a string ("SPX", "NPS1"), an enum member or "N/A"."""
+    name = getattr(v, "name", None) or (v if isinstance(v, str) else None)
+    if not name or name in ("N/A", "UNKNOWN", "INVALID"):
+        return None
+    return str(name).replace("AMDSMI_COMPUTE_PARTITION_", "").replace("AMDSMI_MEMORY_PARTITION_", "")
 
 
 def topology_to_raw(topo: Dict[str, Any]) -> Dict[str, Any]:

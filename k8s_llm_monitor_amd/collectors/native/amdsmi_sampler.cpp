@@ -122,6 +122,8 @@ struct Gpu {
   uint64_t hive_id = 0, node_id = 0;
   std::string topo_note, xgmi_err = "unknown";
   bool xgmi_err_supported = true;
+  std::string compute_partition, memory_partition;     // "SPX" / "NPS1" ...; empty: the driver does not say
+  bool partition_supported = true;
   double cap_w = NAN, energy_res_uj = NAN;
   Gauge gfx, umc, power, temp, temp_mem, temp_edge, clk;
   amdsmi_gpu_metrics_t m;
@@ -194,6 +196,8 @@ static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, d
     if (g.topo_note.empty()) r.null("xgmi_topology_note");
     else r.str("xgmi_topology_note", g.topo_note.c_str());
     r.str("xgmi_error_status", g.xgmi_err.c_str());
+    if (!g.compute_partition.empty()) r.str("compute_partition", g.compute_partition.c_str());
+    if (!g.memory_partition.empty()) r.str("memory_partition", g.memory_partition.c_str());
     if (g.have_m) {
       const amdsmi_gpu_metrics_t& m = g.m;
       r.num("gfx_activity", g.gfx.mean());
@@ -388,6 +392,19 @@ static void read_xgmi_error(Gpu& g) {
   }
 }
 
+// compute / memory partition modes: strings from the driver ("SPX", "NPS1"; "N/A" where there is none). Asked once where unsupported.
+static void read_partitions(Gpu& g) {
+  if (!g.partition_supported) return;
+  char c[64] = {0}, m[64] = {0};
+  const bool okc = amdsmi_get_gpu_compute_partition(g.h, c, sizeof c) == AMDSMI_STATUS_SUCCESS;
+  const bool okm = amdsmi_get_gpu_memory_partition(g.h, m, sizeof m) == AMDSMI_STATUS_SUCCESS;
+  c[sizeof c - 1] = m[sizeof m - 1] = 0;
+  auto clean = [](const char* v) { return (!v[0] || !strcmp(v, "N/A") || !strcmp(v, "UNKNOWN")) ? std::string() : std::string(v); };
+  g.compute_partition = okc ? clean(c) : std::string();
+  g.memory_partition = okm ? clean(m) : std::string();
+  if (!okc && !okm) g.partition_supported = false;
+}
+
 // --selftest: render one line from synthetic metrics (no driver needed), including
 // unsupported-field sentinels and a 32-bit activity accumulator near its wrap. Lets the JSON
 // writer run under host sanitizers and feeds the Python reader in CPU tests.
@@ -443,6 +460,7 @@ static int selftest() {
     g.hive_id = 6319504153631384352ull;
     g.node_id = i;
     g.xgmi_err = "not_supported";
+    if (i == 0) g.compute_partition = "SPX", g.memory_partition = "NPS1";      // GPU 1: the driver does not say
     for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
       LinkTopo t;
       t.max_gbps = 608;
@@ -570,6 +588,7 @@ int main(int argc, char** argv) {
         if (slow % 10 == 0 || !g.have_ecc) {
           g.have_ecc = amdsmi_get_gpu_total_ecc_count(g.h, &g.ecc) == AMDSMI_STATUS_SUCCESS;
           read_xgmi_error(g);
+          read_partitions(g);
           if (processes) {
             static amdsmi_proc_info_t list[64];
             uint32_t n = 64;

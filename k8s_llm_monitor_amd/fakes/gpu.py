@@ -220,7 +220,7 @@ class FakeGpuReader:
                 "xgmi_peer_index": [None if (l == i % 8 or l >= self.n) else l for l in range(8)],
                 "xgmi_peer_source": [None if (l == i % 8 or l >= self.n) else "link_metrics" for l in range(8)],
                 "xgmi_link_max_gbps": [608] * 8, "xgmi_hive_id": 0x57b3c0de57b3c0de, "xgmi_node_id": i % 8,
-                "xgmi_nearest": [j for j in range(self.n) if j != i], "xgmi_topology_note": None, "xgmi_error_status": "no_errors",
+                "xgmi_nearest": [j for j in range(self.n) if j != i], "xgmi_topology_note": None, "xgmi_error_status": "no_errors", "compute_partition": "SPX", "memory_partition": "NPS1",
                 "processes": 1,
                 "process_list": [{"pid": 40000 + i, "name": "python3 (vllm worker)", "vramBytes": int(HBM_TOTAL_MIB * s.hbm_frac) << 20}],
             })

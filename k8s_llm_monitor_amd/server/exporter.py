@@ -55,6 +55,10 @@ def render(snapshot: Mapping[str, Any], stats: Mapping[str, Any]) -> str:
     d.add("klm_host_disk_percent", "Root filesystem used percent.", "gauge", pf((host.get("disk") or {}).get("percent")))
     for g in snapshot.get("gpus") or []:
         L = {"gpu": g.get("index"), "uuid": g.get("uuid"), "name": g.get("name")}
+        part = g.get("partition") or {}
+        if part.get("compute") or part.get("memory"):
+            d.add("klm_gpu_partition_info", "Compute / memory partition mode this device is a slice of (always 1).", "gauge", 1,
+                  dict(L, compute=part.get("compute"), memory=part.get("memory")))
         d.add("klm_gpu_hbm_used_bytes", "HBM in use.", "gauge", g.get("hbmUsedBytes"), L)
         d.add("klm_gpu_hbm_total_bytes", "HBM capacity.", "gauge", g.get("hbmTotalBytes"), L)
         d.add("klm_gpu_gfx_activity_percent", "GFX activity, mean over the last sample period.", "gauge",

@@ -152,6 +152,17 @@ def test_single_gpu_without_named_peers_shows_the_reason(tmp_path, demo_payloads
     assert "not visible" in o["text"]["xgmiMatrixNote"] and o["text"]["gpuValue"].endswith("%") and " 卡" not in o["text"]["gpuLabel"]
 
 
+def test_partitioned_devices_are_tagged_in_the_gpu_table(tmp_path, demo_payloads):
+    """A CPX / NPS4 device is one XCD and a quarter of the HBM channels of a GPU: the table says so next to the name; a whole
+    GPU (SPX / NPS1) keeps its plain name."""
+    g = json.loads(json.dumps(demo_payloads["/api/gpu/metrics"][:2]))
+    g[0]["partition"] = {"compute": "CPX", "memory": "NPS4"}
+    o = run_page(tmp_path, dict(demo_payloads, **{"/api/gpu/metrics": g}))
+    assert o["errors"] == []
+    names = [r[1] for r in o["rows"]["gpuTableBody"]]
+    assert names[0].endswith("[CPX / NPS4]") and names[0].startswith(g[0]["name"]) and names[1] == g[1]["name"]
+
+
 def test_unverified_one_gpu_probe_point_prints_na_not_a_number(tmp_path, demo_payloads):
     """an in-place all-reduce on a one-rank communicator is a no-op and read as 615 678 GB/s; the probe
     now judges such a point implausible, and the page shows n/a for an unverified n = 1 curve and does not draw the point."""

@@ -201,3 +201,35 @@ def test_fake_pcie_scenario_raises_the_replay_alert_and_shows_the_idle_xcd():
     g5 = [g for g in gpus if g["index"] == 5][0]
     assert g5["xcdActivityAvg"][5] == 0.0 and min(v for i, v in enumerate(g5["xcdActivityAvg"]) if i != 5) > 10.0
     assert "XCD" in open(os.path.join(ROOT, "k8s_llm_monitor_amd", "web", "monitor.html"), encoding="utf-8").read()
+
+
+def test_partition_modes_travel_from_the_readers_to_the_api_the_exporter_and_the_page(clock):
+    """What one "GPU" of the list is a slice of (compute partition SPX / CPX ..., memory partition NPS1 ...): from amdsmi
+    (Python reader: asked once where unsupported; C++ sampler: its selftest line) through the normaliser to /api/gpu/metrics,
+    /metrics and the dashboard's GPU table."""
+    import json
+    import subprocess
+    from k8s_llm_monitor_amd.build import artifact
+    from k8s_llm_monitor_amd.collectors.gpu import GpuNormalizer, _partition_name
+    from k8s_llm_monitor_amd.server import exporter
+    g = GpuSource(FakeGpuReader(2, clock=clock)).sample()[0]
+    assert g["partition"] == {"compute": "SPX", "memory": "NPS1"}
+    text = exporter.render({"gpus": [g], "host": {}}, {})
+    assert 'klm_gpu_partition_info{' in text and 'compute="SPX"' in text and 'memory="NPS1"' in text
+    # the forms amdsmi answers in: plain strings, enum members, "N/A"
+    class E:
+        name = "AMDSMI_COMPUTE_PARTITION_CPX"
+    assert _partition_name("SPX") == "SPX" and _partition_name(E()) == "CPX" and _partition_name("N/A") is None and _partition_name(None) is None
+    # a driver that does not say leaves both None and no info series
+    raw = dict(FakeGpuReader(1, clock=clock).read()[0])
+    raw.pop("compute_partition"); raw.pop("memory_partition")
+    g2 = GpuNormalizer().normalize(raw)
+    assert g2["partition"] == {"compute": None, "memory": None} and "klm_gpu_partition_info" not in exporter.render({"gpus": [g2], "host": {}}, {})
+    exe = artifact("klm_amdsmi_sampler")
+    if exe.exists():
+        r = subprocess.run([str(exe), "--selftest"], capture_output=True, text=True, timeout=20)
+        g0, g1 = json.loads(r.stdout)["gpus"]
+        assert g0["compute_partition"] == "SPX" and g0["memory_partition"] == "NPS1" and "compute_partition" not in g1
+        assert GpuNormalizer().normalize(g0)["partition"] == {"compute": "SPX", "memory": "NPS1"}
+    page = open(os.path.join(os.path.dirname(exporter.__file__), "..", "web", "monitor.html"), encoding="utf-8").read()
+    assert "g.partition" in page and "compute partition" in page

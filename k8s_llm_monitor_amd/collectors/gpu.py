@@ -219,6 +219,11 @@ class GpuNormalizer:
             "ecc": {"correctable": _int(raw.get("ecc_correctable")),
                     "uncorrectable": _int(raw.get("ecc_uncorrectable")),
                     "deferred": _int(raw.get("ecc_deferred"))},
+            # retired HBM pages (RAS): taken out of use / waiting for the next driver reload / could not be reserved;
+            # None where the driver does not say
+            "badPages": (None if raw.get("bad_pages_retired") is None else
+                         {"retired": _int(raw.get("bad_pages_retired")), "pending": _int(raw.get("bad_pages_pending")) or 0,
+                          "unreservable": _int(raw.get("bad_pages_unreservable")) or 0}),
             "throttle": {"active": bool(active or throttling),
                          "reasons": sorted(set(active) | set(throttling)),
                          "residencyPercent": residency},
@@ -377,6 +382,7 @@ class AmdSmiReader(GpuReader):
                               "note": f"topology unavailable: {type(e).__name__}: {e}"} for _ in self._handles]
         self._xgmi_err_supported = [True] * len(self._handles)
         self._partition_supported = [True] * len(self._handles)
+        self._bad_pages_supported = [True] * len(self._handles)
         self._slow_every = 12       # ECC and process list change rarely: read every Nth sample
         self._n = 0
         self._slow_cache: Dict[int, Dict[str, Any]] = {}
@@ -455,6 +461,14 @@ class AmdSmiReader(GpuReader):
                                   ecc_deferred=e.get("deferred_count"))
                     except Exception:
                         pass
+                    # retired HBM pages (RAS): how many pages the driver took out of use, and how many wait for the next reload
+                    if self._bad_pages_supported[i]:
+                        try:
+                            sc.update(bad_pages_to_raw(smi.amdsmi_get_gpu_bad_page_info(h)))
+                        except Exception:
+                            self._bad_pages_supported[i] = False
+                    else:
+                        sc.update({k: v for k, v in (self._slow_cache.get(i) or {}).items() if k.startswith("bad_pages_")})
                     if self.processes:       # off by default: the call is slow and noisy on stderr without /proc access
                         try:
                             pl = smi.amdsmi_get_gpu_process_list(h)
@@ -474,6 +488,23 @@ class AmdSmiReader(GpuReader):
             self._smi.amdsmi_shut_down()
         except Exception:
             pass
+
+
+def bad_pages_to_raw(info: Any) -> Dict[str, int]:
+    """amdsmi_get_gpu_bad_page_info -> counts per status. The bindings answer a list of records ({"status": <enum or str>, ...})
+    or, with nothing retired, an empty list / a sentence ("No bad pages found.")."""
+    out = {"bad_pages_retired": 0, "bad_pages_pending": 0, "bad_pages_unreservable": 0}
+    if isinstance(info, (list, tuple)):
+        for rec in info:
+            st = rec.get("status") if isinstance(rec, dict) else None
+            name = str(getattr(st, "name", st) or "").upper()
+            if "PENDING" in name:
+                out["bad_pages_pending"] += 1
+            elif "UNRESERVABLE" in name:
+                out["bad_pages_unreservable"] += 1
+            else:
+                out["bad_pages_retired"] += 1
+    return out
 
 
 def _partition_name(v: Any) -> Optional[str]:

@@ -124,6 +124,8 @@ struct Gpu {
   bool xgmi_err_supported = true;
   std::string compute_partition, memory_partition;     // "SPX" / "NPS1" ...; empty: the driver does not say
   bool partition_supported = true;
+  bool have_bad_pages = false, bad_pages_supported = true;     // retired HBM pages (RAS), by status
+  uint32_t bad_retired = 0, bad_pending = 0, bad_unreservable = 0;
   double cap_w = NAN, energy_res_uj = NAN;
   Gauge gfx, umc, power, temp, temp_mem, temp_edge, clk;
   amdsmi_gpu_metrics_t m;
@@ -196,6 +198,11 @@ static std::string render_line(std::vector<Gpu>& gpus, double now, long polls, d
     if (g.topo_note.empty()) r.null("xgmi_topology_note");
     else r.str("xgmi_topology_note", g.topo_note.c_str());
     r.str("xgmi_error_status", g.xgmi_err.c_str());
+    if (g.have_bad_pages) {
+      r.u64("bad_pages_retired", g.bad_retired);
+      r.u64("bad_pages_pending", g.bad_pending);
+      r.u64("bad_pages_unreservable", g.bad_unreservable);
+    }
     if (!g.compute_partition.empty()) r.str("compute_partition", g.compute_partition.c_str());
     if (!g.memory_partition.empty()) r.str("memory_partition", g.memory_partition.c_str());
     if (g.have_m) {
@@ -392,6 +399,29 @@ static void read_xgmi_error(Gpu& g) {
   }
 }
 
+// retired HBM pages: the count first (a null buffer asks for it), then at most 1024 records, counted by status
+static void read_bad_pages(Gpu& g) {
+  if (!g.bad_pages_supported) return;
+  uint32_t n = 0;
+  if (amdsmi_get_gpu_bad_page_info(g.h, &n, nullptr) != AMDSMI_STATUS_SUCCESS) {
+    g.bad_pages_supported = false;
+    return;
+  }
+  g.bad_retired = g.bad_pending = g.bad_unreservable = 0;
+  if (n) {
+    static amdsmi_retired_page_record_t recs[1024];
+    uint32_t m = n < 1024 ? n : 1024;
+    if (amdsmi_get_gpu_bad_page_info(g.h, &m, recs) != AMDSMI_STATUS_SUCCESS) return;      // keep the previous answer
+    for (uint32_t k = 0; k < (m < 1024 ? m : 1024); ++k) {
+      if (recs[k].status == AMDSMI_MEM_PAGE_STATUS_PENDING) ++g.bad_pending;
+      else if (recs[k].status == AMDSMI_MEM_PAGE_STATUS_UNRESERVABLE) ++g.bad_unreservable;
+      else ++g.bad_retired;
+    }
+    if (n > 1024) g.bad_retired += n - 1024;          // beyond the buffer: counted as retired
+  }
+  g.have_bad_pages = true;
+}
+
 // compute / memory partition modes: strings from the driver ("SPX", "NPS1"; "N/A" where there is none). Asked once where unsupported.
 static void read_partitions(Gpu& g) {
   if (!g.partition_supported) return;
@@ -461,6 +491,7 @@ static int selftest() {
     g.node_id = i;
     g.xgmi_err = "not_supported";
     if (i == 0) g.compute_partition = "SPX", g.memory_partition = "NPS1";      // GPU 1: the driver does not say
+    if (i == 0) g.have_bad_pages = true, g.bad_retired = 2, g.bad_pending = 1;
     for (int l = 0; l < AMDSMI_MAX_NUM_XGMI_LINKS; ++l) {
       LinkTopo t;
       t.max_gbps = 608;
@@ -589,6 +620,7 @@ int main(int argc, char** argv) {
           g.have_ecc = amdsmi_get_gpu_total_ecc_count(g.h, &g.ecc) == AMDSMI_STATUS_SUCCESS;
           read_xgmi_error(g);
           read_partitions(g);
+          read_bad_pages(g);
           if (processes) {
             static amdsmi_proc_info_t list[64];
             uint32_t n = 64;

@@ -40,6 +40,8 @@ class GpuState:
     present: bool = True
     xcd_idle: bool = False       # XCD (index % 8) of this GPU does no work (a kernel whose grid leaves a die out)
     pcie_replays: int = 0        # cumulative PCIe replay count
+    bad_pages: int = 0           # retired HBM pages (RAS)
+    bad_pages_pending: int = 0   # pages marked bad, retired at the next driver reload
 
 
 Scenario = Callable[[float, int], GpuState]
@@ -80,6 +82,10 @@ def _ecc(t: float, i: int) -> GpuState:
     if i == 2:
         s.ecc_ce = int(t // 5)
         s.ecc_ue = 1 if t >= 15 else 0
+        # the driver marks the page bad after the uncorrectable error (retired at the next reload); GPU 5 carries old history
+        s.bad_pages_pending = 1 if t >= 20 else 0
+    if i == 5:
+        s.bad_pages = 3
     return s
 
 
@@ -211,6 +217,7 @@ class FakeGpuReader:
                 "temp_hotspot": round(s.temp), "temp_mem": round(s.temp_mem),
                 "clk_gfx": s.clk_gfx, "clk_mem": 2000,
                 "ecc_correctable": s.ecc_ce, "ecc_uncorrectable": s.ecc_ue, "ecc_deferred": 0,
+                "bad_pages_retired": s.bad_pages, "bad_pages_pending": s.bad_pages_pending, "bad_pages_unreservable": 0,
                 "res_prochot_acc": 0, "res_ppt_acc": int(a["ppt"]), "res_socket_thm_acc": int(a["thm"]),
                 "res_vr_thm_acc": 0, "res_hbm_thm_acc": 0,
                 "xgmi_read_kib": [int(x) for x in a["rd"]], "xgmi_write_kib": [int(x) for x in a["wr"]],

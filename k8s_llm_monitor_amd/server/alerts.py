@@ -106,6 +106,7 @@ _MSG = {
         "power_desc": "功耗 {w}W / 上限 {c}W ({p}%)",
         "ecc_ue": ("GPU{g} 出现不可纠正 ECC 错误", "不可纠正 ECC 错误 {n} 个", "建议：1. 迁移该卡上的负载 2. amd-smi bad-pages / RAS 检查 3. 联系硬件更换"),
         "ecc_ce": ("GPU{g} 可纠正 ECC 错误增加", "可纠正 ECC 错误累计 {n} 个 (新增 {d})", "建议：持续观察，增长过快时安排检修"),
+        "bad_pages": ("GPU{g} HBM 坏页隔离", "已隔离 {n} 页，待隔离 {p} 页，无法隔离 {u} 页", "建议：1. amd-smi bad-pages 查看地址 2. 待隔离页在驱动重载后生效，安排维护窗口 3. 数量持续增长时更换"),
         "xgmi": ("GPU{g} xGMI 链路断开", "链路 {l} 状态 down{peer}", "建议：1. amd-smi xgmi 检查链路 2. RCCL 集合通信将绕行或失败，尽快隔离该节点"),
         "pcie": ("GPU{g} PCIe 链路出现重传", "PCIe replay 新增 {d} 次 (累计 {n})，L0 恢复 {r} 次", "建议：1. 检查 PCIe 插槽 / 线缆 / riser 2. lspci -vv 查看链路速率是否降级 3. 持续增长时安排检修"),
         "throttle_thm": ("GPU{g} 温度降频中", "降频原因: {r}", "建议：检查散热，降低负载；性能数据在降频期间不可信"),
@@ -160,6 +161,7 @@ _MSG["en"] = {
     "power_desc": "power {w}W of {c}W cap ({p}%)",
     "ecc_ue": ("GPU{g} uncorrectable ECC errors", "{n} uncorrectable ECC error(s)", "Drain the GPU; check amd-smi bad-pages / RAS; schedule replacement"),
     "ecc_ce": ("GPU{g} correctable ECC errors rising", "{n} correctable ECC errors so far (+{d})", "Keep watching; service the GPU if the rate grows"),
+    "bad_pages": ("GPU{g} HBM pages retired", "{n} page(s) retired, {p} pending, {u} unreservable", "amd-smi bad-pages lists them; pending pages retire at the next driver reload: plan a window; replace the GPU if the count keeps growing"),
     "xgmi": ("GPU{g} xGMI link down", "link {l} is down{peer}", "Check amd-smi xgmi; RCCL collectives will reroute or fail; isolate the node"),
     "pcie": ("GPU{g} PCIe link replays", "{d} new PCIe replay(s) ({n} so far), {r} L0 recoveries", "Check the slot / cable / riser; lspci -vv for a downgraded link; service the node if the count keeps growing"),
     "throttle_thm": ("GPU{g} thermal throttling", "reasons: {r}", "Check cooling, reduce load; performance numbers are unreliable while throttled"),
@@ -298,6 +300,13 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
                 t, d, f = msgs["ecc_ce"]
                 _add(alerts, "minor", f"{k}/ecc_ce", t.format(g=g), d.format(n=ce, d=ce - before), f, edge=True, signal="ecc")
             next_ecc[idx] = ce
+        bp = gpu.get("badPages") or {}
+        n_bp, p_bp, u_bp = (bp.get(x) or 0 for x in ("retired", "pending", "unreservable"))
+        if n_bp or p_bp or u_bp:
+            # retired pages are history the driver has dealt with (minor); pages still waiting, or that could not be taken
+            # out, are memory in use that is known bad (serious)
+            t, d, f = msgs["bad_pages"]
+            _add(alerts, "serious" if (p_bp or u_bp) else "minor", f"{k}/bad_pages", t.format(g=g), d.format(n=n_bp, p=p_bp, u=u_bp), f, signal="ras")
         if th.xgmi_link_down_tier in TIERS:
             for link in (gpu.get("xgmi") or {}).get("links") or []:
                 if link.get("state") == "down":

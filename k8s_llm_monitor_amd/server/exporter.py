@@ -59,6 +59,10 @@ def render(snapshot: Mapping[str, Any], stats: Mapping[str, Any]) -> str:
         if part.get("compute") or part.get("memory"):
             d.add("klm_gpu_partition_info", "Compute / memory partition mode this device is a slice of (always 1).", "gauge", 1,
                   dict(L, compute=part.get("compute"), memory=part.get("memory")))
+        bp = g.get("badPages")
+        if bp:
+            for st in ("retired", "pending", "unreservable"):
+                d.add("klm_gpu_bad_pages", "HBM pages the driver retired (RAS), by status.", "gauge", bp.get(st), dict(L, status=st))
         d.add("klm_gpu_hbm_used_bytes", "HBM in use.", "gauge", g.get("hbmUsedBytes"), L)
         d.add("klm_gpu_hbm_total_bytes", "HBM capacity.", "gauge", g.get("hbmTotalBytes"), L)
         d.add("klm_gpu_gfx_activity_percent", "GFX activity, mean over the last sample period.", "gauge",

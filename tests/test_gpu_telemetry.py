@@ -230,6 +230,29 @@ def test_partition_modes_travel_from_the_readers_to_the_api_the_exporter_and_the
         r = subprocess.run([str(exe), "--selftest"], capture_output=True, text=True, timeout=20)
         g0, g1 = json.loads(r.stdout)["gpus"]
         assert g0["compute_partition"] == "SPX" and g0["memory_partition"] == "NPS1" and "compute_partition" not in g1
+        assert (g0["bad_pages_retired"], g0["bad_pages_pending"], g0["bad_pages_unreservable"]) == (2, 1, 0) and "bad_pages_retired" not in g1
+        assert GpuNormalizer().normalize(g0)["badPages"] == {"retired": 2, "pending": 1, "unreservable": 0}
         assert GpuNormalizer().normalize(g0)["partition"] == {"compute": "SPX", "memory": "NPS1"}
     page = open(os.path.join(os.path.dirname(exporter.__file__), "..", "web", "monitor.html"), encoding="utf-8").read()
     assert "g.partition" in page and "compute partition" in page
+
+
+def test_bad_page_records_are_counted_by_status_and_exported(clock):
+    from k8s_llm_monitor_amd.collectors.gpu import GpuNormalizer, bad_pages_to_raw
+    from k8s_llm_monitor_amd.server import exporter
+
+    class St:
+        def __init__(self, name):
+            self.name = name
+    recs = [{"status": St("AMDSMI_MEM_PAGE_STATUS_RESERVED"), "page_address": 1}, {"status": St("AMDSMI_MEM_PAGE_STATUS_PENDING")},
+            {"status": "RESERVED"}, {"status": St("AMDSMI_MEM_PAGE_STATUS_UNRESERVABLE")}]
+    assert bad_pages_to_raw(recs) == {"bad_pages_retired": 2, "bad_pages_pending": 1, "bad_pages_unreservable": 1}
+    assert bad_pages_to_raw([]) == bad_pages_to_raw("No bad pages found.") == {"bad_pages_retired": 0, "bad_pages_pending": 0, "bad_pages_unreservable": 0}
+    raw = dict(FakeGpuReader(1, clock=clock).read()[0], **bad_pages_to_raw(recs))
+    g = GpuNormalizer().normalize(raw)
+    assert g["badPages"] == {"retired": 2, "pending": 1, "unreservable": 1}
+    text = exporter.render({"gpus": [g], "host": {}}, {})
+    assert 'klm_gpu_bad_pages{' in text and 'status="pending"} 1' in text and 'status="retired"} 2' in text
+    raw.pop("bad_pages_retired")                    # a driver that does not say: no field, no series
+    g = GpuNormalizer().normalize(raw)
+    assert g["badPages"] is None and "klm_gpu_bad_pages" not in exporter.render({"gpus": [g], "host": {}}, {})

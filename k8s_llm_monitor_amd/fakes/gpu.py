@@ -85,7 +85,7 @@ def _ecc(t: float, i: int) -> GpuState:
         # the driver marks the page bad after the uncorrectable error (retired at the next reload); GPU 5 carries old history
         s.bad_pages_pending = 1 if t >= 20 else 0
     if i == 5:
-        s.bad_pages = 3
+        s.bad_pages = 3 + (1 if t >= 10 else 0)
     return s
 
 

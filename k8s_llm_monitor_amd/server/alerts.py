@@ -41,6 +41,7 @@ class AlertState:
     pods: Dict[str, Dict[str, Any]] = field(default_factory=dict)   # "ns/name" -> {status, restarts, age}
     gpu_count: Optional[int] = None
     ecc_correctable: Dict[int, int] = field(default_factory=dict)
+    bad_pages_retired: Dict[int, int] = field(default_factory=dict)   # GPU index -> retired HBM pages at the last evaluation
     vllm_endpoints: int = 0          # most vLLM endpoints ever seen answering (0 = never seen: no "down" alert)
     evaluations: int = 0
 
@@ -264,6 +265,7 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
     many = len(gpus) > 1
     checked = gpus[:1] if compat.gpu0_only_alerts else gpus
     next_ecc: Dict[int, int] = dict(state.ecc_correctable)
+    next_bad: Dict[int, int] = dict(state.bad_pages_retired)
     for gpu in checked:
         idx = gpu.get("index", 0)
         g = f" {idx}" if many else ""
@@ -300,13 +302,20 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
                 t, d, f = msgs["ecc_ce"]
                 _add(alerts, "minor", f"{k}/ecc_ce", t.format(g=g), d.format(n=ce, d=ce - before), f, edge=True, signal="ecc")
             next_ecc[idx] = ce
-        bp = gpu.get("badPages") or {}
-        n_bp, p_bp, u_bp = (bp.get(x) or 0 for x in ("retired", "pending", "unreservable"))
-        if n_bp or p_bp or u_bp:
-            # retired pages are history the driver has dealt with (minor); pages still waiting, or that could not be taken
-            # out, are memory in use that is known bad (serious)
+        bp = gpu.get("badPages")
+        if isinstance(bp, dict):
+            n_bp, p_bp, u_bp = (bp.get(x) or 0 for x in ("retired", "pending", "unreservable"))
             t, d, f = msgs["bad_pages"]
-            _add(alerts, "serious" if (p_bp or u_bp) else "minor", f"{k}/bad_pages", t.format(g=g), d.format(n=n_bp, p=p_bp, u=u_bp), f, signal="ras")
+            if p_bp or u_bp:
+                # memory that is known bad and still in use (waiting for the next driver reload, or impossible to take out):
+                # level-triggered, serious
+                _add(alerts, "serious", f"{k}/bad_pages", t.format(g=g), d.format(n=n_bp, p=p_bp, u=u_bp), f, signal="ras")
+            else:
+                # retired pages are history the driver has dealt with: say so when the count GROWS (the table shows the count)
+                before = state.bad_pages_retired.get(idx)
+                if before is not None and n_bp > before:
+                    _add(alerts, "minor", f"{k}/bad_pages", t.format(g=g), d.format(n=n_bp, p=0, u=0), f, edge=True, signal="ras")
+            next_bad[idx] = n_bp
         if th.xgmi_link_down_tier in TIERS:
             for link in (gpu.get("xgmi") or {}).get("links") or []:
                 if link.get("state") == "down":
@@ -395,7 +404,7 @@ def check_alerts(host: Mapping[str, Any], gpus: Sequence[Mapping[str, Any]], pod
         if isinstance(ttft, (int, float)):
             _tiered(alerts, msgs, "ttft", "vllm/ttft", float(ttft), th.vllm_ttft_p99_s, msgs["ttft_desc"].format(v=_fmt(ttft, 2)))
 
-    nxt = AlertState(pods=cur_pods, gpu_count=next_gpu_count, ecc_correctable=next_ecc,
+    nxt = AlertState(pods=cur_pods, gpu_count=next_gpu_count, ecc_correctable=next_ecc, bad_pages_retired=next_bad,
                      vllm_endpoints=next_vllm_endpoints, evaluations=state.evaluations + 1)
     return alerts, nxt
 

@@ -212,6 +212,7 @@ class Monitor:
             st = self._alert_state
             doc = {"saved": self.clock(), "pods": st.pods, "gpu_count": st.gpu_count,
                    "ecc_correctable": {str(k): v for k, v in st.ecc_correctable.items()},
+                   "bad_pages_retired": {str(k): v for k, v in st.bad_pages_retired.items()},
                    "vllm_endpoints": st.vllm_endpoints, "evaluations": st.evaluations,
                    "book": self.book.to_state()}
         tmp = self._state_path(f"alert_state.json.tmp.{os.getpid()}")
@@ -228,6 +229,7 @@ class Monitor:
             if self.clock() - float(d.get("saved", 0.0)) <= max_age_s:       # a stale pod table would raise false edges
                 self._alert_state = AlertState(pods={str(k): dict(v) for k, v in d["pods"].items()}, gpu_count=d.get("gpu_count"),
                                                ecc_correctable={int(k): int(v) for k, v in (d.get("ecc_correctable") or {}).items()},
+                                               bad_pages_retired={int(k): int(v) for k, v in (d.get("bad_pages_retired") or {}).items()},
                                                vllm_endpoints=int(d.get("vllm_endpoints", 0)),
                                                evaluations=int(d.get("evaluations", 0)))
                 self.restored["alert_state"] = True

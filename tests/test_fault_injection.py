@@ -79,12 +79,15 @@ def test_ecc_xgmi_gpu_lost_and_kv_pressure(clock):
     mon = stepped_monitor(clock, gpu="ecc")
     mon.tick_all(); clock.advance(16); mon.tick_all()
     assert "gpu/2/ecc_ue" in keys(mon, "critical") and "gpu/2/ecc_ce" in keys(mon, "minor")
-    # retired HBM pages (RAS): old history the driver has dealt with is minor, a page still waiting to be retired serious
-    assert "gpu/5/bad_pages" in keys(mon, "minor") and "gpu/2/bad_pages" not in keys(mon, "serious")
+    # retired HBM pages (RAS): GPU 5 came up with 3 (history: no alert) and gained a fourth (minor, edge); a page still waiting to be
+    # retired is serious for as long as it waits
+    assert "gpu/5/bad_pages" in keys(mon, "minor") and "gpu/2/bad_pages" not in keys(mon, "serious") and "gpu/0/bad_pages" not in keys(mon, "minor")
     clock.advance(6); mon.tick_all()
-    assert "gpu/2/bad_pages" in keys(mon, "serious") and "gpu/5/bad_pages" in keys(mon, "minor")
+    assert "gpu/2/bad_pages" in keys(mon, "serious")
     g = {x["index"]: x for x in mon.get("gpus")}
-    assert g[5]["badPages"] == {"retired": 3, "pending": 0, "unreservable": 0} and g[2]["badPages"]["pending"] == 1 and g[0]["badPages"]["retired"] == 0
+    assert g[5]["badPages"] == {"retired": 4, "pending": 0, "unreservable": 0} and g[2]["badPages"]["pending"] == 1 and g[0]["badPages"]["retired"] == 0
+    clock.advance(40); mon.tick_all()
+    assert "gpu/5/bad_pages" not in keys(mon, "minor") and "gpu/2/bad_pages" in keys(mon, "serious")      # the edge expired, the level did not
     mon = stepped_monitor(clock, gpu="xgmi_down")
     mon.tick_all(); clock.advance(11); mon.tick_all()
     assert any(k.startswith("gpu/3/xgmi/") for k in keys(mon, "critical"))

@@ -222,6 +222,39 @@ def test_gemm_streams_take_row_pitched_operands(env, pad_bytes):
     assert ops.padded_operand(256, 8192, torch.bfloat16, dev).is_contiguous() and ops.padded_operand(256, 12032, torch.bfloat16, dev).is_contiguous()
 
 
+def test_default_dispatch_rates_guard_the_kernel_choice(env):
+    """Loose floors (a third below what the kernels measure) that a wrong default trips: 2048^3 on the 256 x 256 stream runs at
+    ~460 TFLOP/s where the 128 x 128 ring kernel gives ~800; 6144^3 without its split round loses 10 %; 8192^3 on a ring kernel
+    would read ~1000."""
+    torch, ops, dev = env
+    g = torch.Generator(device=dev).manual_seed(99)
+
+    def rate(fn, flop, iters):
+        fn()
+        best = 0.0
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); e1.synchronize()
+            best = max(best, flop * iters / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        return best
+
+    for (M, N, K), floor_bf16, floor_fp8 in (((2048, 2048, 2048), 560.0, 950.0), ((1024, 4096, 4096), 620.0, 1100.0),
+                                             ((6144, 6144, 6144), 1150.0, 2100.0), ((8192, 8192, 8192), 1250.0, 2500.0)):
+        a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        flop, iters = 2.0 * M * N * K, max(3, int(2e12 / (2.0 * M * N * K)))
+        r = rate(lambda: ops.gemm_bf16(a, b, out=c), flop, iters)
+        assert r > floor_bf16, f"bf16 {M}x{N}x{K}: {r:.0f} TFLOP/s on variant {ops.pick_bf16_variant(M, N, K)}"
+        a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+        r8 = rate(lambda: ops.gemm_fp8(a8, b8, out=c), flop, iters)
+        assert r8 > floor_fp8, f"fp8 {M}x{N}x{K}: {r8:.0f} TFLOP/s on variant {ops.pick_mx_variant(M, N, K, 0, 7)}"
+        del a, b, c, a8, b8
+
+
 def test_superblock_tile_order_gives_the_same_product(env):
     """The persistent streams' second tile order (KlmQuadPlan.map = 1: one 16 x 16 super-block of tiles per round of the chip,
     an 8 x 4 patch per XCD; picked by itself for operands well past the Infinity Cache): every tile exactly once, the same bits

@@ -405,12 +405,17 @@ class AmdSmiReader(GpuReader):
             return None
         return v / 1e6 if v > 100000 else v   # reported in microwatts
 
-    def read(self) -> List[Dict[str, Any]]:
+    supports_fast = True
+
+    def read(self, fast: bool = False) -> List[Dict[str, Any]]:
+        """`fast`: the alert watcher's read between two regular samples: the metrics table and VRAM only, the slow-path
+        answers (ECC, bad pages, partitions, processes) from the cache, the slow-path cadence untouched."""
         smi = self._smi
         out = []
         with self._lock:
-            slow = (self._n % self._slow_every) == 0
-            self._n += 1
+            slow = (not fast) and (self._n % self._slow_every) == 0
+            if not fast:
+                self._n += 1
             for i, h in enumerate(self._handles):
                 st = self._static[i]
                 t = time.monotonic()
@@ -430,7 +435,7 @@ class AmdSmiReader(GpuReader):
                     m = {}
                 raw.update(metrics_to_raw(m))
                 raw.update(topology_to_raw(self.topology[i]))
-                if slow or i not in self._slow_cache:
+                if slow or (i not in self._slow_cache and not fast):
                     sc: Dict[str, Any] = {}
                     if self._xgmi_err_supported[i]:
                         try:
@@ -479,7 +484,7 @@ class AmdSmiReader(GpuReader):
                         except Exception:
                             pass
                     self._slow_cache[i] = sc
-                raw.update(self._slow_cache[i])
+                raw.update(self._slow_cache.get(i) or {})
                 out.append(raw)
         return out
 

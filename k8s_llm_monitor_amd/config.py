@@ -42,6 +42,10 @@ class PeriodsConfig:
     # the page's /api/alerts poll (its fallback path; /api/events pushes alerts as they appear). The reference polls every
     # 10 s (monitor.html:608); 4 s keeps the poll path alone under the 10 s target: realtime 5 s + tick + 4 s < 10 s
     page_alert_poll: float = 4.0
+    # the alert watcher: between two realtime ticks the GPUs are read again every `alert_watch` seconds (one amdsmi metrics call
+    # per GPU, ~0.5 ms; no slow-path calls) and, when a tiered signal (HBM %, temperatures, power %) sits in another tier than the
+    # published snapshot says, the realtime tick runs right away instead of at its next grid point. 0 = off.
+    alert_watch: float = 1.0
     probe: float = 0.0               # RCCL probe re-run period, 0 = only on demand
     peers: float = 5.0               # cluster view: peer poll period
 
@@ -173,7 +177,7 @@ REFERENCE_PRESET = {
                "language": "zh", "reference_text": True, "reference_rules_only": True, "alert_extra_fields": False,
                "alerts_per_request": True},
     "thresholds": {"gpu_temp": [-1.0, 75.0, 85.0]},                       # :183-184
-    "periods": {"page_alert_poll": 10.0},                                 # monitor.html:608
+    "periods": {"page_alert_poll": 10.0, "alert_watch": 0.0},             # monitor.html:608; the reference evaluates per request
 }
 
 
@@ -268,6 +272,8 @@ def validate(cfg: Config) -> None:
     # the page substitutes this into setInterval(fetchAlerts, ms): 0 or a negative value would hammer /api/alerts
     if cfg.periods.page_alert_poll < 0.25:
         raise ConfigError(f"periods.page_alert_poll must be >= 0.25 s (got {cfg.periods.page_alert_poll})")
+    if cfg.periods.alert_watch != 0 and cfg.periods.alert_watch < 0.1:
+        raise ConfigError(f"periods.alert_watch must be 0 (off) or >= 0.1 s (got {cfg.periods.alert_watch})")
     if cfg.notify.min_tier not in ("minor", "serious", "critical"):
         raise ConfigError("notify.min_tier must be minor, serious or critical")
     if cfg.notify.debounce_s < 0:

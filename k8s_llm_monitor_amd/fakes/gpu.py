@@ -138,6 +138,7 @@ SCENARIOS: Dict[str, Scenario] = {
 
 class FakeGpuReader:
     kind = "fake"
+    supports_fast = True
 
     def __init__(self, n_gpus: int = 8, scenario: Any = "", clock: Callable[[], float] = time.monotonic):
         if callable(scenario):
@@ -167,7 +168,7 @@ class FakeGpuReader:
     def close(self) -> None:
         pass
 
-    def read(self) -> List[Dict[str, Any]]:
+    def read(self, fast: bool = False) -> List[Dict[str, Any]]:
         now = self.clock()
         t = now - self.t0
         dt = 0.0 if self._last_t is None else max(0.0, now - self._last_t)

@@ -24,7 +24,7 @@ from ..collectors.vllm import VllmSource, open_vllm_source
 from ..config import Config
 from ..utils.ringbuffer import HistoryStore
 from ..utils.timefmt import parse_duration
-from .alerts import AlertBook, AlertState, check_alerts, empty_alerts
+from .alerts import AlertBook, AlertState, check_alerts, empty_alerts, tier_of
 
 
 class PeriodicTask:
@@ -164,6 +164,10 @@ class Monitor:
         self._hist_lock = threading.Lock()
 
         self._lock = threading.RLock()
+        self._tick_lock = threading.Lock()
+        from ..collectors.gpu import GpuNormalizer
+        self._watch_norm = GpuNormalizer()
+        self.watch_pokes = 0        # early realtime ticks the alert watcher asked for
         self._snap: Dict[str, Any] = {"host": {"cpu": {}, "memory": {}, "disk": {}}, "gpus": [], "pods": [],
                                       "vllm": {"available": False}, "alerts": empty_alerts(),
                                       "t_host": 0.0, "t_gpu": 0.0, "t_pods": 0.0, "t_vllm": 0.0, "t_alerts": 0.0}
@@ -183,6 +187,9 @@ class Monitor:
             "pods": PeriodicTask("pods", self.tick_pods, c.periods.pods),
             "vllm": PeriodicTask("vllm", self.tick_vllm, c.periods.vllm),
         }
+        if (c.periods.alert_watch > 0 and c.periods.alert_watch < c.periods.realtime and not c.compat.alerts_per_request
+                and getattr(self.gpu.reader, "supports_fast", False)):
+            self.tasks["watch"] = PeriodicTask("watch", self.tick_watch, c.periods.alert_watch)
         from ..collectors.peers import PeerPoller
         self.peers = PeerPoller(c.sources.peers, timeout=min(2.0, c.periods.peers))
         if self.peers.peers:
@@ -242,6 +249,10 @@ class Monitor:
 
     # ---- ticks -------------------------------------------------------------------------
     def tick_realtime(self) -> None:
+        with self._tick_lock:                 # the realtime task and the alert watcher's early tick never run it concurrently
+            self._tick_realtime()
+
+    def _tick_realtime(self) -> None:
         host = self.host.collect()
         gpus = self.gpu.sample()
         if self.cfg.sources.gpu_processes and gpus:
@@ -257,6 +268,44 @@ class Monitor:
         self.store.record(now, hist.history_values(host, gpus, vllm if vllm.get("available") else None))
         self._evaluate(now)
         self._emit("realtime", {"host": host, "gpus": gpus})
+
+    # ---- the alert watcher ----------------------------------------------------------------
+    def _tier_signature(self, gpus) -> Dict[str, Optional[str]]:
+        """key -> tier of the tiered GPU signals (the rules of server/alerts.py that compare a value with three thresholds)."""
+        th = self.cfg.thresholds
+        sig: Dict[str, Optional[str]] = {}
+        for g in gpus or []:
+            k = f"gpu/{g.get('index', 0)}"
+            used, total = g.get("memoryUsed"), g.get("memoryTotal")
+            if isinstance(used, (int, float)) and isinstance(total, (int, float)) and total > 0:
+                sig[k + "/hbm"] = tier_of(used / total * 100.0, th.hbm)
+            if isinstance(g.get("temperature"), (int, float)):
+                sig[k + "/temp"] = tier_of(float(g["temperature"]), th.gpu_temp)
+            if isinstance(g.get("temperatureHbm"), (int, float)):
+                sig[k + "/hbm_temp"] = tier_of(float(g["temperatureHbm"]), th.hbm_temp)
+            pw, cap = g.get("powerW"), g.get("powerCapW")
+            if isinstance(pw, (int, float)) and isinstance(cap, (int, float)) and cap > 0:
+                sig[k + "/power"] = tier_of(pw / cap * 100.0, th.power_pct)
+        return sig
+
+    def tick_watch(self) -> None:
+        """Between two realtime ticks: one cheap read of the GPUs through the watcher's OWN normaliser (the published path's
+        accumulator deltas are not touched); when a tiered signal sits in another tier than the published snapshot says, the
+        realtime tick runs now. Threshold crossing -> alert is then bounded by `periods.alert_watch`, not `periods.realtime`."""
+        reader = self.gpu.reader
+        if not getattr(reader, "supports_fast", False):
+            return
+        try:
+            quick = [self._watch_norm.normalize(r) for r in reader.read(fast=True)]
+        except Exception:
+            return                                      # the regular tick reports reader errors
+        with self._lock:
+            published = self._snap["gpus"]
+            if not self._snap["t_gpu"]:
+                return                                  # nothing published yet: the first regular tick is about to come
+        if self._tier_signature(quick) != self._tier_signature(published):
+            self.watch_pokes += 1
+            self.tick_realtime()
 
     def tick_pods(self) -> None:
         pods = self.kube.pods()
@@ -443,5 +492,6 @@ class Monitor:
                            "prometheus": self.prom.last_error},
                 "history_points": {n: len(self.store.series(n)) for n in self.store.names()[:64]},
                 "alert_evaluations": self._alert_state.evaluations,
+                "alert_watch": {"period_s": self.cfg.periods.alert_watch if "watch" in self.tasks else 0.0, "early_ticks": self.watch_pokes},
                 "state_dir": self.state_dir or None, "restored": self.restored,
                 "webhook": self.notifier.stats() if self.notifier is not None else None}

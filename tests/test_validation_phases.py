@@ -3,6 +3,8 @@ import json
 import time
 import urllib.request
 
+import pytest
+
 from k8s_llm_monitor_amd.validation import phases, rocprof
 
 
@@ -137,6 +139,47 @@ def test_alert_latency_loop_measures_a_distribution_on_every_path():
     assert abs(level["frac"] - 0.10) < 1e-9                                       # everything released
     s = phases.summarize({"alert_latency": r})
     assert s["pass"] == {"latency": True} and s["alert_latency_crossings"] == 6 and s["sse_latency_max_s"] == r["sse"]["max"]
+
+
+def test_alert_watcher_runs_the_tick_early_when_a_tier_changes():
+    """`periods.alert_watch`: between two realtime ticks (here 30 s apart: none happens during the test) the GPUs are read again
+    through the watcher's own normaliser; a tiered signal in another tier than the published snapshot runs the tick at once."""
+    import time
+    from k8s_llm_monitor_amd.collectors.gpu import GpuSource
+    from k8s_llm_monitor_amd.config import demo_config
+    from k8s_llm_monitor_amd.fakes.gpu import FakeGpuReader, GpuState
+    from k8s_llm_monitor_amd.server.sampler import Monitor
+    level = {"frac": 0.10, "temp": 50.0}
+    scen = lambda t, i: GpuState(hbm_frac=level["frac"], temp=level["temp"])
+    cfg = demo_config(periods={"realtime": 30.0, "alert_watch": 0.1}, sources={"kube": "none", "vllm": "none"})
+    mon = Monitor(cfg, gpu=GpuSource(FakeGpuReader(1, scenario=scen))).start()
+    try:
+        assert "watch" in mon.tasks and mon.stats()["alert_watch"]["period_s"] == 0.1
+        time.sleep(0.5)
+        assert mon.watch_pokes == 0 and mon.tasks["realtime"].calls == 1 and mon.alerts_public() == {"minor": [], "serious": [], "critical": []}
+        level["frac"] = 0.72                                    # crosses 70 %: the next watcher read sees another tier
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 3.0 and not mon.alerts_public()["minor"]:
+            time.sleep(0.01)
+        dt = time.perf_counter() - t0
+        assert [a["key"] for a in mon.alerts_public()["minor"]] == ["gpu/0/hbm"] and dt < 0.6 and mon.watch_pokes == 1
+        time.sleep(0.4)
+        assert mon.watch_pokes == 1                             # the published snapshot now says "minor": nothing more to do
+        level["frac"], level["temp"] = 0.10, 96.0               # one clears, another appears: one early tick for both
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 3.0 and mon.alerts_public()["minor"]:
+            time.sleep(0.01)
+        assert time.perf_counter() - t0 < 0.6 and mon.watch_pokes == 2
+        assert any(a["key"] == "gpu/0/temp" for tier in mon.alerts_public().values() for a in tier)
+        assert mon.tasks["realtime"].calls == 1                 # the task's own grid was not disturbed
+    finally:
+        mon.stop()
+    # off: by configuration, under the reference preset (alerts are evaluated per request there), for a source without a fast read
+    off = Monitor(demo_config(periods={"alert_watch": 0.0}, sources={"kube": "none", "vllm": "none"}))
+    ref = Monitor(demo_config(compat={"reference_defaults": True}, sources={"kube": "none", "vllm": "none"}))
+    assert "watch" not in off.tasks and "watch" not in ref.tasks and ref.cfg.periods.alert_watch == 0.0
+    with pytest.raises(Exception, match="alert_watch"):
+        demo_config(periods={"alert_watch": 0.01})
 
 
 def test_throttle_phase_sees_both_alerts_appear_and_clear():

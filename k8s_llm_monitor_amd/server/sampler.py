@@ -24,7 +24,7 @@ from ..collectors.vllm import VllmSource, open_vllm_source
 from ..config import Config
 from ..utils.ringbuffer import HistoryStore
 from ..utils.timefmt import parse_duration
-from .alerts import AlertBook, AlertState, check_alerts, empty_alerts, tier_of
+from .alerts import THERMAL_REASONS, AlertBook, AlertState, check_alerts, empty_alerts, tier_of
 
 
 class PeriodicTask:
@@ -286,6 +286,12 @@ class Monitor:
             pw, cap = g.get("powerW"), g.get("powerCapW")
             if isinstance(pw, (int, float)) and isinstance(cap, (int, float)) and cap > 0:
                 sig[k + "/power"] = tier_of(pw / cap * 100.0, th.power_pct)
+            # the level-triggered conditions that are a yes / no: power-cap throttling, thermal throttling, links down
+            res = (g.get("throttle") or {}).get("residencyPercent") or {}
+            sig[k + "/throttle_ppt"] = "on" if (isinstance(res.get("ppt"), (int, float)) and res["ppt"] > 50.0) else None
+            sig[k + "/throttle_thm"] = "on" if any((res.get(r) or 0) > 0 for r in THERMAL_REASONS) else None
+            down = sorted(str(l.get("link")) for l in (g.get("xgmi") or {}).get("links") or [] if l.get("state") == "down")
+            sig[k + "/xgmi_down"] = ",".join(down) or None
         return sig
 
     def tick_watch(self) -> None:

@@ -25,7 +25,9 @@ BASELINE.json metric as flat scalars, ``gemm_variant``, ``rccl_ranks_seen`` and 
 per n. Everything else (per-phase rows, the full curves, llm_serving, vendor_comparison) goes to
 ``bench_detail.json`` (its path is in the line as ``detail``) and, as progress, to stderr.
 ``--time-budget S`` (default 540) sheds sections and validation phases, longest first, rather than
-overrunning; what was shed is listed in the line (``shed``).
+overrunning; what was shed is listed in the line (``shed``). A section that was started and never returns
+(a wedged collective) is ended by a watchdog ``--watchdog-grace`` seconds after the budget: rank 0 prints the
+line from the timed number it already holds, with ``watchdog`` naming the section.
 
 Launch: ``python bench.py --gpus N`` starts its own N ranks (one process per GPU under
 ``torch.distributed.run``, as a CHILD of a parent that never touches the GPU), or launch the ranks
@@ -78,6 +80,9 @@ def parse_args():
                          "validation phases that do not fit are shed, longest first, instead of overrunning")
     ap.add_argument("--min-warmup-seconds", type=float, default=2.0,
                     help="warm up for at least this long (on top of --warmup steps) so that `value` is a steady-state figure")
+    ap.add_argument("--watchdog-grace", type=float, default=40.0,
+                    help="with a time budget: this long after the budget has run out every rank ends itself, rank 0 printing the "
+                         "result line from the timed number it already holds (a section that never returns must not cost the record)")
     ap.add_argument("--detail-out", default="", help="where the full result goes (default: bench_detail.json next to bench.py)")
     ap.add_argument("--rehearsal-phases", default="",
                     help="--cpu-rehearsal only: stand-in validation phases 'name:priced_s:actual_s,...' (tests of the time budget)")
@@ -202,7 +207,12 @@ def main():
     a.budget = phases.Budget(a.time_budget if a.time_budget > 0 else None, t0=time.monotonic() - spent)
     if os.environ.get("KLM_BENCH_LAUNCHER") == "self" and a.budget.seconds is not None and not (a.no_probe or a.no_native_probe or a.cpu_rehearsal):
         a.budget.reserve_s += 25.0 * len([n for n in (1, 2, 4, 8) if n <= a.gpus])      # the parent's native probe comes after the ranks
+    a.section, a.provisional, dog = "start", None, None
+    if a.budget.seconds is not None and a.watchdog_grace > 0:
+        dog = benchlib.Watchdog(a, rank, a.budget.seconds + a.watchdog_grace, a.budget.t0).start()
     result = benchlib.run(a, rank=rank, world=world, dev=dev, ops=ops)
+    if dog is not None:
+        dog.cancel()
     if rank == 0:
         result.setdefault("launcher", "torch.distributed.run" if env_world is not None and
                           os.environ.get("KLM_BENCH_LAUNCHER") != "self" else "single process")
@@ -217,8 +227,12 @@ def main():
               file=sys.stderr, flush=True)
         print(json.dumps(benchlib.compact(result, path)), flush=True)
     if distributed:
-        dist.barrier(group=a.ctrl_group)
-        dist.destroy_process_group()
+        try:
+            dist.barrier(group=a.ctrl_group)
+            dist.destroy_process_group()
+        except RuntimeError as e:
+            # a peer that is gone (its own failure is what the launcher reports) must not turn this rank's finished work into one
+            print(f"[bench] rank {rank}: closing barrier: {str(e).splitlines()[0][:200]}", file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

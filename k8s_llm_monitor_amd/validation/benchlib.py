@@ -274,6 +274,10 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     wall["timed_steps_only"] = round(dt, 4)
     ms = dt / a.steps * 1e3
     tflops = load.flops * world / (dt / a.steps) / 1e12
+    head = _headline(a, world, size, ms, tflops, dev)
+    # from here on the number exists: the watchdog (bench.py) prints it if a later, untimed section never returns
+    a.provisional = (head, extras)
+    a.section = "after_timed_steps"
     if dd:
         algbw = load.allreduce_bytes / (dt / a.steps) / 1e9
         extras["allreduce_bytes_per_step"] = load.allreduce_bytes
@@ -283,6 +287,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
 
     # the same step on the kernel the N > 1 ranks run (one workgroup per tile, variant 4), still on one GPU: the point a
     # scaling curve's efficiency should be taken against, so that it does not include a kernel change
+    a.section = "dp_kernel"
     if gpu and not dd and load.gemm_variant not in (None, 4) and size % 256 == 0 and allowed("dp_kernel"):
         t_sec = time.perf_counter()
         dp = _Load(torch, dist, ops, dev, world, size, distributed=False, dp_kernel=True)
@@ -298,6 +303,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     if sampler is not None:
         extras["sampler_stats"] = sampler.stats()
 
+    a.section = "rccl_probe"
     t_sec = time.perf_counter()
     if not getattr(a, "no_probe", False) and allowed("probe"):
         # the RCCL all-reduce curve at EVERY n in {1, 2, 4, 8} <= world from this one launch (outside the
@@ -328,6 +334,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
         except Exception as e:
             extras["rccl_curves"] = {"error": f"{type(e).__name__}: {e}"}
 
+    a.section = "xgmi_fidelity"
     which = getattr(a, "validation_phases", "all") or "all"
     xf = None
     if dd and not a.no_validation and (which == "all" or "xgmi" in which.split(",")) and allowed("xgmi"):
@@ -341,6 +348,7 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
 
     wall["rccl_probe_and_xgmi_check"] = round(time.perf_counter() - t_sec, 2)
     t_sec = time.perf_counter()
+    a.section = "other_kernels"
     if not a.no_validation and rank == 0 and gpu and which == "all" and allowed("other_kernels"):
         # the other validation-load kernels, 1 s each (outside the timed region)
         try:
@@ -356,11 +364,13 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             extras["vendor_comparison"] = vendor_comparison(torch, ops, dev, size)
         except Exception as e:
             extras["other_kernels"] = {"error": f"{type(e).__name__}: {e}"}
+    a.section = "llm_serving"
     if not a.no_validation and rank == 0 and gpu and which == "all" and allowed("llm_serving"):
         extras["llm_serving"] = llm_serving_rates(torch, dev)
 
     wall["other_kernels_and_llm_serving"] = round(time.perf_counter() - t_sec, 2)
     t_sec = time.perf_counter()
+    a.section = "validation_phases"
     local_phases = ",".join(p for p in which.split(",") if p != "xgmi")
     v: Dict[str, Any] = {}
     spec = getattr(a, "rehearsal_phases", "")
@@ -394,6 +404,12 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
     extras["time_budget_s"] = None if budget is None else budget.seconds
     extras["shed"] = shed
 
+    a.section = "done"
+    return {**head, **extras}
+
+
+def _headline(a, world: int, size: int, ms: float, tflops: float, dev) -> Dict[str, Any]:
+    """The contract's keys of the result line (everything else is `extras`)."""
     return {
         "metric": "monitored validation-load throughput: bf16 MFMA burner training step (fwd+dgrad+wgrad GEMMs, DP all-reduce over RCCL) under telemetry sampling",
         "value": round(tflops, 2),
@@ -413,8 +429,75 @@ def run(a, rank: int, world: int, dev, ops) -> Dict[str, Any]:
             "seq_len": size,
             "parallelism": f"dp{world}" if world > 1 else "single",
         },
-        **extras,
     }
+
+
+class Watchdog:
+    """Last line of defence for the output contract. The time budget sheds sections BEFORE they start; it cannot help when a
+    section that was started never returns (a collective on a communicator one rank never joined, a wedged child). At
+    `deadline_s` after the run's start every rank's watchdog thread ends its process; rank 0 first prints the compact line
+    from what is known by then -- the timed number (complete since `a.provisional` was set) plus `watchdog`: which section
+    was running -- so that the driver records the measurement instead of a timeout. Before the timed steps have finished
+    there is no number to print and the exit status says so (3)."""
+
+    def __init__(self, a, rank: int, deadline_s: float, t0: float, out=None, exit_fn=None):
+        import threading
+        self.a, self.rank, self.deadline_s, self.t0 = a, rank, deadline_s, t0
+        self.out, self.exit_fn = out, exit_fn
+        self._cancel = threading.Event()
+        self._th = threading.Thread(target=self._run, name="klm-bench-watchdog", daemon=True)
+
+    def start(self) -> "Watchdog":
+        self._th.start()
+        return self
+
+    def cancel(self) -> None:
+        self._cancel.set()
+
+    def line(self) -> Optional[Dict[str, Any]]:
+        prov = getattr(self.a, "provisional", None)
+        if prov is None:
+            return None
+        head, extras = prov
+        res = {**head, **dict(extras)}
+        res.setdefault("shed", [])
+        res.setdefault("wall_seconds", {"total": round(time.monotonic() - self.t0, 2), "incomplete": True})
+        res["watchdog"] = {"fired_after_s": round(time.monotonic() - self.t0, 1), "section": getattr(self.a, "section", "?")}
+        return res
+
+    def _run(self) -> None:
+        import json
+        import os
+        import sys
+        # rank 0 prints at the deadline and leaves last: a rank waiting for it at the closing (gloo) barrier would see its exit
+        # as a broken connection, so the others go 2 s after the deadline and rank 0 4 s after it
+        wait = self.deadline_s - (time.monotonic() - self.t0) + (0.0 if self.rank == 0 else 2.0)
+        if self._cancel.wait(max(0.0, wait)):
+            return
+        code = 0
+        if self.rank == 0:
+            res = self.line()
+            if res is None:
+                print(f"[bench] watchdog: no timed result after {self.deadline_s:.0f} s (section {getattr(self.a, 'section', 'start')})",
+                      file=sys.stderr, flush=True)
+                code = 3
+            else:
+                path = ""
+                try:
+                    path = write_detail(res, detail_path(self.a))
+                except Exception:
+                    path = ""
+                print(f"[bench] watchdog: section {res['watchdog']['section']} did not return; printing the timed result",
+                      file=sys.stderr, flush=True)
+                line = compact(res, path)
+                line["watchdog"] = res["watchdog"]
+                (self.out or sys.stdout).write(json.dumps(line) + "\n")
+                (self.out or sys.stdout).flush()
+            if self.exit_fn is None:
+                time.sleep(4.0)
+        elif getattr(self.a, "provisional", None) is None:
+            code = 3
+        (self.exit_fn or os._exit)(code)
 
 
 def llm_serving_rates(torch, dev) -> Dict[str, Any]:

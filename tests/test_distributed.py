@@ -151,6 +151,45 @@ def test_four_ranks_wait_for_rank0_validation_and_the_budget_sheds_phases(tmp_pa
     assert "probe" in d["shed"] and "quick" in d["shed"] and "peak_busbw_GBps" not in d
 
 
+@pytest.mark.timeout(240)
+def test_a_section_that_never_returns_still_leaves_the_result_line(tmp_path):
+    """The budget sheds sections before they start; a section that was started and hangs (on hardware: a collective one rank
+    never joined) is ended by the watchdog. Rank 0 prints the compact line from the timed number it already holds, every
+    rank exits 0, and the line says which section was cut."""
+    import time
+    t0 = time.time()
+    r = torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-rehearsal", "--size", "128", "--steps", "2", "--warmup", "1",
+                     "--no-probe", "--time-budget", "16", "--watchdog-grace", "1", "--rehearsal-phases", "hang:0.5:600",
+                     "--detail-out", str(tmp_path / "d.json")])
+    took = time.time() - t0
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d, full = check_bench_line(r.stdout, 2, 2, 1)
+    assert d["watchdog"]["section"] == "validation_phases" and 16.5 < d["watchdog"]["fired_after_s"] < 30 and took < 60
+    assert full["watchdog"] == d["watchdog"] and "did not return" in r.stderr
+
+
+def test_watchdog_unit():
+    import io
+    import types
+    from k8s_llm_monitor_amd.validation import benchlib
+    import time
+    codes = []
+    # no timed result yet: nothing to print, exit status 3
+    a = types.SimpleNamespace(provisional=None, section="start", detail_out="")
+    out = io.StringIO()
+    benchlib.Watchdog(a, 0, 0.05, time.monotonic(), out=out, exit_fn=codes.append).start()._th.join(5)
+    assert codes == [3] and out.getvalue() == ""
+    # cancelled in time: nothing happens
+    w = benchlib.Watchdog(a, 0, 0.2, time.monotonic(), out=out, exit_fn=codes.append).start()
+    w.cancel()
+    w._th.join(5)
+    assert codes == [3]
+    # a rank other than 0 prints nothing
+    a.provisional = ({"metric": "m", "value": 1.0}, {"shed": []})
+    benchlib.Watchdog(a, 1, 0.0, time.monotonic() - 5, out=out, exit_fn=codes.append).start()._th.join(5)
+    assert codes == [3, 0] and out.getvalue() == ""
+
+
 def test_compact_line_stays_under_the_limit_whatever_the_run_produced():
     """The line is built from a fixed set of scalars; if a future field ever bloats it, optional parts are dropped, never the
     contract's keys (and the 8-rank shape of the result, with four curves from both executors, fits as it is)."""

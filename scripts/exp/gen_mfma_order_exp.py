@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Generates scripts/exp/native/mfma_order_power.hip: register-only MFMA loops whose instruction ORDER is written out (one asm
+block per variant, explicit registers, accumulators in place), to price what the order of a K tile's MFMAs costs in energy.
+The card sits on its 1400 W cap under the burner, so the sustained rate of a loop IS its energy per FLOP.
+
+Every variant issues the same 128 MFMAs of 16x16x32 bf16 (or 32 of 32x32x16) per loop pass on the same 8 + 8 random fragments;
+the second half of a pass runs on -A so the accumulators return to ~0 (a GEMM's accumulators are zero-mean random walks)."""
+import os
+
+A0, B0, AN = 40, 72, 104
+
+
+def frag(base, i):
+    return f"v[{base + 4 * i}:{base + 4 * i + 3}]"
+
+
+def order16(kind):
+    out = []
+    for i in range(64):
+        if kind == "m":
+            m, n = i >> 3, i & 7
+        elif kind == "m_snake":
+            m = i >> 3
+            n = 7 - (i & 7) if m & 1 else i & 7
+        elif kind == "n":
+            n, m = i >> 3, i & 7
+        elif kind == "n_snake":
+            n = i >> 3
+            m = 7 - (i & 7) if n & 1 else i & 7
+        elif kind == "diag":
+            m, n = i & 7, ((i & 7) + (i >> 3)) & 7
+        elif kind == "block2":      # 2 x 2 blocks of tiles, walked so that every step changes ONE source
+            blk, j = i >> 2, i & 3
+            bm, bn = blk >> 2, blk & 3
+            if bm & 1:
+                bn = 3 - bn
+            dm, dn = ((0, 0), (0, 1), (1, 1), (1, 0))[j]
+            m, n = 2 * bm + dm, 2 * bn + dn
+        elif kind in ("zigzag2", "zigzag2n"):
+            # two rows at a time, every step changes exactly ONE source: (r0,n) (r1,n) (r1,n') (r0,n') (r0,n'') ..
+            p, j = i >> 4, i & 15
+            col, k = j >> 1, j & 1
+            n = 7 - col if p & 1 else col
+            r = (k ^ (col & 1))            # 0 1 | 1 0 | 0 1 ..
+            if p & 1:
+                r ^= 1                      # the pair before ended on its row 0 (col 7: k=1 -> r=0): start the next on ITS row 0? see assert
+            m = 2 * p + r
+            if kind == "zigzag2n":
+                m, n = n, m
+        out.append((m, n))
+    assert len(set(out)) == 64
+    if kind.startswith("zigzag2"):
+        assert all((a[0] != b[0]) + (a[1] != b[1]) == 1 for a, b in zip(out, out[1:])), out
+    return out
+
+
+def body16(kind, bounded=True):
+    o = []
+    for h in (0, 1):
+        abase = AN if (h and bounded) else A0
+        for m, n in order16(kind):
+            c = 4 * (8 * m + n)
+            o.append(f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], {frag(B0, n)}, {frag(abase, m)}, a[{c}:{c + 3}]")
+    return o
+
+
+def body32(kind):
+    """16 accumulator tiles of 32x32 (16 registers each); fragments 0..3 are k-step 0, 4..7 k-step 1."""
+    o = []
+    for h in (0, 1):
+        abase = AN if h else A0
+        for ks in (0, 1):
+            for i in range(16):
+                m, n = i >> 2, i & 3
+                if kind == "m_snake" and m & 1:
+                    n = 3 - n
+                c = 16 * (4 * m + n)
+                o.append(f"v_mfma_f32_32x32x16_bf16 a[{c}:{c + 15}], {frag(B0, 4 * ks + n)}, {frag(abase, 4 * ks + m)}, a[{c}:{c + 15}]")
+    return o
+
+
+VARIANTS = [("16x16x32 m-major (the streams' order)", body16("m")), ("16x16x32 m-major snake", body16("m_snake")),
+            ("16x16x32 n-major", body16("n")), ("16x16x32 n-major snake", body16("n_snake")),
+            ("16x16x32 2x2 blocks, one source changes per step", body16("block2")),
+            ("16x16x32 zigzag over row pairs, one source changes per step", body16("zigzag2")),
+            ("16x16x32 zigzag over column pairs", body16("zigzag2n")),
+            ("16x16x32 diagonal (no shared source)", body16("diag")),
+            ("32x32x16 m-major", body32("m")), ("32x32x16 m-major snake", body32("m_snake")),
+            ("16x16x32 m-major, growing accumulators", body16("m", bounded=False))]
+
+
+def kernel(idx, lines):
+    pre = ["s_mov_b32 s64, %[p0]", "s_mov_b32 s65, %[p1]", "s_mov_b32 s66, %[iters]"]
+    for i in range(16):
+        base = A0 + 4 * i          # A fragments then B fragments: v40..v103
+        pre += [f"global_load_dwordx4 v[{base}:{base + 3}], %[off], s[64:65]", "s_add_u32 s64, s64, 0x1000", "s_addc_u32 s65, s65, 0"]
+    pre += [f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)]
+    pre += ["s_waitcnt vmcnt(0)"]
+    pre += [f"v_xor_b32 v{AN + i}, 0x80008000, v{A0 + i}" for i in range(32)]
+    pre += ["s_nop 4", "s_memtime s[68:69]", "s_memrealtime s[70:71]", "s_waitcnt lgkmcnt(0)", "1:"]
+    post = ["s_sub_u32 s66, s66, 1", "s_cmp_lg_u32 s66, 0", "s_cbranch_scc1 1b", "s_memtime s[72:73]", "s_memrealtime s[74:75]", "s_waitcnt lgkmcnt(0)",
+            "s_sub_u32 %[dc], s72, s68", "s_sub_u32 %[dr], s74, s70", "s_nop 15", "s_nop 15", "v_accvgpr_read_b32 %[r], a0"]
+    text = "".join(f'      "{l}\\n\\t"\n' for l in pre + lines + post)
+    clob = ", ".join(f'"{c}"' for c in ["memory", "scc"] + [f"s{i}" for i in range(64, 76)] + [f"v{i}" for i in range(40, 136)] + [f"a{i}" for i in range(256)])
+    return f"""__global__ __launch_bounds__(256) void kern{idx}(const char* __restrict__ src, float* __restrict__ sink, int iters) {{
+  const unsigned off = threadIdx.x * 16u;
+  const unsigned long long p = (unsigned long long)src;
+  const unsigned p0 = __builtin_amdgcn_readfirstlane((unsigned)p), p1 = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  float r;
+  unsigned dc, dr;
+  asm volatile(
+{text}      : [r] "=v"(r), [dc] "=s"(dc), [dr] "=s"(dr)
+      : [p0] "s"(p0), [p1] "s"(p1), [iters] "s"(iters), [off] "v"(off)
+      : {clob});
+  if (r == 12345.678f) sink[0] = r;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sink[2] = (float)dc / (float)dr * 100.0f;     // shader clock in MHz (s_memrealtime: 100 MHz)
+}}
+"""
+
+
+MAIN = r"""
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+int main(int argc, char** argv) {
+  const double secs = argc > 1 ? atof(argv[1]) : 3.0;
+  const int rounds = argc > 2 ? atoi(argv[2]) : 3;
+  int cus = 0;
+  CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+  std::vector<unsigned short> h(4096 * 8);
+  srand(7);
+  for (auto& x : h) {     // bf16 uniform [-1, 1)
+    float f = (float)rand() / 2147483648.f * 2.f - 1.f;
+    unsigned u; memcpy(&u, &f, 4); x = (unsigned short)(u >> 16);
+  }
+  char* src; float* sink;
+  CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&sink, 16));
+  CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const double mac_per_pass_wave = 128.0 * 16 * 16 * 32;
+  const int it = 10000;
+  printf("{\"cus\": %d, \"rows\": [\n", cus);
+  for (int r = 0; r < rounds; ++r)
+    for (int which = 0; which < NW; ++which) {
+      double t_total = 0; long launches = 0;
+      CK(hipEventRecord(e0));
+      while (true) {
+        for (int q = 0; q < 5; ++q) { launch(which, cus, src, sink, it); ++launches; }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        t_total = ms * 1e-3;
+        if (t_total >= secs) break;
+      }
+      const double flops = 2.0 * mac_per_pass_wave * it * 4.0 * cus * launches / t_total;
+      float mhz = 0; CK(hipMemcpy(&mhz, sink + 2, 4, hipMemcpyDeviceToHost));
+      // busy: the rate over what 4 SIMDs x 1024 FLOP per clock would give at the clock the last launch ran at
+      printf("  {\"round\": %d, \"variant\": \"%s\", \"seconds\": %.3f, \"tflops\": %.1f, \"clock_mhz\": %.0f, \"mfma_busy\": %.3f}%s\n", r, names[which], t_total, flops / 1e12,
+             mhz, flops / (4.0 * cus * 1024.0 * mhz * 1e6),
+             (r == rounds - 1 && which == NW - 1) ? "" : ",");
+      fflush(stdout);
+    }
+  printf("]}\n");
+  return 0;
+}
+"""
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "native", "mfma_order_power.hip")
+    with open(out, "w") as f:
+        f.write("// GENERATED by scripts/exp/gen_mfma_order_exp.py -- do not edit.\n#include <hip/hip_runtime.h>\n#include <cstdio>\n"
+                "#include <cstdlib>\n#include <cstring>\n#include <vector>\n\n")
+        for i, (_, lines) in enumerate(VARIANTS):
+            f.write(kernel(i, lines))
+        f.write(f"#define NW {len(VARIANTS)}\nstatic const char* names[NW] = {{" + ", ".join('"%s"' % n for n, _ in VARIANTS) + "};\n")
+        f.write("static void launch(int w, int cus, const char* src, float* sink, int it) {\n  switch (w) {\n")
+        for i in range(len(VARIANTS)):
+            f.write(f"    case {i}: hipLaunchKernelGGL(kern{i}, dim3(cus), dim3(256), 0, 0, src, sink, it); break;\n")
+        f.write("  }\n}\n")
+        f.write(MAIN)
+    print(out)
+
+
+if __name__ == "__main__":
+    main()

@@ -57,10 +57,33 @@ STORE_CACHE = ""    # cache-policy bits on the epilogue's stores (" nt": streami
 DMA_CACHE = ""      # cache-policy bits on the LDS-DMA (" sc0", " sc1", " nt", ..): experiment bodies only
 
 
+# The ORDER of a k-step's 64 MFMAs over the 8 x 8 accumulator tiles. On a card that sits on its power cap the rate is energy per
+# FLOP, and what an MFMA costs depends on which of its sources the one before it used (scripts/exp/gen_mfma_order_exp.py,
+# register-only loops on the cap: tile-row-major 2100 TFLOP/s, the same as a snake 2135, no shared source 2035, and 2182 when
+# every step changes exactly ONE source and the two sources take turns):
+#   "rows"    m-tile-major: 8 consecutive MFMAs share the A fragment, at a row change both sources change (rounds 2 - 3)
+#   "zigzag"  two tile rows at a time: (r0,n) (r1,n) (r1,n') (r0,n') (r0,n'') .., the next pair of rows walks back; every step
+#             changes one source, never both
+MFMA_ORDER = os.environ.get("KLM_GEN_MFMA_ORDER", "zigzag")
+
+
+def tile_of_step(j, order=None):
+    """(m tile, n tile) of MFMA j < 64 of a k-step."""
+    order = order or MFMA_ORDER
+    if order == "rows":
+        return j // 8, j % 8
+    p, q = j >> 4, j & 15
+    col, k = q >> 1, q & 1
+    n = 7 - col if p & 1 else col
+    r = k ^ (col & 1) ^ (p & 1)
+    return 2 * p + r, n
+
+
 def mfma(i, czero=False):
-    """MFMA i of a K tile: k-step i // 64, m tile (i % 64) // 8, n tile i % 8 (NMAJOR: the roles of m and n swapped).
+    """MFMA i of a K tile: k-step i // 64, accumulator tile by MFMA_ORDER (NMAJOR: the roles of m and n swapped).
     czero: an output tile's first K tile -- k-step 0 adds to the constant 0 instead of the accumulator (no clearing pass)."""
-    ks, mi, ni = i // 64, (i % 64) // 8, i % 8
+    ks = i // 64
+    mi, ni = tile_of_step(i % 64)
     if NMAJOR:
         mi, ni = ni, mi
     a, b = (A0, B0) if ks == 0 else (A1, B1)
@@ -356,7 +379,7 @@ def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
     if fp8:
         for j in range(8):
             o += [read_fp8("a", j, 0, 0, 0), read_fp8("a", j, 1, 0, 0)]
-        for j in range(7):
+        for j in range(6 if MFMA_ORDER == "zigzag" else 7):
             o += [read_fp8("b", j, 0, 0), read_fp8("b", j, 1, 0)]
     else:
         for j in range(16):
@@ -446,7 +469,8 @@ PER_WAVE = {"stagger"}
 #                            MFMAs on it are issued (the MFMAs run n-tile-major)
 #   v[232:239] read bases (as bf16), v240 the unit scales
 # per K tile t (stage S = t & 1), gaps = "after MFMA i", i < 64:
-#   0, 1        B[7](t) (its slot was busy until the previous tile's last MFMA)
+#   0, 1        B[7](t) (its slot was busy until the previous tile's last MFMA); order "zigzag" walks columns 6 and 7 together,
+#               so B[6](t) follows at gaps 2, 3 instead of being read after MFMA 55 of the tile before
 #   6           s_waitcnt lgkmcnt(0); s_barrier     every wave holds all of tile t in registers: stage S is free
 #   7 .. 44     the 16 LDS-DMA pieces of tile t+2 -> stage S, every 2.5 gaps (= 80 cycles, what bf16 'spread' settled on)
 #   46          s_waitcnt vmcnt(16); s_barrier      tile t+1 landed for every wave (>= 60 gaps = 1.9 k cycles after its last piece)
@@ -463,7 +487,9 @@ def f8(base, i):
 
 
 def mfma_fp8(i, aset, czero=False):
-    ni, mi = i // 8, i % 8
+    # the order of bf16 with the roles of m and n swapped ("rows": n-tile-major; "zigzag": two tile COLUMNS at a time), because
+    # the B slots are refilled column by column
+    ni, mi = tile_of_step(i)
     if not MX_SCALED:
         return f"v_mfma_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {f8(FB, ni)}, {f8(FA[aset], mi)}, {'0' if czero else acc(mi, ni)}"
     return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {f8(FB, ni)}, {f8(FA[aset], mi)}, {'0' if czero else acc(mi, ni)}, "
@@ -483,8 +509,14 @@ def tile_fp8(t, mode, landed=46, step2=5, czero=False):
     stage, aset = t & 1, t & 1
     out = [f"; ---- fp8 K tile in stage {stage}, {mode}"]
     after = {i: [] for i in range(64)}
+    zz = MFMA_ORDER == "zigzag"
     after[0].append(read_fp8("b", 7, 0, stage))
     after[1].append(read_fp8("b", 7, 1, stage))
+    if zz:
+        # columns 6 and 7 are walked together (MFMAs 48 .. 63), so B[6]'s slot is busy to the tile's end as well: the tile
+        # reads its own B[6] next to its B[7]
+        after[2].append(read_fp8("b", 6, 0, stage))
+        after[3].append(read_fp8("b", 6, 1, stage))
     after[6] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
     if mode == "full":
         for p in range(16):
@@ -504,10 +536,11 @@ def tile_fp8(t, mode, landed=46, step2=5, czero=False):
             after[landed + 1 + (k * span) // len(nxt)].append(read_fp8(op, j, h, stage ^ 1, aset ^ 1))
         for op, j, h in (("b", 5, 0), ("b", 5, 1)):
             after[60].append(read_fp8(op, j, h, stage ^ 1))
-        for op, j, h in (("b", 6, 0), ("b", 6, 1)):
-            after[61].append(read_fp8(op, j, h, stage ^ 1))
-        # the next tile starts on A[*] and B[0]; B[5], B[6] (the last four reads, in order) may still be in flight
-        after[63].append("s_waitcnt lgkmcnt(4)")
+        if not zz:
+            for op, j, h in (("b", 6, 0), ("b", 6, 1)):
+                after[61].append(read_fp8(op, j, h, stage ^ 1))
+        # the next tile starts on A[*] and B[0] (zigzag: B[0], B[1]); B[5], B[6] (the last reads, in order) may still be in flight
+        after[63].append("s_waitcnt lgkmcnt(%d)" % (2 if zz else 4))
     for i in range(64):
         out.append(mfma_fp8(i, aset, czero))
         out += after[i]
@@ -528,7 +561,7 @@ def body_fp8(**kw):
     o += ["s_waitcnt vmcnt(16)", "s_barrier"]
     for j in range(8):
         o += [read_fp8("a", j, 0, 0, 0), read_fp8("a", j, 1, 0, 0)]
-    for j in range(7):                    # B[7] is read by the tile itself, like every tile's
+    for j in range(6 if MFMA_ORDER == "zigzag" else 7):      # B[7] (zigzag: B[6] too) is read by the tile itself, like every tile's
         o += [read_fp8("b", j, 0, 0), read_fp8("b", j, 1, 0)]
     o += ["s_waitcnt lgkmcnt(0)", "; ==== main loop: two K tiles per pass", "1:"]
     o += tile_fp8(0, "full", **kw) + tile_fp8(1, "full", **kw)

@@ -73,23 +73,52 @@ def test_bf16_tiles_hold_every_instruction_once_and_respect_the_hazards(gen, sch
 def test_fp8_tile_refills_a_b_slot_only_after_its_last_mfma(gen):
     full = gen.tile_fp8(0, "full")
     assert _kinds(full) == {"mfma": 64, "dma": 16, "read": 32, "barrier": 2}
-    last_use, pos = {}, {}
+    last_use, first_use, pos = {}, {}, {}
     n = -1
     for l in full:
         if l.startswith("v_mfma"):
             n += 1
             b = int(re.match(r"v_mfma\S+ a\[\d+:\d+\], v\[(\d+):", l).group(1))
             last_use[b] = n
+            first_use.setdefault(b, n)
         elif l.startswith("ds_read"):
             lo = int(re.match(r"ds_read_b128 v\[(\d+):", l).group(1))
             pos[lo] = n
+    # the tile's own late fragments: B[7] at gaps 0, 1 and -- order "zigzag", which walks columns 6 and 7 together -- B[6] at gaps 2, 3;
+    # both land before the wait at gap 6 and are first used long after it
+    own = {gen.FB + 56: 1} if gen.MFMA_ORDER != "zigzag" else {gen.FB + 56: 1, gen.FB + 48: 3}
+    wait6 = [i for i, l in enumerate(full) if l == "s_waitcnt lgkmcnt(0)"][0]
+    assert sum(l.startswith("v_mfma") for l in full[:wait6]) == 7
     for lo, at in pos.items():
         slot = lo - (lo - gen.FB) % 8 if gen.FB <= lo < gen.FB + 64 else None
-        if slot is not None and not (slot == gen.FB + 56 and at <= 1):        # B[7] of THIS tile is read at gaps 0, 1
+        if slot in own and at <= own[slot]:
+            assert first_use[slot] > 6, (lo, at, first_use[slot])
+        elif slot is not None:
             assert at >= last_use[slot], (lo, at, last_use[slot])             # a next-tile B fragment: its slot's MFMAs are all issued
+    assert sum(1 for lo, at in pos.items() if gen.FB <= lo < gen.FB + 64 and at <= 3) == 2 * len(own)
     # the wait for tile t+1 comes after all 16 pieces of tile t+2 went out
     idx = next(i for i, l in enumerate(full) if l.startswith("s_waitcnt vmcnt"))
     assert "vmcnt(16)" in full[idx] and sum(l.startswith("buffer_load") for l in full[:idx]) == 16
+
+
+def test_mfma_order_changes_one_source_per_step(gen):
+    """Order "zigzag" (the shipped one): every MFMA of a k-step shares exactly one source fragment with the one before it, the
+    two sources take turns, every accumulator tile is visited once; "rows" is the tile-row-major order of rounds 2 - 3."""
+    z = [gen.tile_of_step(j, "zigzag") for j in range(64)]
+    assert len(set(z)) == 64 and z[0] == (0, 0)
+    assert all((a[0] != b[0]) + (a[1] != b[1]) == 1 for a, b in zip(z, z[1:]))
+    changed = ["m" if a[0] != b[0] else "n" for a, b in zip(z, z[1:])]
+    for p in range(4):                                                        # m, n, m, n, .. inside a pair of rows; m from pair to pair
+        assert changed[16 * p: 16 * p + 15] == ["m", "n"] * 7 + ["m"]
+    assert [changed[16 * p + 15] for p in range(3)] == ["m"] * 3
+    assert [gen.tile_of_step(j, "rows") for j in range(64)] == [(j // 8, j % 8) for j in range(64)]
+    assert gen.MFMA_ORDER == "zigzag"
+    # the bf16 K tile follows it in both k-steps; fp8 with the roles of m and n swapped (its B slots are refilled by column)
+    t = [l for l in gen.tile(0, "full", "stagger", (), 0) if l.startswith("v_mfma")]
+    accs = [int(re.match(r"v_mfma\S+ a\[(\d+):", l).group(1)) // 4 for l in t]
+    assert accs[:64] == [8 * m + n for m, n in z] and accs[64:] == accs[:64]
+    t8 = [l for l in gen.tile_fp8(0, "full") if l.startswith("v_mfma")]
+    assert [int(re.match(r"v_mfma\S+ a\[(\d+):", l).group(1)) // 4 for l in t8] == [8 * n + m for m, n in z]
 
 
 def test_epilogue_pairs_tiles_and_pads_the_permlane_hazard(gen):

@@ -4,7 +4,7 @@
 set -o pipefail
 R=gpurun_out/${1:-pmc_r3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for n in 8192 6144 2048; do
+for n in ${KLM_PMC_SIZES:-8192 6144 2048}; do
   O=$R/n$n
   mkdir -p $O
   export KLM_PROF_N=$n

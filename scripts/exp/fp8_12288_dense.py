@@ -1,6 +1,9 @@
 """fp8 12288^3 on DENSE operands (row pitch 12 KiB: camps mildly) is the one shape of the review's list below 0.97 x
 torch._scaled_mm. What the existing switches do there: K loops staggered per XCD, super-block tile order, C streamed, and the
-padded layout for reference. Alternating with the vendor kernel, medians."""
+padded layout for reference. Alternating with the vendor kernel, medians.
+(profiles/r3_prof/fp8_12288_dense_wg_stagger.json also holds `wg_rot_*`: the workgroups INSIDE an XCD staggered in four groups by
+1 / 2 / 4 passes -- a few K tiles, which the XCD's L2 still bridges. Measured through a hook in klm_quad_plan that was removed
+again: 0.93 - 0.94 at 12288^3 against 0.945 for the plain stream, i.e. nothing.)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,7 +14,7 @@ _o = next((x for x in sys.argv[1:] if not x.startswith("--")), "gpurun_out/fp8_1
 os.makedirs(os.path.dirname(_o) or ".", exist_ok=True)
 one = torch.ones((), device=dev)
 out = {}
-for M, N, K in ((12288, 12288, 12288), (8192, 8192, 12288), (12288, 12288, 6144)):
+for M, N, K in ((12288, 12288, 12288), (8192, 8192, 12288)):
     a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.float8_e4m3fn)
     b = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.float8_e4m3fn)
     c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

@@ -79,6 +79,20 @@ def body32(kind):
     return o
 
 
+def body_mx(kind, fmt):
+    """f8f6f4 16x16x128: fp8 fragments are 8 registers (A v40.., B v104.., -A v168..), fp4 ones 4 (the bf16 map, cbsz:4 blgp:4)."""
+    o = []
+    w = 8 if fmt == "fp8" else 4
+    a0, b0, an = (40, 104, 168) if fmt == "fp8" else (A0, B0, AN)
+    mod = "" if fmt == "fp8" else " cbsz:4 blgp:4"
+    for h in (0, 1):
+        abase = an if h else a0
+        for m, n in order16(kind):
+            c = 4 * (8 * m + n)
+            o.append(f"v_mfma_f32_16x16x128_f8f6f4 a[{c}:{c + 3}], v[{b0 + w * n}:{b0 + w * n + w - 1}], v[{abase + w * m}:{abase + w * m + w - 1}], a[{c}:{c + 3}]{mod}")
+    return o
+
+
 VARIANTS = [("16x16x32 m-major (the streams' order)", body16("m")), ("16x16x32 m-major snake", body16("m_snake")),
             ("16x16x32 n-major", body16("n")), ("16x16x32 n-major snake", body16("n_snake")),
             ("16x16x32 2x2 blocks, one source changes per step", body16("block2")),
@@ -86,22 +100,34 @@ VARIANTS = [("16x16x32 m-major (the streams' order)", body16("m")), ("16x16x32 m
             ("16x16x32 zigzag over column pairs", body16("zigzag2n")),
             ("16x16x32 diagonal (no shared source)", body16("diag")),
             ("32x32x16 m-major", body32("m")), ("32x32x16 m-major snake", body32("m_snake")),
-            ("16x16x32 m-major, growing accumulators", body16("m", bounded=False))]
+            ("16x16x32 m-major, growing accumulators", body16("m", bounded=False)),
+            ("fp8 16x16x128 n-major (the fp8 stream's order in rounds 2 - 3)", body_mx("n", "fp8")), ("fp8 16x16x128 zigzag over column pairs", body_mx("zigzag2n", "fp8")),
+            ("fp8 16x16x128 diagonal (no shared source)", body_mx("diag", "fp8")),
+            ("fp4 16x16x128 m-major", body_mx("m", "fp4")), ("fp4 16x16x128 zigzag over row pairs", body_mx("zigzag2", "fp4")),
+            ("fp4 16x16x128 diagonal (no shared source)", body_mx("diag", "fp4"))]
 
 
-def kernel(idx, lines):
+def kernel(idx, lines, fmt="bf16"):
     pre = ["s_mov_b32 s64, %[p0]", "s_mov_b32 s65, %[p1]", "s_mov_b32 s66, %[iters]"]
-    for i in range(16):
-        base = A0 + 4 * i          # A fragments then B fragments: v40..v103
+    nload = 32 if fmt == "fp8" else 16
+    for i in range(nload):
+        base = A0 + 4 * i          # A fragments then B fragments: v40..v103 (fp8: v40..v167)
         pre += [f"global_load_dwordx4 v[{base}:{base + 3}], %[off], s[64:65]", "s_add_u32 s64, s64, 0x1000", "s_addc_u32 s65, s65, 0"]
     pre += [f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)]
     pre += ["s_waitcnt vmcnt(0)"]
-    pre += [f"v_xor_b32 v{AN + i}, 0x80008000, v{A0 + i}" for i in range(32)]
+    if fmt == "fp8":
+        # random bytes hold NaNs (S.1111.111): clear the exponent's top bit; -A flips every byte's sign
+        pre += [f"v_and_b32 v{40 + i}, 0xbfbfbfbf, v{40 + i}" for i in range(128)]
+        pre += [f"v_xor_b32 v{168 + i}, 0x80808080, v{40 + i}" for i in range(64)]
+    elif fmt == "fp4":
+        pre += [f"v_xor_b32 v{AN + i}, 0x88888888, v{A0 + i}" for i in range(32)]
+    else:
+        pre += [f"v_xor_b32 v{AN + i}, 0x80008000, v{A0 + i}" for i in range(32)]
     pre += ["s_nop 4", "s_memtime s[68:69]", "s_memrealtime s[70:71]", "s_waitcnt lgkmcnt(0)", "1:"]
     post = ["s_sub_u32 s66, s66, 1", "s_cmp_lg_u32 s66, 0", "s_cbranch_scc1 1b", "s_memtime s[72:73]", "s_memrealtime s[74:75]", "s_waitcnt lgkmcnt(0)",
             "s_sub_u32 %[dc], s72, s68", "s_sub_u32 %[dr], s74, s70", "s_nop 15", "s_nop 15", "v_accvgpr_read_b32 %[r], a0"]
     text = "".join(f'      "{l}\\n\\t"\n' for l in pre + lines + post)
-    clob = ", ".join(f'"{c}"' for c in ["memory", "scc"] + [f"s{i}" for i in range(64, 76)] + [f"v{i}" for i in range(40, 136)] + [f"a{i}" for i in range(256)])
+    clob = ", ".join(f'"{c}"' for c in ["memory", "scc"] + [f"s{i}" for i in range(64, 76)] + [f"v{i}" for i in range(40, 232)] + [f"a{i}" for i in range(256)])
     return f"""__global__ __launch_bounds__(256) void kern{idx}(const char* __restrict__ src, float* __restrict__ sink, int iters) {{
   const unsigned off = threadIdx.x * 16u;
   const unsigned long long p = (unsigned long long)src;
@@ -125,7 +151,7 @@ int main(int argc, char** argv) {
   const int rounds = argc > 2 ? atoi(argv[2]) : 3;
   int cus = 0;
   CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-  std::vector<unsigned short> h(4096 * 8);
+  std::vector<unsigned short> h(8192 * 8);      // 128 KiB: up to 32 fragment loads of 4 KiB per workgroup
   srand(7);
   for (auto& x : h) {     // bf16 uniform [-1, 1)
     float f = (float)rand() / 2147483648.f * 2.f - 1.f;
@@ -135,7 +161,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&sink, 16));
   CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const double mac_per_pass_wave = 128.0 * 16 * 16 * 32;
+  const double mac_per_pass_wave_bf16 = 128.0 * 16 * 16 * 32;
   const int it = 10000;
   printf("{\"cus\": %d, \"rows\": [\n", cus);
   for (int r = 0; r < rounds; ++r)
@@ -149,11 +175,13 @@ int main(int argc, char** argv) {
         t_total = ms * 1e-3;
         if (t_total >= secs) break;
       }
+      const double mac_per_pass_wave = mac_per_pass_wave_bf16 * ((names[which][0] == 'f') ? 4.0 : 1.0);     // 16x16x128: four times the MACs
+      const double peak_per_clk = (names[which][0] == 'f') ? (names[which][2] == '4' ? 4096.0 : 2048.0) : 1024.0;
       const double flops = 2.0 * mac_per_pass_wave * it * 4.0 * cus * launches / t_total;
       float mhz = 0; CK(hipMemcpy(&mhz, sink + 2, 4, hipMemcpyDeviceToHost));
       // busy: the rate over what 4 SIMDs x 1024 FLOP per clock would give at the clock the last launch ran at
       printf("  {\"round\": %d, \"variant\": \"%s\", \"seconds\": %.3f, \"tflops\": %.1f, \"clock_mhz\": %.0f, \"mfma_busy\": %.3f}%s\n", r, names[which], t_total, flops / 1e12,
-             mhz, flops / (4.0 * cus * 1024.0 * mhz * 1e6),
+             mhz, flops / (4.0 * cus * peak_per_clk * mhz * 1e6),
              (r == rounds - 1 && which == NW - 1) ? "" : ",");
       fflush(stdout);
     }
@@ -169,8 +197,8 @@ def main():
     with open(out, "w") as f:
         f.write("// GENERATED by scripts/exp/gen_mfma_order_exp.py -- do not edit.\n#include <hip/hip_runtime.h>\n#include <cstdio>\n"
                 "#include <cstdlib>\n#include <cstring>\n#include <vector>\n\n")
-        for i, (_, lines) in enumerate(VARIANTS):
-            f.write(kernel(i, lines))
+        for i, (name, lines) in enumerate(VARIANTS):
+            f.write(kernel(i, lines, "fp8" if name.startswith("fp8") else "fp4" if name.startswith("fp4") else "bf16"))
         f.write(f"#define NW {len(VARIANTS)}\nstatic const char* names[NW] = {{" + ", ".join('"%s"' % n for n, _ in VARIANTS) + "};\n")
         f.write("static void launch(int w, int cus, const char* src, float* sink, int it) {\n  switch (w) {\n")
         for i in range(len(VARIANTS)):

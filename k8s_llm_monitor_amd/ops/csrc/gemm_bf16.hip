@@ -316,7 +316,7 @@ struct klm_op_quad_bf16 {
 #pragma unroll
       for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // fragment read R of 16 in the order the m-tile-major MFMA sequence needs them: A0, B0..B7, A1..A7
+  // fragment read R of 16: A0, B0..B7, A1..A7 (all sixteen have landed before the k-step that uses them starts, whatever its order)
   template <int SET, int PART, int R>
   __device__ __forceinline__ void read1(const char* stage) {
     if constexpr (R == 0) fa[SET][0] = *reinterpret_cast<const bf16x8*>(stage + a_off[PART]);

@@ -8,7 +8,7 @@ statements pinned with sched_barrier) the compiler still decides the waits and t
 0.75 MFMA-busy; the vendor's hand-written kernel of the same geometry reaches 0.86 - 0.88. Here every instruction's place
 is fixed. The shipped bf16 / fp4 schedule ("stagger", see SCHEDULES for the others and docs/KERNELS.md for what each measured):
 
-  per K tile (stage S, 128 MFMAs, m-tile-major so consecutive MFMAs share the A fragment), gap = "after MFMA i":
+  per K tile (stage S, 128 MFMAs; which accumulator tile MFMA i works on: MFMA_ORDER / tile_of_step below), gap = "after MFMA i":
     0, 2, .., 30       the 16 ds_read_b128 of this tile's k-step 1 -> fragment set 1 (A[0], B[0..7], A[1..7])
     36                 s_waitcnt lgkmcnt(0); s_barrier      every wave is done reading stage S
     39 + 5 p + w       LDS-DMA piece p (0..7 A, 8..15 B) of tile t+2 -> stage S, for wave w: one per FIVE MFMAs (closer
@@ -466,7 +466,7 @@ PER_WAVE = {"stagger"}
 # MFMAs of 32 cycles, and a fragment takes 8 registers, so two whole fragment sets do not fit beside 256 accumulators:
 #   v[40:103] / v[104:167]   A fragments of the even / odd K tiles (8 x 8 registers each)
 #   v[168:231]               B fragments, ONE set: slot ni is refilled with the next tile's B[ni] once this tile's 8
-#                            MFMAs on it are issued (the MFMAs run n-tile-major)
+#                            MFMAs on it are issued (the MFMAs walk the tile columns: one by one under order "rows", in pairs under "zigzag")
 #   v[232:239] read bases (as bf16), v240 the unit scales
 # per K tile t (stage S = t & 1), gaps = "after MFMA i", i < 64:
 #   0, 1        B[7](t) (its slot was busy until the previous tile's last MFMA); order "zigzag" walks columns 6 and 7 together,

@@ -64,6 +64,40 @@ def body16(kind, bounded=True):
     return o
 
 
+A1, B1, A1N = 136, 168, 200
+
+
+def body16_two_sets(kind):
+    """As the GEMM streams: TWO fragment sets (k-step 0 and 1 of a K tile), every accumulator tile gets one MFMA from each.
+    'ksteps': all 64 tiles on set 0, then all 64 on set 1, zigzag (the streams). 'dependent': tile by tile, k-step 0 then k-step 1
+    back to back on the same accumulator (does the hardware forward it instead of reading the register file? at the price of
+    both sources changing every step). 'pairs': T0 k0, T1 k0, T0 k1, T1 k1 over zigzag neighbours (accumulator reuse distance 2,
+    every second step shares a source)."""
+    o = []
+    z = order16("zigzag2")
+    for h in (0, 1):
+        a = ((A0, A1), (AN, A1N))[h]
+        seq = []
+        if kind == "ksteps":
+            seq = [(m, n, 0) for m, n in z] + [(m, n, 1) for m, n in z]
+        elif kind == "dependent":
+            for m, n in z:
+                seq += [(m, n, 0), (m, n, 1)]
+        elif kind == "double_snake":
+            # T0 k0, T0 k1, T1 k1, T1 k0, T2 k0, T2 k1, ..: every step shares the accumulator (k changes) or one source (the tile
+            # changes along the zigzag, k stays)
+            for i, (m, n) in enumerate(z):
+                seq += [(m, n, 0), (m, n, 1)] if i % 2 == 0 else [(m, n, 1), (m, n, 0)]
+        elif kind == "pairs":
+            for i in range(0, 64, 2):
+                (m0, n0), (m1, n1) = z[i], z[i + 1]
+                seq += [(m0, n0, 0), (m1, n1, 0), (m0, n0, 1), (m1, n1, 1)]
+        for m, n, ks in seq:
+            c = 4 * (8 * m + n)
+            o.append(f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], {frag((B0, B1)[ks], n)}, {frag(a[ks], m)}, a[{c}:{c + 3}]")
+    return o
+
+
 def body32(kind):
     """16 accumulator tiles of 32x32 (16 registers each); fragments 0..3 are k-step 0, 4..7 k-step 1."""
     o = []
@@ -101,6 +135,10 @@ VARIANTS = [("16x16x32 m-major (the streams' order)", body16("m")), ("16x16x32 m
             ("16x16x32 diagonal (no shared source)", body16("diag")),
             ("32x32x16 m-major", body32("m")), ("32x32x16 m-major snake", body32("m_snake")),
             ("16x16x32 m-major, growing accumulators", body16("m", bounded=False)),
+            ("2sets: 16x16x32 zigzag, k-step 0 then k-step 1 (the streams)", body16_two_sets("ksteps")),
+            ("2sets: 16x16x32 tile by tile, both k-steps back to back on one accumulator", body16_two_sets("dependent")),
+            ("2sets: 16x16x32 double snake: T0k0 T0k1 T1k1 T1k0 .. (each step shares the accumulator or one source)", body16_two_sets("double_snake")),
+            ("2sets: 16x16x32 zigzag neighbours interleaved, accumulator reuse distance 2", body16_two_sets("pairs")),
             ("fp8 16x16x128 n-major (the fp8 stream's order in rounds 2 - 3)", body_mx("n", "fp8")), ("fp8 16x16x128 zigzag over column pairs", body_mx("zigzag2n", "fp8")),
             ("fp8 16x16x128 diagonal (no shared source)", body_mx("diag", "fp8")),
             ("fp4 16x16x128 m-major", body_mx("m", "fp4")), ("fp4 16x16x128 zigzag over row pairs", body_mx("zigzag2", "fp4")),
@@ -109,7 +147,7 @@ VARIANTS = [("16x16x32 m-major (the streams' order)", body16("m")), ("16x16x32 m
 
 def kernel(idx, lines, fmt="bf16"):
     pre = ["s_mov_b32 s64, %[p0]", "s_mov_b32 s65, %[p1]", "s_mov_b32 s66, %[iters]"]
-    nload = 32 if fmt == "fp8" else 16
+    nload = 32 if fmt in ("fp8", "2sets") else 16
     for i in range(nload):
         base = A0 + 4 * i          # A fragments then B fragments: v40..v103 (fp8: v40..v167)
         pre += [f"global_load_dwordx4 v[{base}:{base + 3}], %[off], s[64:65]", "s_add_u32 s64, s64, 0x1000", "s_addc_u32 s65, s65, 0"]
@@ -121,6 +159,12 @@ def kernel(idx, lines, fmt="bf16"):
         pre += [f"v_xor_b32 v{168 + i}, 0x80808080, v{40 + i}" for i in range(64)]
     elif fmt == "fp4":
         pre += [f"v_xor_b32 v{AN + i}, 0x88888888, v{A0 + i}" for i in range(32)]
+    elif fmt == "2sets":
+        # loaded: v40..v167 = A0, B0, (scratch), A1; B1 = a copy-free reuse of the scratch block's neighbours is not possible, so
+        # move: the third block loaded (v104..135) becomes B1 (v168..199), then the negated sets are derived
+        pre += [f"v_mov_b32 v{B1 + i}, v{104 + i}" for i in range(32)]
+        pre += [f"v_xor_b32 v{AN + i}, 0x80008000, v{A0 + i}" for i in range(32)]
+        pre += [f"v_xor_b32 v{A1N + i}, 0x80008000, v{A1 + i}" for i in range(32)]
     else:
         pre += [f"v_xor_b32 v{AN + i}, 0x80008000, v{A0 + i}" for i in range(32)]
     pre += ["s_nop 4", "s_memtime s[68:69]", "s_memrealtime s[70:71]", "s_waitcnt lgkmcnt(0)", "1:"]
@@ -175,7 +219,7 @@ int main(int argc, char** argv) {
         t_total = ms * 1e-3;
         if (t_total >= secs) break;
       }
-      const double mac_per_pass_wave = mac_per_pass_wave_bf16 * ((names[which][0] == 'f') ? 4.0 : 1.0);     // 16x16x128: four times the MACs
+      const double mac_per_pass_wave = mac_per_pass_wave_bf16 * ((names[which][0] == 'f') ? 4.0 : (names[which][0] == '2') ? 2.0 : 1.0);     // 16x16x128: four times the MACs; two sets: 256 MFMAs per pass
       const double peak_per_clk = (names[which][0] == 'f') ? (names[which][2] == '4' ? 4096.0 : 2048.0) : 1024.0;
       const double flops = 2.0 * mac_per_pass_wave * it * 4.0 * cus * launches / t_total;
       float mhz = 0; CK(hipMemcpy(&mhz, sink + 2, 4, hipMemcpyDeviceToHost));
@@ -198,7 +242,7 @@ def main():
         f.write("// GENERATED by scripts/exp/gen_mfma_order_exp.py -- do not edit.\n#include <hip/hip_runtime.h>\n#include <cstdio>\n"
                 "#include <cstdlib>\n#include <cstring>\n#include <vector>\n\n")
         for i, (name, lines) in enumerate(VARIANTS):
-            f.write(kernel(i, lines, "fp8" if name.startswith("fp8") else "fp4" if name.startswith("fp4") else "bf16"))
+            f.write(kernel(i, lines, "fp8" if name.startswith("fp8") else "fp4" if name.startswith("fp4") else "2sets" if name.startswith("2sets") else "bf16"))
         f.write(f"#define NW {len(VARIANTS)}\nstatic const char* names[NW] = {{" + ", ".join('"%s"' % n for n, _ in VARIANTS) + "};\n")
         f.write("static void launch(int w, int cus, const char* src, float* sink, int it) {\n  switch (w) {\n")
         for i in range(len(VARIANTS)):

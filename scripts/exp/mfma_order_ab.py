@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 import torch
 from k8s_llm_monitor_amd import ops
 dev = torch.device("cuda:0")
-libs = {"rows": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/exp/libklm_ops_rows.so")),
+BASE = os.environ.get("KLM_AB_BASE", "rows")      # rows: tile-row-major (rounds 2 - 3); zigzag: the zigzag order on schedule "stagger"
+libs = {"rows": ctypes.CDLL(os.path.join(ROOT, f"k8s_llm_monitor_amd/_native/lib/exp/libklm_ops_{BASE}.so")),
         "tree": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/libklm_ops.so"))}
 vp, i = ctypes.c_void_p, ctypes.c_int
 sz = ctypes.c_size_t
@@ -20,7 +21,7 @@ for l in libs.values():
 g = torch.Generator(device=dev); g.manual_seed(11)
 _o = next((x for x in sys.argv[1:] if not x.startswith("--")), "gpurun_out/exp/mfma_order_ab.json")
 os.makedirs(os.path.dirname(_o) or ".", exist_ok=True)
-out = {}
+out = {"base_library": BASE}
 one = torch.ones((), device=dev)
 for (M, N, K) in ((8192, 8192, 8192), (4096, 4096, 4096), (8192, 8192, 2048)):
     a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)

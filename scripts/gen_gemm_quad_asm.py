@@ -137,6 +137,9 @@ def tile(stage, mode, sched="one_barrier", ablate=(), wave=0, czero=False):
     """mode: 'full' (issues tile t+2), 'tail2' (tile nt-2: no DMA), 'last' (tile nt-1: no DMA, no next reads).
     sched: where the pieces go (see SCHEDULES). ablate: diagnostic builds that drop 'dma', 'read' or 'barrier'
     instructions from the loop (wrong results, right timing: what each kind of instruction costs)."""
+    if sched == "chain":
+        assert not ablate
+        return tile_chain(stage, mode, wave, czero)
     out = [f"; ---- K tile in stage {stage}, {mode}, {sched}"]
     after = {i: [] for i in range(128)}
     P = SCHEDULES[sched]
@@ -175,6 +178,104 @@ def tile(stage, mode, sched="one_barrier", ablate=(), wave=0, czero=False):
     for i in range(128):
         out.append(mfma(i, czero))
         out += [x for x in after[i] if not any(x.startswith(d) for d in drop)]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Schedule "chain" (bf16 / fp4, the shipped one since the last session of round 3). Energy again: back-to-back MFMAs on the SAME
+# accumulator cost less than anything else measured -- the register-only loops of scripts/exp/gen_mfma_order_exp.py run at 2105
+# TFLOP/s in the zigzag order with k-step 0 of all 64 tiles before k-step 1 (schedule "stagger"), at 2170 - 2187 when each tile
+# gets its two k-steps back to back, although then BOTH sources change at every step: the accumulator is forwarded instead of
+# being read from the register file again. Each accumulator still adds k-step 0 before k-step 1, so the bits do not change.
+# Chaining needs both k-steps' fragments of a tile at once, which turns the register plan around:
+#   v[40:103]     A fragments, ONE set: (m tile, k-step) at v[40 + 4 (2 m + k)]; a pair of tile rows (the zigzag's unit, 32 MFMAs)
+#                 is refilled with the next K tile's fragments as soon as its MFMAs are issued
+#   v[104:167] / v[168:231]   B fragments of the K tile in stage 0 / stage 1, (n tile, k-step) at base + 4 (2 n + k): all 16 are
+#                 needed by every row pair, so B is double-buffered
+#   v[232:239] read bases, v240 unit scales, v241.. the persistent kernels' table registers (= the fp8 kernel's numbers)
+# per K tile t in stage S, gap = "after MFMA i" of 128:
+#   0 .. 3          A rows 6, 7 of tile t itself (their registers were busy to the end of tile t-1)
+#   6               s_waitcnt lgkmcnt(0); s_barrier       every wave has read ALL of stage S (30 gaps earlier than "stagger")
+#   9 + 5 p + w     LDS-DMA piece p of tile t+2 -> stage S, wave w one gap later each (as "stagger"); M0 one gap before
+#   56              s_waitcnt vmcnt(pieces issued so far); s_barrier      tile t+1 landed (97 gaps after its last piece)
+#   57 ..           B[0..7] x 2 k-steps of tile t+1 -> the other B buffer, then A rows 0 - 1 and 2 - 3 of tile t+1 (their row pairs are
+#                   done at 31 / 63), one read per gap, DMA gaps skipped; A rows 4 - 5 from gap 96 on
+#   126             s_waitcnt lgkmcnt(0)
+CA = 40
+CB = (104, 168)
+CRB, CSCALE, TBL_CHAIN = 232, 240, 241
+CHAIN_FREE, CHAIN_DMA0, CHAIN_DMA_STEP, CHAIN_LANDED = 6, 9, 5, 56
+
+
+def cfrag_a(m, k):
+    b = CA + 4 * (2 * m + k)
+    return f"v[{b}:{b + 3}]"
+
+
+def cfrag_b(stage, n, k):
+    b = CB[stage] + 4 * (2 * n + k)
+    return f"v[{b}:{b + 3}]"
+
+
+def cread(operand, idx, k, stage, buf=None):
+    """ds_read_b128 of fragment (operand, tile idx, k-step k) from LDS stage `stage`; B goes to buffer `buf` (default: its stage's)."""
+    if operand == "a":
+        return f"ds_read_b128 {cfrag_a(idx, k)}, v{CRB + 4 * stage + k}" + (f" offset:{idx * 2048}" if idx else "")
+    return f"ds_read_b128 {cfrag_b(stage if buf is None else buf, idx, k)}, v{CRB + 4 * stage + 2 + k}" + (f" offset:{idx * 2048}" if idx else "")
+
+
+def mfma_chain(i, stage, czero=False):
+    """MFMA i of 128: tile tile_of_step(i // 2, "zigzag"), k-step i % 2 -- a tile's two k-steps back to back."""
+    mi, ni = tile_of_step(i // 2, "zigzag")
+    ks = i % 2
+    c = "0" if (czero and ks == 0) else acc(mi, ni)
+    if DTYPE == "fp4":
+        if not MX_SCALED:
+            return f"v_mfma_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {cfrag_b(stage, ni, ks)}, {cfrag_a(mi, ks)}, {c} cbsz:4 blgp:4"
+        return (f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(mi, ni)}, {cfrag_b(stage, ni, ks)}, {cfrag_a(mi, ks)}, {c}, v{CSCALE}, v{CSCALE} "
+                f"op_sel_hi:[0,0,0] cbsz:4 blgp:4")
+    return f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {cfrag_b(stage, ni, ks)}, {cfrag_a(mi, ks)}, {c}"
+
+
+def chain_first_reads(stage=0):
+    """What a K tile needs in registers before its first MFMA: all of B and A rows 0 .. 5 (rows 6, 7 are read by the tile itself)."""
+    return [cread("b", n, k, stage) for n in range(8) for k in (0, 1)] + [cread("a", m, k, stage) for m in range(6) for k in (0, 1)]
+
+
+def tile_chain(stage, mode, wave=0, czero=False):
+    out = [f"; ---- K tile in stage {stage}, {mode}, chain, wave {wave}"]
+    after = {i: [] for i in range(128)}
+    for j, (m, k) in enumerate(((6, 0), (6, 1), (7, 0), (7, 1))):
+        after[j].append(cread("a", m, k, stage))
+    after[CHAIN_FREE] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    dma_gaps = [CHAIN_DMA0 + CHAIN_DMA_STEP * p + wave for p in range(16)]
+    if mode == "full":
+        for p, i in enumerate(dma_gaps):
+            pre, main = dma(stage, p)
+            after[i - 1] += pre
+            after[i] += main
+        n_before = sum(1 for i in dma_gaps if i <= CHAIN_LANDED)
+        after[CHAIN_LANDED] += [f"s_waitcnt vmcnt({n_before})", "s_barrier"]
+    elif mode == "tail2":
+        after[CHAIN_LANDED] += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    if mode != "last":
+        nxt = stage ^ 1
+        reads = [(cread("b", n, k, nxt), 0) for n in range(8) for k in (0, 1)]
+        # A rows of pair p may be overwritten once MFMA 32 p + 31 is issued
+        reads += [(cread("a", m, k, nxt), 32 * (m // 2) + 31) for m in range(6) for k in (0, 1)]
+        g = CHAIN_LANDED + 1
+        busy = set(dma_gaps) if mode == "full" else set()
+        for text, not_before in reads:
+            g = max(g, not_before)
+            while g in busy:
+                g += 1
+            after[g].append(text)
+            g += 1
+        assert g <= 126, g
+        after[126].append("s_waitcnt lgkmcnt(0)")
+    for i in range(128):
+        out.append(mfma_chain(i, stage, czero))
+        out += after[i]
     return out
 
 
@@ -244,7 +345,8 @@ def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
     global NMAJOR, DTYPE, DMA_CACHE
     NMAJOR, DTYPE = nmajor, dtype
     DMA_CACHE = "".join(" " + x[6:] for x in ablate if x.startswith("cache:"))
-    o = setup_lines(RB, SCALE)
+    chain = sched == "chain"
+    o = setup_lines(CRB, CSCALE) if chain else setup_lines(RB, SCALE)
     o += ["; ==== prologue: tiles 0 and 1 on their way, accumulators cleared meanwhile"]
     for st in (0, 1):
         for p in range(16):
@@ -253,8 +355,11 @@ def body(sched="one_barrier", ablate=(), nmajor=False, dtype="bf16"):
     for i in range(256):
         o.append(f"v_accvgpr_write_b32 a{i}, 0")
     o += ["s_waitcnt vmcnt(16)", "s_barrier"]
-    for j in range(16):
-        o.append(read(0, 0, j))
+    if chain:
+        o += chain_first_reads(0)
+    else:
+        for j in range(16):
+            o.append(read(0, 0, j))
     o += ["s_waitcnt lgkmcnt(0)"]
     if sched in PER_WAVE:
         # four copies of the loop, one per wave of the workgroup (they differ only in where the DMA pieces sit)
@@ -363,12 +468,13 @@ SWITCH = ["; ---- last pass of this unit: its DMA fetches the next unit's K tile
           "s_mov_b32 s64, s96", "s_mov_b32 s65, s97", "s_mov_b32 s66, s80", "s_mov_b32 s68, s98", "s_mov_b32 s69, s99", "s_mov_b32 s70, s80"]
 
 
-def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
+def body_p(dtype="bf16", sched="chain", ablate=(), **kw):
     global NMAJOR, DTYPE, DMA_CACHE, MX_SCALED
     NMAJOR, DTYPE, DMA_CACHE = False, dtype, ""
     MX_SCALED = "scaled" in ablate
     fp8 = dtype == "fp8"
-    rb, scale, tbl = (FRB, FSCALE, TBL_FP8) if fp8 else (RB, SCALE, TBL_BF16)
+    chain = sched == "chain" and not fp8
+    rb, scale, tbl = (FRB, FSCALE, TBL_FP8) if fp8 else (CRB, CSCALE, TBL_CHAIN) if chain else (RB, SCALE, TBL_BF16)
     o = setup_lines_p(rb, scale, tbl)
     o += ["; ==== prologue: K tiles 0 and 1 of the first output tile on their way"]
     for st in (0, 1):
@@ -381,6 +487,8 @@ def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
             o += [read_fp8("a", j, 0, 0, 0), read_fp8("a", j, 1, 0, 0)]
         for j in range(6 if MFMA_ORDER == "zigzag" else 7):
             o += [read_fp8("b", j, 0, 0), read_fp8("b", j, 1, 0)]
+    elif chain:
+        o += chain_first_reads(0)
     else:
         for j in range(16):
             o.append(read(0, 0, j))
@@ -414,7 +522,8 @@ def body_p(dtype="bf16", sched="stagger", ablate=(), **kw):
     # holds the next output tile's first fragments
     global STORE_CACHE
     STORE_CACHE = "".join(" " + x[8:] for x in ablate if x.startswith("stcache:"))
-    epi = epilogue_lines(tmp=A1)
+    # (schedule "chain": the B buffer of stage 1 -- a unit ends on a stage-1 tile, and the other buffer holds the next unit's B)
+    epi = epilogue_lines(tmp=CB[1] if chain else A1)
     STORE_CACHE = ""
     if "store" in ablate:          # diagnostic: what the stores cost (C is never written)
         epi = [l for l in epi if not l.startswith("buffer_store")]
@@ -457,7 +566,7 @@ def _stagger(wave, first=39, step=5, landed=85):
 
 
 SCHEDULES["stagger"] = _stagger
-PER_WAVE = {"stagger"}
+PER_WAVE = {"stagger", "chain"}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -574,12 +683,12 @@ def body_fp8(**kw):
 # macro suffix -> (schedule, ablations, dtype). SHIPPED: the bodies libklm_ops.so and klm_burner are built from. DIAGNOSTIC: earlier
 # placements kept for the A/B record and streams with parts of the loop removed (they keep a GEMM's timing, not its result);
 # generated only with --diag and compiled only under -DKLM_GEMM_DIAG (scripts/exp/build_exp.sh), never into the shipped library.
-SHIPPED = {"": ("stagger", (), "bf16"), "_FP4": ("stagger", (), "fp4"), "_FP8": ("fp8", (), "fp8"),
+SHIPPED = {"": ("chain", (), "bf16"), "_FP4": ("chain", (), "fp4"), "_FP8": ("fp8", (), "fp8"),
            # _ST: C stored with `sc1 nt` (written through, not kept): for shapes whose operands just fit the 256 MB Infinity Cache
            "_P_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "bf16"), "_P_FP4_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp4"),
            "_P_FP8_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp8"),
            "_P": ("persistent", (), "bf16"), "_P_FP4": ("persistent", (), "fp4"), "_P_FP8": ("persistent", (), "fp8")}
-DIAGNOSTIC = {"_SPREAD": ("spread", (), "bf16"), "_ONEBAR": ("one_barrier", (), "bf16"), "_PEROP": ("per_operand", (), "bf16"),
+DIAGNOSTIC = {"_STAGGER": ("stagger", (), "bf16"), "_SPREAD": ("spread", (), "bf16"), "_ONEBAR": ("one_barrier", (), "bf16"), "_PEROP": ("per_operand", (), "bf16"),
               "_NODMA": ("spread", ("dma",), "bf16"), "_NOREAD": ("spread", ("read",), "bf16"), "_L2ONLY": ("spread", ("bump",), "bf16"),
               "_MFMAONLY": ("spread", ("dma", "read", "barrier"), "bf16"),
               "_FP8B": ("fp8", (("landed", 46), ("step2", 6)), "fp8"),

@@ -117,8 +117,79 @@ def test_mfma_order_changes_one_source_per_step(gen):
     t = [l for l in gen.tile(0, "full", "stagger", (), 0) if l.startswith("v_mfma")]
     accs = [int(re.match(r"v_mfma\S+ a\[(\d+):", l).group(1)) // 4 for l in t]
     assert accs[:64] == [8 * m + n for m, n in z] and accs[64:] == accs[:64]
+    # ... and the shipped schedule ("chain") visits the tiles in the same order, both k-steps of a tile back to back
+    t = [l for l in gen.tile(0, "full", "chain", (), 0) if l.startswith("v_mfma")]
+    accs = [int(re.match(r"v_mfma\S+ a\[(\d+):", l).group(1)) // 4 for l in t]
+    assert accs[0::2] == [8 * m + n for m, n in z] and accs[1::2] == accs[0::2]
+    assert gen.SHIPPED[""][0] == "chain" and gen.SHIPPED["_FP4"][0] == "chain"
     t8 = [l for l in gen.tile_fp8(0, "full") if l.startswith("v_mfma")]
     assert [int(re.match(r"v_mfma\S+ a\[(\d+):", l).group(1)) // 4 for l in t8] == [8 * n + m for m, n in z]
+
+
+def test_chain_tile_keeps_every_fragment_alive_until_its_last_mfma(gen):
+    """Schedule "chain" (bf16 / fp4): a tile's two k-steps run back to back on one accumulator (k-step 0 first: the bits of the
+    other schedules), A is one register set refilled row pair by row pair, B is double-buffered by stage."""
+    for wave in range(4):
+        for stage in (0, 1):
+            full = gen.tile_chain(stage, "full", wave)
+            assert _kinds(full) == {"mfma": 128, "dma": 16, "read": 32, "barrier": 2}
+            mf = [l for l in full if l.startswith("v_mfma")]
+            accs = [re.match(r"v_mfma\S+ (a\[\d+:\d+\])", l).group(1) for l in mf]
+            assert all(accs[2 * j] == accs[2 * j + 1] for j in range(64)) and len(set(accs)) == 64
+            src = [tuple(int(x) for x in re.match(r"v_mfma\S+ a\[\d+:\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\]", l).groups()) for l in mf]
+            # k-step 0 before k-step 1 on every accumulator: the even MFMA reads the k = 0 fragments
+            assert all((b - gen.CB[stage]) % 8 == 0 and (a - gen.CA) % 8 == 0 for b, a in src[0::2])
+            assert all((b - gen.CB[stage]) % 8 == 4 and (a - gen.CA) % 8 == 4 for b, a in src[1::2])
+            # walk the stream: a register is written by a read only after its last MFMA of THIS tile, and read by an MFMA only
+            # after the wait that covers the read
+            n, last_use, first_use = -1, {}, {}
+            for l in mf:
+                n += 1
+                for r in src[n]:
+                    last_use[r] = n
+                    first_use.setdefault(r, n)
+            n, pending = -1, {}
+            own = set()
+            for l in full:
+                if l.startswith("v_mfma"):
+                    n += 1
+                    for r in src[n]:
+                        assert r not in pending, (wave, stage, n, r)          # never reads a fragment whose load has not been waited for
+                elif l.startswith("ds_read"):
+                    lo = int(re.match(r"ds_read_b128 v\[(\d+):", l).group(1))
+                    if n <= 3:
+                        own.add(lo)                                             # rows 6, 7 of this tile
+                        assert first_use[lo] >= 96
+                    else:
+                        # the next tile's fragments: A into the one A set (its row pair is done), B into the OTHER stage's buffer
+                        assert (gen.CA <= lo < gen.CA + 48 and n >= last_use[lo]) or gen.CB[stage ^ 1] <= lo < gen.CB[stage ^ 1] + 64, (lo, n)
+                    pending[lo] = n
+                elif l.startswith("s_waitcnt lgkmcnt(0)"):
+                    pending.clear()
+            assert own == {gen.CA + 48 + 4 * i for i in range(4)} and not pending
+            # the wait for tile t+1 leaves exactly the pieces of tile t+2 issued before it in flight; no gap holds two memory instructions
+            idx = next(i for i, l in enumerate(full) if l.startswith("s_waitcnt vmcnt"))
+            assert int(re.search(r"vmcnt\((\d+)\)", full[idx]).group(1)) == sum(l.startswith("buffer_load") for l in full[:idx])
+            gap = 0
+            for a, b in zip(full, full[1:]):
+                assert not (a.startswith("s_") and len(a.split()) > 1 and "m0" in a.split()[1] and b.startswith("buffer_load")), (a, b)
+            for l in full:
+                if l.startswith("v_mfma"):
+                    gap = 0
+                elif l.startswith(("ds_read", "buffer_load")):
+                    gap += 1
+                    assert gap <= 1, (wave, l)
+        assert _kinds(gen.tile_chain(0, "tail2", wave))["dma"] == 0 and _kinds(gen.tile_chain(0, "tail2", wave))["read"] == 32
+        last = _kinds(gen.tile_chain(1, "last", wave))
+        assert last == {"mfma": 128, "dma": 0, "read": 4, "barrier": 1}
+    # what must be in registers before a tile starts is exactly what the tile before it (or the prologue) loads ahead
+    first = {int(re.match(r"ds_read_b128 v\[(\d+):", l).group(1)) for l in gen.chain_first_reads(0)}
+    assert first == {gen.CB[0] + 4 * i for i in range(16)} | {gen.CA + 4 * i for i in range(12)}
+    ahead = {int(re.match(r"ds_read_b128 v\[(\d+):", l).group(1)) for l in gen.tile_chain(1, "full", 0) if l.startswith("ds_read")} - {gen.CA + 48 + 4 * i for i in range(4)}
+    assert ahead == first
+    # the first K tile of an output tile starts every accumulator from the constant 0 on its k-step 0 MFMA
+    z = [l for l in gen.tile_chain(0, "full", 0, czero=True) if l.startswith("v_mfma")]
+    assert all(l.endswith(", 0") for l in z[0::2]) and not any(l.endswith(", 0") for l in z[1::2])
 
 
 def test_epilogue_pairs_tiles_and_pads_the_permlane_hazard(gen):
@@ -151,10 +222,12 @@ def test_persistent_body_is_one_stream_over_output_tiles(gen, dtype):
         marks = [i for i, l in enumerate(L) if l.startswith("; ==== wave")] + [L.index("Lklm%=_epilogue:")]
         counts = [sum(l == "s_barrier" for l in L[a:b]) for a, b in zip(marks, marks[1:])]
         assert len(set(counts)) == 1, counts
-    # the epilogue's scratch is fragment set 1 (set 0 already holds the next output tile's first fragments)
+    # the epilogue's scratch is dead by then: fp8 the odd K tiles' A set; bf16 / fp4 (schedule "chain") the B buffer of stage 1 (a unit
+    # ends on a stage-1 tile; the A set and the other B buffer already hold the next output tile's first fragments)
     e = L[L.index("Lklm%=_epilogue:"):]
     regs = {int(m) for l in e if l.startswith("v_accvgpr_read") for m in re.findall(r"v_accvgpr_read_b32 v(\d+)", l)}
-    assert regs and min(regs) >= gen.A1 and max(regs) < gen.A1 + 64
+    lo = gen.A1 if dtype == "fp8" else gen.CB[1]
+    assert regs and min(regs) >= lo and max(regs) < lo + 64
     # a table entry is fetched only while another output tile follows; the kernel ends with its (empty) DMA drained
     assert L[-1] == "s_waitcnt vmcnt(0)" and L[-3] == "Lklm%=_done:"
     for tag in ("first", "loop"):

@@ -6,7 +6,9 @@ Why generated text and not HIP source: with one wave per SIMD there is no partne
 order of the wave's own instruction stream IS the schedule. Written as HIP (gemm_quad128.h: builtins or per-MFMA asm
 statements pinned with sched_barrier) the compiler still decides the waits and the interleave, and that kernel reached
 0.75 MFMA-busy; the vendor's hand-written kernel of the same geometry reaches 0.86 - 0.88. Here every instruction's place
-is fixed. The shipped bf16 / fp4 schedule ("stagger", see SCHEDULES for the others and docs/KERNELS.md for what each measured):
+is fixed. The shipped bf16 / fp4 schedule is "chain" (documented at tile_chain below: a tile's two k-steps back to back on its
+accumulator); the one before it, "stagger", which "chain" took its DMA placement from (see SCHEDULES for the others and
+docs/KERNELS.md for what each measured):
 
   per K tile (stage S, 128 MFMAs; which accumulator tile MFMA i works on: MFMA_ORDER / tile_of_step below), gap = "after MFMA i":
     0, 2, .., 30       the 16 ds_read_b128 of this tile's k-step 1 -> fragment set 1 (A[0], B[0..7], A[1..7])

@@ -1,5 +1,5 @@
-"""Clock, power and energy per GEMM of the streams built with the tile-row-major MFMA order (rounds 2 - 3) and with the zigzag
-order, next to the vendor kernels: both libraries in one process (ctypes), each arm `seconds` without a gap while a thread reads
+"""Clock, power and energy per GEMM of the streams built with the tile-row-major MFMA order (rounds 2 - 3), with the zigzag
+order, and with schedule "chain" on top of it (the tree's build), next to the vendor kernels: both libraries in one process (ctypes), each arm `seconds` without a gap while a thread reads
 the raw amdsmi metrics table (gemm_clock_power.py's method: power = energy accumulator over the table's own clock). The claim to
 check: same cycles per GEMM, fewer joules, hence a higher clock on the 1400 W cap."""
 import ctypes, json, os, sys, threading, time
@@ -22,7 +22,8 @@ one = torch.ones((), device=dev)
 a4 = torch.randint(0, 256, (n, n // 2), device=dev, dtype=torch.uint8, generator=g)
 b4 = torch.randint(0, 256, (n, n // 2), device=dev, dtype=torch.uint8, generator=g)
 libs = {"rows": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/exp/libklm_ops_rows.so")),
-        "zigzag": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/libklm_ops.so"))}
+        "zigzag": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/exp/libklm_ops_zigzag.so")),
+        "chain": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/libklm_ops.so"))}     # the tree's build
 vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 for l in libs.values():
     l.klm_gemm_stream.argtypes, l.klm_gemm_stream.restype = [i, vp, vp, vp, i, i, i, i, i, i, i, vp, sz, vp], i
@@ -33,10 +34,10 @@ def stream(lib, code, x, y, kb):
     return lambda: libs[lib].klm_gemm_stream(code, x.data_ptr(), y.data_ptr(), c.data_ptr(), n, n, kb, 0, 0, 1, 0, None, 0, st)
 
 
-arms = {"bf16_rows": stream("rows", 0, a, b, 2 * n), "bf16_zigzag": stream("zigzag", 0, a, b, 2 * n),
+arms = {"bf16_rows": stream("rows", 0, a, b, 2 * n), "bf16_zigzag": stream("zigzag", 0, a, b, 2 * n), "bf16_chain": stream("chain", 0, a, b, 2 * n),
         "bf16_hipblaslt": lambda: torch.matmul(a, bt, out=c),
-        "fp4_rows": stream("rows", 2, a4, b4, n // 2), "fp4_zigzag": stream("zigzag", 2, a4, b4, n // 2),
-        "fp8_rows": stream("rows", 1, a8, b8, n), "fp8_zigzag": stream("zigzag", 1, a8, b8, n),
+        "fp4_rows": stream("rows", 2, a4, b4, n // 2), "fp4_zigzag": stream("zigzag", 2, a4, b4, n // 2), "fp4_chain": stream("chain", 2, a4, b4, n // 2),
+        "fp8_zigzag": stream("chain", 1, a8, b8, n),
         "fp8_scaled_mm": lambda: torch._scaled_mm(a8, b8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16)}
 
 amdsmi.amdsmi_init()

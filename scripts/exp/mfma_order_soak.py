@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 dev = torch.device("cuda:0")
 seconds = float(os.environ.get("KLM_SOAK_S", "8"))
-libs = {"rows": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/exp/libklm_ops_rows.so")),
+libs = {"rows": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/exp/libklm_ops_%s.so" % os.environ.get("KLM_AB_BASE", "rows"))),
         "tree": ctypes.CDLL(os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib/libklm_ops.so"))}
 vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 for l in libs.values():

@@ -197,16 +197,17 @@ def tile(stage, mode, sched="one_barrier", ablate=(), wave=0, czero=False):
 #   v[232:239] read bases, v240 unit scales, v241.. the persistent kernels' table registers (= the fp8 kernel's numbers)
 # per K tile t in stage S, gap = "after MFMA i" of 128:
 #   0 .. 3          A rows 6, 7 of tile t itself (their registers were busy to the end of tile t-1)
-#   6               s_waitcnt lgkmcnt(0); s_barrier       every wave has read ALL of stage S (30 gaps earlier than "stagger")
-#   9 + 5 p + w     LDS-DMA piece p of tile t+2 -> stage S, wave w one gap later each (as "stagger"); M0 one gap before
-#   56              s_waitcnt vmcnt(pieces issued so far); s_barrier      tile t+1 landed (97 gaps after its last piece)
+#   9               s_waitcnt lgkmcnt(0); s_barrier       every wave has read ALL of stage S (27 gaps earlier than "stagger"; at gap 6,
+#                   three MFMAs behind the last read, the wait came before an LDS read returns: 0.2 - 0.7 % slower, chain_free_gap.json)
+#   12 + 5 p + w    LDS-DMA piece p of tile t+2 -> stage S, wave w one gap later each (as "stagger"); M0 one gap before
+#   56              s_waitcnt vmcnt(pieces issued so far); s_barrier      tile t+1 landed (94 gaps after its last piece)
 #   57 ..           B[0..7] x 2 k-steps of tile t+1 -> the other B buffer, then A rows 0 - 1 and 2 - 3 of tile t+1 (their row pairs are
 #                   done at 31 / 63), one read per gap, DMA gaps skipped; A rows 4 - 5 from gap 96 on
 #   126             s_waitcnt lgkmcnt(0)
 CA = 40
 CB = (104, 168)
 CRB, CSCALE, TBL_CHAIN = 232, 240, 241
-CHAIN_FREE, CHAIN_DMA0, CHAIN_DMA_STEP, CHAIN_LANDED = 6, 9, 5, 56
+CHAIN_FREE, CHAIN_DMA0, CHAIN_DMA_STEP, CHAIN_LANDED = (int(x) for x in os.environ.get("KLM_GEN_CHAIN", "9,12,5,56").split(","))   # env: experiments
 
 
 def cfrag_a(m, k):

@@ -1,6 +1,9 @@
 """Schedule "chain": where should the stage-free wait sit? The tile reads its own A rows 6 - 7 at gaps 0 - 3 and waits for them
 (and frees the LDS stage) at gap CHAIN_FREE; at 6 the wait comes 3 MFMAs after the last read, earlier than an LDS read returns.
-Builds with (free, first DMA gap, step, landed) = 6,9,5,56 (the tree) / 9,12,5,56 / 12,15,5,58 in one process, alternating."""
+Builds with (free, first DMA gap, step, landed) = 6,9,5,56 (the tree at the time) / 9,12,5,56 / 12,15,5,58 in one process, alternating.
+The two extra libraries: `KLM_GEN_CHAIN=9,12,5,56 python scripts/gen_gemm_quad_asm.py <copy of ops/csrc>/gemm_quad_asm.inc`, then hipcc
+-shared gemm_bf16.hip gemm_mx.hip hbm.hip of that copy into _native/lib/exp/libklm_ops_free9.so (free12 alike). Outcome: 9,12,5,56
+became the default (profiles/r3_prof/chain_free_gap.json)."""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -143,13 +143,23 @@ def _cmd_serve_llm_tp_launch(a, argv: Sequence[str]) -> int:
                    PYTHONUNBUFFERED="1")
         procs.append(subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", *argv], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    stopping = threading.Event()
+
+    def _stop(*_):
+        stopping.set()
+        procs[0].terminate()                                         # rank 0 stops the engine, the others follow it out
+
     for sig in (signal.SIGINT, signal.SIGTERM):
-        signal.signal(sig, lambda *_: procs[0].terminate())          # rank 0 stops the engine, the others follow it out
+        signal.signal(sig, _stop)
     rc = 0
     try:
         # a rank that dies takes the job with it: the others would otherwise wait for it in a collective forever
         while procs[0].poll() is None:
             dead = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() is not None]
+            if stopping.is_set():
+                # a requested stop: a follower may be out before rank 0 is (its exit status 0 is the stop working, not a rank
+                # lost in mid-job); only a rank that FAILS on the way out is reported
+                dead = [d for d in dead if d[1] != 0]
             if dead:
                 print(f"[tp] rank {dead[0][0]} exited with {dead[0][1]} while the job was running: stopping all ranks",
                       file=sys.stderr, flush=True)

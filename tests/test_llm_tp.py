@@ -20,6 +20,36 @@ def free_port() -> int:
 RENDEZVOUS_ERRORS = ("Address already in use", "errno: 98", "Connection refused", "Connection reset by peer", "Broken pipe")
 
 
+def start_tp_server(attempts: int = 2):
+    """`serve-llm --tp 2` on CPU, up and answering /health. The ports (HTTP here, the ranks' rendezvous inside the launcher) are
+    picked free and bound a moment later, so a start that dies on a port somebody else took in between is started once more
+    (nothing else is retried: a server that stays alive and never answers fails the test)."""
+    import time
+    import urllib.request
+    err = ""
+    for _ in range(attempts):
+        port = free_port()
+        p = subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--model", "tiny", "--device", "cpu", "--tp", "2",
+                              "--host", "127.0.0.1", "--port", str(port), "--max-num-seqs", "4", "--max-model-len", "128", "--kv-blocks", "32"],
+                             cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2"), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True)
+        url = f"http://127.0.0.1:{port}"
+        t_end = time.time() + 120
+        while p.poll() is None:
+            try:
+                urllib.request.urlopen(url + "/health", timeout=1).read()
+                return p, url
+            except OSError:
+                if time.time() > t_end:
+                    p.kill()
+                    raise AssertionError("server did not come up")
+                time.sleep(0.3)
+        err = (p.stderr.read() or "")[-1500:]
+        if not any(e in err for e in RENDEZVOUS_ERRORS):
+            break
+    raise AssertionError("server exited during start-up: " + err)
+
+
 def run_ranks(world, args=(), timeout=240, attempts=2):
     """Runs tests/tp_worker.py as `world` processes. The rendezvous port is found by binding and releasing it, which another
     process can win in between: such a start-up failure (and only that) gets a second attempt on a new port."""
@@ -168,21 +198,8 @@ def test_serve_llm_tp_cli_two_cpu_ranks():
     import signal
     import time
     import urllib.request
-    port = free_port()
-    p = subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--model", "tiny", "--device", "cpu", "--tp", "2",
-                          "--host", "127.0.0.1", "--port", str(port), "--max-num-seqs", "4", "--max-model-len", "128", "--kv-blocks", "32"],
-                         cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2"), stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True)
+    p, url = start_tp_server()
     try:
-        url = f"http://127.0.0.1:{port}"
-        t_end = time.time() + 120
-        while True:
-            try:
-                urllib.request.urlopen(url + "/health", timeout=1).read()
-                break
-            except OSError:
-                assert p.poll() is None and time.time() < t_end, "server did not come up"
-                time.sleep(0.3)
         req = urllib.request.Request(url + "/v1/completions", data=json.dumps({"prompt_len": 30, "max_tokens": 5, "seed": 1}).encode(),
                                      headers={"Content-Type": "application/json"})
         out = json.loads(urllib.request.urlopen(req, timeout=60).read())

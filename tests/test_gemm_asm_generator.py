@@ -255,3 +255,27 @@ def test_persistent_body_is_one_stream_over_output_tiles(gen, dtype):
             assert int(m) < 100, l
         for m in re.findall(r"\bv\[?(\d+)", l):
             assert int(m) < 256, l
+
+
+def test_mfma_order_harness_orders_are_permutations():
+    """scripts/exp/gen_mfma_order_exp.py (the register-only loops behind MFMA_ORDER and schedule "chain"): every order visits each
+    of the 64 accumulator tiles once, the zigzags change exactly one source per step, the two-set bodies give every accumulator
+    both k-steps, and the generated file holds one kernel per variant."""
+    spec = importlib.util.spec_from_file_location("gen_mfma_order_exp", os.path.join(ROOT, "scripts", "exp", "gen_mfma_order_exp.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for kind in ("m", "m_snake", "n", "n_snake", "diag", "block2", "zigzag2", "zigzag2n"):
+        o = m.order16(kind)
+        assert sorted(o) == [(a, b) for a in range(8) for b in range(8)], kind
+    for kind in ("zigzag2", "zigzag2n", "m_snake", "n_snake"):
+        o = m.order16(kind)
+        assert all((a[0] != b[0]) + (a[1] != b[1]) == 1 for a, b in zip(o, o[1:])), kind
+    assert all((a[0] != b[0]) and (a[1] != b[1]) for a, b in zip(m.order16("diag"), m.order16("diag")[1:]))
+    for kind in ("ksteps", "dependent", "double_snake", "pairs"):
+        body = m.body16_two_sets(kind)
+        accs = [re.match(r"v_mfma\S+ (a\[\d+:\d+\])", l).group(1) for l in body]
+        assert len(body) == 256 and all(accs.count(a) == 4 for a in set(accs)) and len(set(accs)) == 64     # two halves (A, -A) x two k-steps
+    dep = m.body16_two_sets("dependent")
+    assert all(dep[i].split(",")[0] == dep[i + 1].split(",")[0] for i in range(0, 256, 2))                 # back to back on one accumulator
+    names = [n for n, _ in m.VARIANTS]
+    assert len(names) == len(set(names)) and all(len(l) in (32, 64, 128, 256) for _, l in m.VARIANTS)

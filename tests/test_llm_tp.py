@@ -218,20 +218,8 @@ def test_tp_launcher_stops_the_job_when_a_rank_dies():
     import signal
     import time
     import urllib.request
-    port = free_port()
-    p = subprocess.Popen([sys.executable, "-m", "k8s_llm_monitor_amd", "serve-llm", "--model", "tiny", "--device", "cpu", "--tp", "2",
-                          "--host", "127.0.0.1", "--port", str(port), "--max-num-seqs", "4", "--max-model-len", "128", "--kv-blocks", "32"],
-                         cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2"), stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True)
+    p, _ = start_tp_server()
     try:
-        t_end = time.time() + 120
-        while True:
-            try:
-                urllib.request.urlopen(f"http://127.0.0.1:{port}/health", timeout=1).read()
-                break
-            except OSError:
-                assert p.poll() is None and time.time() < t_end, "server did not come up"
-                time.sleep(0.3)
         # find rank 1 among the launcher's children and kill exactly that process
         kids = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()
         assert len(kids) == 2, kids

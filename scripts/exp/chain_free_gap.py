@@ -10,7 +10,10 @@ sys.path.insert(0, ROOT)
 import torch
 dev = torch.device("cuda:0")
 L = os.path.join(ROOT, "k8s_llm_monitor_amd/_native/lib")
-libs = {"free6_tree": ctypes.CDLL(L + "/libklm_ops.so"), "free9": ctypes.CDLL(L + "/exp/libklm_ops_free9.so"), "free12": ctypes.CDLL(L + "/exp/libklm_ops_free12.so")}
+# KLM_CHAIN_LIBS: names of other builds under _native/lib/exp (a later sweep: the landed gap and the DMA spacing)
+libs = {"free6_tree": ctypes.CDLL(L + "/libklm_ops.so")}
+for _n in os.environ.get("KLM_CHAIN_LIBS", "free9,free12").split(","):
+    libs[_n] = ctypes.CDLL(L + f"/exp/libklm_ops_{_n}.so")
 vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 for l in libs.values():
     l.klm_gemm_stream.argtypes, l.klm_gemm_stream.restype = [i, vp, vp, vp, i, i, i, i, i, i, i, vp, sz, vp], i

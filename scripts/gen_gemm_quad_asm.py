@@ -202,7 +202,7 @@ def tile(stage, mode, sched="one_barrier", ablate=(), wave=0, czero=False):
 #   12 + 5 p + w    LDS-DMA piece p of tile t+2 -> stage S, wave w one gap later each (as "stagger"); M0 one gap before
 #   56              s_waitcnt vmcnt(pieces issued so far); s_barrier      tile t+1 landed (94 gaps after its last piece)
 #   57 ..           B[0..7] x 2 k-steps of tile t+1 -> the other B buffer, then A rows 0 - 1 and 2 - 3 of tile t+1 (their row pairs are
-#                   done at 31 / 63), one read per gap, DMA gaps skipped; A rows 4 - 5 from gap 96 on
+#                   done at 31 / 63), one read per gap, DMA gaps skipped; A rows 4 - 5 from gap 95 on (their pair is done at 95)
 #   126             s_waitcnt lgkmcnt(0)
 CA = 40
 CB = (104, 168)

@@ -210,6 +210,9 @@ CRB, CSCALE, TBL_CHAIN = 232, 240, 241
 CHAIN_FREE, CHAIN_DMA0, CHAIN_DMA_STEP, CHAIN_LANDED = (int(x) for x in os.environ.get("KLM_GEN_CHAIN", "9,12,5,56").split(","))   # env: experiments
 
 
+CHAIN_SLEEP = int(os.environ.get("KLM_GEN_CHAIN_SLEEP", "0"))      # experiments only: s_sleep N (64 N cycles) at gap 110 of every K tile
+
+
 def cfrag_a(m, k):
     b = CA + 4 * (2 * m + k)
     return f"v[{b}:{b + 3}]"
@@ -276,6 +279,9 @@ def tile_chain(stage, mode, wave=0, czero=False):
             g += 1
         assert g <= 126, g
         after[126].append("s_waitcnt lgkmcnt(0)")
+    if CHAIN_SLEEP:
+        # EXPERIMENT (scripts/exp/idle_cycles_on_the_cap.py): idle cycles in every K tile -- on a power-capped card, does the clock pay them back?
+        after[110].append(f"s_sleep {CHAIN_SLEEP}")
     for i in range(128):
         out.append(mfma_chain(i, stage, czero))
         out += after[i]

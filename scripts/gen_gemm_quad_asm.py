@@ -692,7 +692,9 @@ def body_fp8(**kw):
 # macro suffix -> (schedule, ablations, dtype). SHIPPED: the bodies libklm_ops.so and klm_burner are built from. DIAGNOSTIC: earlier
 # placements kept for the A/B record and streams with parts of the loop removed (they keep a GEMM's timing, not its result);
 # generated only with --diag and compiled only under -DKLM_GEMM_DIAG (scripts/exp/build_exp.sh), never into the shipped library.
-SHIPPED = {"": ("chain", (), "bf16"), "_FP4": ("chain", (), "fp4"), "_FP8": ("fp8", (), "fp8"),
+# KLM_GEN_SCHEDULE=stagger (with KLM_GEN_MFMA_ORDER=rows|zigzag) regenerates the bf16 / fp4 streams of earlier states for A/B builds
+BF16_SCHEDULE = os.environ.get("KLM_GEN_SCHEDULE", "chain")
+SHIPPED = {"": (BF16_SCHEDULE, (), "bf16"), "_FP4": (BF16_SCHEDULE, (), "fp4"), "_FP8": ("fp8", (), "fp8"),
            # _ST: C stored with `sc1 nt` (written through, not kept): for shapes whose operands just fit the 256 MB Infinity Cache
            "_P_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "bf16"), "_P_FP4_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp4"),
            "_P_FP8_ST": ("persistent", ("stcache:sc1", "stcache:nt"), "fp8"),
@@ -717,7 +719,7 @@ def main():
         f.write("// GENERATED by scripts/gen_gemm_quad_asm.py%s -- do not edit; the schedules are documented there.\n" % (" --diag" if diag else ""))
         for suffix, (sched, ablate, dtype) in (DIAGNOSTIC if diag else SHIPPED).items():
             if sched == "persistent":
-                lines = body_p(dtype, ablate=ablate)
+                lines = body_p(dtype, ablate=ablate) if diag else body_p(dtype, sched=BF16_SCHEDULE, ablate=ablate)
             else:
                 lines = body_fp8(**dict(ablate)) if dtype == "fp8" else body(sched, ablate, dtype=dtype)
             f.write(f"#define KLM_QUAD_ASM_BODY{suffix} \\\n")

@@ -149,6 +149,10 @@ def vendor_comparison(torch, ops, dev, size: int, rounds: int = 5, iters: int = 
         out["hbm"] = hbm_vendor_comparison(torch, ops, dev)
     except Exception as e:
         out["hbm"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        out["step_energy"] = step_energy_comparison(torch, ops, dev, size)
+    except Exception as e:
+        out["step_energy"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -172,6 +176,68 @@ def step_vendor_comparison(torch, ops, dev, size: int, rounds: int = 3, steps: i
                 runs[name].append(st.flops * steps / (e0.elapsed_time(e1) * 1e-3) / 1e12)
     med = {k: round(sorted(v)[len(v) // 2], 1) for k, v in runs.items()}
     return {"tflops_median": med, "klm_over_hipblaslt": round(med["klm"] / med["hipblaslt"], 4)}
+
+
+def step_energy_comparison(torch, ops, dev, size: int, seconds: float = 3.5, settle_s: float = 1.0) -> Dict[str, Any]:
+    """Joules per training step of the hand-written kernels and of hipBLASLt, from the card's own energy accumulator. The card
+    runs this load on its power cap, so energy per step IS the rate; the figure says why one side is faster. Each arm runs
+    without a gap for `seconds`; power = energy accumulator over the metrics table's OWN firmware clock between the first table
+    refresh after `settle_s` and the last one (both numbers come from the same snapshot, so the ~1 s refresh period of the table
+    costs no accuracy); J per step = that power x the step time measured with HIP events over the same window."""
+    import threading
+    from ..collectors.gpu import open_gpu_source
+    from ..models.linear_step import LinearLayerStep
+    from . import phases as _ph
+    src = open_gpu_source("amdsmi")
+    try:
+        idx = _ph._smi_index_for(torch, dev, src)
+        arms = {"klm": LinearLayerStep(torch, None, ops, dev, 1, size),
+                "hipblaslt": LinearLayerStep(torch, None, ops, dev, 1, size, gemm=lambda a, b, out: torch.matmul(a, b.t(), out=out))}
+        out: Dict[str, Any] = {"seconds_per_arm": seconds, "unit": "J per step (fwd + dgrad + wgrad)"}
+        for name, st in arms.items():
+            rows: List[Any] = []
+            stop = threading.Event()
+
+            def watch():
+                while not stop.is_set():
+                    g = _ph._gpu_sample(src, idx)
+                    if g and g.get("energyJ") is not None and g.get("metricsTableTimeS") is not None:
+                        rows.append((time.perf_counter(), float(g["energyJ"]), float(g["metricsTableTimeS"])))
+                    stop.wait(0.15)
+            st.step()
+            torch.cuda.synchronize()
+            th = threading.Thread(target=watch, daemon=True)
+            t0 = time.perf_counter()
+            th.start()
+            marks = []
+            while time.perf_counter() - t0 < seconds:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    st.step()
+                e1.record()
+                e1.synchronize()
+                marks.append((time.perf_counter() - t0, e0.elapsed_time(e1) / 10.0))
+            stop.set()
+            th.join(2.0)
+            late = [r for r in rows if r[0] - t0 >= settle_s]
+            tables = [r for i, r in enumerate(late) if i == 0 or r[2] != late[i - 1][2]]           # one row per refresh of the table
+            ms = [m for t, m in marks if t >= settle_s]
+            if len(tables) < 2 or tables[-1][2] <= tables[0][2] or not ms:
+                out[name] = {"error": f"{len(tables)} table refreshes in the window"}
+                continue
+            watts = (tables[-1][1] - tables[0][1]) / (tables[-1][2] - tables[0][2])
+            step_ms = sum(ms) / len(ms)
+            out[name] = {"power_w": round(watts, 1), "ms_per_step": round(step_ms, 4), "joule_per_step": round(watts * step_ms * 1e-3, 4),
+                         "tflops": round(st.flops / (step_ms * 1e-3) / 1e12, 1), "table_refreshes": len(tables)}
+        if "joule_per_step" in out.get("klm", {}) and "joule_per_step" in out.get("hipblaslt", {}):
+            out["klm_over_hipblaslt_joules"] = round(out["klm"]["joule_per_step"] / out["hipblaslt"]["joule_per_step"], 4)
+        return out
+    finally:
+        try:
+            src.close()
+        except Exception:
+            pass
 
 
 def hbm_vendor_comparison(torch, ops, dev, gib: int = 2, rounds: int = 3, iters: int = 10) -> Dict[str, Any]:
@@ -203,7 +269,7 @@ def hbm_vendor_comparison(torch, ops, dev, gib: int = 2, rounds: int = 3, iters:
 
 
 #: what the sections around the timed region cost (seconds, one MI355X), for the time budget
-SECTION_COST_S = {"dp_kernel": 4.0, "probe": 10.0, "xgmi": 15.0, "other_kernels": 25.0, "llm_serving": 30.0}
+SECTION_COST_S = {"dp_kernel": 4.0, "probe": 10.0, "xgmi": 15.0, "other_kernels": 35.0, "llm_serving": 30.0}
 
 
 def _rehearsal_validation(spec: str, budget) -> Dict[str, Any]:
@@ -612,6 +678,13 @@ def compact(result: Dict[str, Any], detail: str = "") -> Dict[str, Any]:
     for k in ("bf16_klm_over_hipblaslt", "fp8_klm_over_scaled_mm"):
         if k in vc:
             line[k] = vc[k]
+    se = vc.get("step_energy") or {}
+    if "joule_per_step" in (se.get("klm") or {}):
+        line["joule_per_step"] = se["klm"]["joule_per_step"]
+        if "joule_per_step" in (se.get("hipblaslt") or {}):
+            line["joule_per_step_hipblaslt"] = se["hipblaslt"]["joule_per_step"]
+    if isinstance(vc.get("training_step"), dict) and "klm_over_hipblaslt" in vc["training_step"]:
+        line["step_klm_over_hipblaslt"] = vc["training_step"]["klm_over_hipblaslt"]
     if "wall_seconds" in result:
         line["wall_total_s"] = result["wall_seconds"].get("total")
     if detail:

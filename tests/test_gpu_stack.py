@@ -266,3 +266,21 @@ def test_product_overhead_leg_samples_at_least_four_times(torch_dev):
     assert r["sampler_stats"]["on"]["clients"]["errors"] == 0 and r["sampler_stats"]["on"]["clients"]["sse_events"] >= 1
     assert r["overhead"]["n"] == 2 and r["overhead"]["ci95_pct"] is not None
     assert abs(r["overhead_pct"]) < 3.0 and abs(r["overhead_gpu_side_pct"]) < 3.0, r
+
+
+def test_step_energy_comparison_reads_joules_per_step(torch_dev):
+    """bench.py's energy block: joules per training step of this repo's kernels and of hipBLASLt from the card's energy accumulator
+    (power over the metrics table's own clock x the step time): both arms measured, on the power cap, and consistent with the rates."""
+    torch, dev = torch_dev
+    from k8s_llm_monitor_amd import ops
+    from k8s_llm_monitor_amd.validation import benchlib
+    r = benchlib.step_energy_comparison(torch, ops, dev, 8192, seconds=3.5)
+    for arm in ("klm", "hipblaslt"):
+        a = r[arm]
+        assert "error" not in a, r
+        assert 900.0 < a["power_w"] < 1500.0 and a["table_refreshes"] >= 2
+        assert a["joule_per_step"] == pytest.approx(a["power_w"] * a["ms_per_step"] * 1e-3, rel=1e-3)
+        assert a["tflops"] == pytest.approx(6 * 8192 ** 3 / (a["ms_per_step"] * 1e-3) / 1e12, rel=1e-3)
+    # same power on both sides, so the ratio of joules is the ratio of step times; and this repo's step is not the costlier one
+    assert r["klm_over_hipblaslt_joules"] == pytest.approx(r["klm"]["joule_per_step"] / r["hipblaslt"]["joule_per_step"], rel=1e-3)
+    assert r["klm_over_hipblaslt_joules"] < 1.02

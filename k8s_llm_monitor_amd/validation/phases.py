@@ -560,7 +560,12 @@ def power_temperature(torch, dev, src, smi_idx: int, idle_s: float = 2.0, burn_s
                    "power_avg_w": None if r["power_avg_w"] is None else round(r["power_avg_w"], 1), "temperature": r["temperature"],
                    "clock_gfx_mhz": r["clock_gfx_mhz"]} for r in trace[::max(1, int(hz / 2))]]}
     if temps and t_idle is not None:
-        rise = max(temps) - t_idle
+        # the rise is taken from the LOWEST reading before the load took hold (idle window and the first sample under load), not
+        # from the idle mean: when a loaded phase (or test) ran just before, the card is still cooling through the idle window,
+        # the mean sits 2 - 4 C above the point the load starts from, and a real 6 C rise read as 4 (third hardware run of round 3)
+        base = min([r["temperature"] for r in idle if r["temperature"] is not None] + temps[:1])
+        rise = max(temps) - base
+        res["temperature_baseline_c"] = base
         res["temperature_rise_c"] = rise
         res["temperature_monotonic"] = bool(worst_drop <= 2.0 and temps[-1] >= temps[0])
         res["temperature_follows_load"] = bool(rise >= 3.0 and t_cool_min is not None and t_cool_min <= max(temps) - 2.0)

@@ -248,6 +248,9 @@ def test_power_gauge_agrees_with_the_energy_accumulator_and_temperature_follows_
     src = open_gpu_source("amdsmi")
     try:
         idx = phases._smi_index_for(torch, dev, src)
+        # the tests before this one load the card: let it cool for a few seconds, so that the 9 s burn has a rise to show on any
+        # box (one with good cooling showed 1.75 C from a still-warm start)
+        time.sleep(6.0)
         r = phases.power_temperature(torch, dev, src, idx, idle_s=1.0, burn_s=9.0, cool_s=3.0, steady_after_s=5.0)
     finally:
         src.close()
